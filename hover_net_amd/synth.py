@@ -1,0 +1,71 @@
+"""Synthetic workloads of the shapes BASELINE.json names (pure numpy, no torch).
+
+* `synth_tiles`     -- uint8 RGB network input patches (seeded noise).
+* `synth_pred_maps` -- structured `[type?, p, h, v]` prediction maps the way a trained
+  HoVer-Net emits them: random, partly overlapping elliptical nuclei, `p` high inside,
+  `h`/`v` the per-instance horizontal/vertical distance maps in [-1, 1] (semantics of
+  /root/reference/models/hovernet/targets.py:63-93), plus noise.  These give the
+  post-processing a realistic instance load independent of any weights.
+"""
+import numpy as np
+
+
+def synth_tiles(n, size=270, seed=1):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, 256, size=(n, size, size, 3), dtype=np.uint8)
+
+
+def _one_map(rng, H, W, nr_types, k_lo, k_hi, noise):
+    inst = np.zeros((H, W), np.int32)
+    k = int(rng.integers(k_lo, k_hi + 1))
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    for i in range(1, k + 1):
+        cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+        ra, rb = rng.uniform(4, 12), rng.uniform(4, 12)
+        th = rng.uniform(0, np.pi)
+        c, s = np.cos(th), np.sin(th)
+        u = (xx - cx) * c + (yy - cy) * s
+        v = -(xx - cx) * s + (yy - cy) * c
+        m = (u / ra) ** 2 + (v / rb) ** 2 <= 1.0
+        inst[m] = i  # later nuclei overwrite earlier ones -> touching instances
+    hmap = np.zeros((H, W), np.float64)
+    vmap = np.zeros((H, W), np.float64)
+    tmap = np.zeros((H, W), np.float64)
+    for i in range(1, k + 1):
+        m = inst == i
+        if not m.any():
+            continue
+        ys, xs = np.nonzero(m)
+        dx = xs - np.round(xs.mean())
+        dy = ys - np.round(ys.mean())
+        if dx.min() < 0:
+            dx[dx < 0] /= -dx.min()
+        if dx.max() > 0:
+            dx[dx > 0] /= dx.max()
+        if dy.min() < 0:
+            dy[dy < 0] /= -dy.min()
+        if dy.max() > 0:
+            dy[dy > 0] /= dy.max()
+        hmap[ys, xs] = dx
+        vmap[ys, xs] = dy
+        if nr_types:
+            tmap[ys, xs] = 1 + (i % (nr_types - 1))
+    mask = inst > 0
+    p = 0.9 * mask + 0.05 + rng.normal(0, noise, (H, W))
+    hmap = hmap + rng.normal(0, noise, (H, W))
+    vmap = vmap + rng.normal(0, noise, (H, W))
+    chans = [p, hmap, vmap]
+    if nr_types:
+        flip = rng.uniform(size=(H, W)) < 0.05  # some mis-typed pixels
+        tmap = np.where(flip, rng.integers(0, nr_types, (H, W)), tmap)
+        chans = [tmap] + chans
+    return np.stack(chans, -1).astype(np.float32), inst
+
+
+def synth_pred_maps(n, H=80, W=80, nr_types=None, seed=0, k_lo=5, k_hi=40, noise=0.02):
+    """-> (pred [n,H,W,3|4] float32, painted instance maps [n,H,W] int32)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    scale = (H * W) / 6400.0
+    lo, hi = max(1, int(k_lo * scale)), max(1, int(k_hi * scale))
+    maps, insts = zip(*[_one_map(rng, H, W, nr_types, lo, hi, noise) for _ in range(n)])
+    return np.stack(maps), np.stack(insts)

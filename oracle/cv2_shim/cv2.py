@@ -1,0 +1,56 @@
+"""Stand-in `cv2` module -- TEST INFRASTRUCTURE ONLY (golden-vector generation).
+
+OpenCV is not installed on the build box.  To run the reference's own, unmodified
+models/hovernet/post_proc.py (under /opt/conda/bin/python3.9, which has real scipy
+and scikit-image) this module supplies the cv2 entry points that file touches
+(post_proc.py:49-54,56-57,59-68,76,83-84), implemented by the C restatement in
+oracle/hvn_oracle.c.  The scipy / skimage / numpy parts of the golden vectors are
+therefore the real thing; the cv2 parts are the restatement (parity unpinned).
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import postproc as _o  # noqa: E402  (oracle/postproc.py)
+
+NORM_MINMAX = 32
+CV_8U, CV_32F, CV_64F = 0, 5, 6
+MORPH_OPEN = 2
+MORPH_ELLIPSE = 2
+RETR_TREE = 3
+CHAIN_APPROX_SIMPLE = 2
+COLOR_BGR2RGB = 4
+
+
+def normalize(src, dst=None, alpha=0, beta=1, norm_type=NORM_MINMAX, dtype=CV_32F):
+    assert norm_type == NORM_MINMAX and alpha == 0 and beta == 1 and dtype == CV_32F
+    if src.dtype == np.float32:
+        return _o.normalize_32f(src)
+    assert src.dtype == np.float64
+    return _o.normalize_64f32f(src)
+
+
+def Sobel(src, ddepth, dx, dy, ksize=3):
+    assert ddepth == CV_64F and ksize == 21 and src.dtype == np.float32
+    assert (dx, dy) in ((1, 0), (0, 1))
+    return _o.sobel21(src, dx)
+
+
+def GaussianBlur(src, ksize, sigmaX):
+    assert tuple(ksize) == (3, 3) and sigmaX == 0 and src.dtype == np.float64
+    return _o.gauss3_64f(src)
+
+
+def getStructuringElement(shape, ksize):
+    assert shape == MORPH_ELLIPSE and tuple(ksize) == (5, 5)
+    return np.array(
+        [[0, 0, 1, 0, 0], [1] * 5, [1] * 5, [1] * 5, [0, 0, 1, 0, 0]], np.uint8
+    )
+
+
+def morphologyEx(src, op, kernel):
+    assert op == MORPH_OPEN and src.dtype == np.uint8
+    assert np.array_equal(kernel, getStructuringElement(MORPH_ELLIPSE, (5, 5)))
+    return _o.morph_open5(src)
