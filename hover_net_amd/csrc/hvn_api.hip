@@ -1,0 +1,187 @@
+// hvn_api.hip -- the C ABI (include/hvn.h) over the kernels: descriptor validation,
+// plan execution, error text, optional per-launch timing of the conv kernel.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/hvn.h"
+#include "hvn_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *a = "", long b = 0)
+{
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+extern "C" {
+
+int hvn_version(void) { return 100; }
+
+const char *hvn_last_error(void) { return g_err; }
+
+int hvn_device_ok(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ---- profiling of CONV launches (bench.py's roofline leg) -------------------------------
+static bool g_prof = false;
+static std::vector<hipEvent_t> g_ev;   // pairs
+static size_t g_ev_used = 0;
+
+int hvn_profile_enable(int on)
+{
+    g_prof = on != 0;
+    g_ev_used = 0;
+    return 0;
+}
+
+static void prof_mark(hipStream_t s)
+{
+    if (g_ev_used == g_ev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_ev.push_back(e);
+    }
+    hipEventRecord(g_ev[g_ev_used++], s);
+}
+
+double hvn_profile_conv_ms(void)
+{
+    if (g_ev_used < 2) return -1.0;
+    hipEventSynchronize(g_ev[g_ev_used - 1]);
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < g_ev_used; i += 2) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]);
+        total += ms;
+    }
+    return total;
+}
+
+int hvn_profile_conv_launches(void) { return (int)(g_ev_used / 2); }
+
+// ---- one op ---------------------------------------------------------------------------------
+static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int run_one(const hvn_op *op, int batch, hipStream_t s)
+{
+    switch (op->kind) {
+    case HVN_OP_CONV0: {
+        Conv0Args a;
+        a.img = op->x.base;
+        a.isn = op->x.sn; a.isy = op->x.sy; a.isx = op->x.sx; a.isc = op->x.sc ? op->x.sc : 1;
+        a.is_f32 = op->x_dtype;
+        a.H = op->x.h; a.W = op->x.w;
+        a.w = op->w; a.bias = op->bias;
+        a.y = (float *)op->y.base;
+        a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
+        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.pad = op->pad_t;
+        if (op->kh != 7 || op->kw != 7 || op->x.c != 3 || op->y.c != 64 || !op->w || !op->bias)
+            return fail(HVN_E_ARG, "conv0: expects 7x7x3->64 with bias%s", "");
+        if (!aligned16(a.y) || (a.ysx & 3) || (a.ysy & 3) || (a.ysn & 3)) return fail(HVN_E_ARG, "conv0: output view not 16-byte aligned%s", "");
+        return hvn_launch_conv0(a, s);
+    }
+    case HVN_OP_CONV: {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = (const float *)op->x.base;
+        a.xsn = op->x.sn; a.xsy = op->x.sy; a.xsx = op->x.sx;
+        a.H = op->x.h; a.W = op->x.w; a.Cin = op->x.c;
+        a.w = op->w; a.bias = op->bias;
+        a.pre_s = op->pre_scale; a.pre_b = op->pre_shift;
+        a.post_s = op->post_scale; a.post_b = op->post_shift;
+        a.res = (const float *)op->res.base;
+        a.rsn = op->res.sn; a.rsy = op->res.sy; a.rsx = op->res.sx;
+        a.y = (float *)op->y.base;
+        a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
+        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.Cout = op->cout;
+        a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_t = op->pad_t; a.pad_l = op->pad_l;
+        a.relu = op->relu;
+        a.M = (long)batch * a.Ho * a.Wo;
+        if (!a.x || !a.w || !a.y) return fail(HVN_E_ARG, "conv: null pointer%s", "");
+        if (a.Cin % 32) return fail(HVN_E_ARG, "conv: input channels must be a multiple of 32 (got %s%ld)", "", a.Cin);
+        if (!aligned16(a.x) || !aligned16(a.w) || (a.xsx & 3) || (a.xsy & 3) || (a.xsn & 3))
+            return fail(HVN_E_ARG, "conv: input view / weights not 16-byte aligned%s", "");
+        if ((a.pre_s && !aligned16(a.pre_s)) || (a.pre_b && !aligned16(a.pre_b)) || (!a.pre_s != !a.pre_b))
+            return fail(HVN_E_ARG, "conv: prologue vectors must be 16-byte aligned and come in pairs%s", "");
+        if (!a.post_s != !a.post_b) return fail(HVN_E_ARG, "conv: epilogue affine must come in pairs%s", "");
+        if (op->y.c != op->cout) return fail(HVN_E_ARG, "conv: output view channels != cout%s", "");
+        if (g_prof) prof_mark(s);
+        int rc = hvn_launch_conv(a, op->tile_n, s);
+        if (g_prof) prof_mark(s);
+        if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "conv: launch failed (tile_n=%s%ld)", "", op->tile_n);
+        return 0;
+    }
+    case HVN_OP_UPADD: {
+        UpAddArgs a;
+        a.lo = (const float *)op->x.base;
+        a.lsn = op->x.sn; a.lsy = op->x.sy; a.lsx = op->x.sx;
+        a.skip = (const float *)op->res.base;
+        a.ssn = op->res.sn; a.ssy = op->res.sy; a.ssx = op->res.sx;
+        a.y = (float *)op->y.base;
+        a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
+        a.N = batch; a.H = op->y.h; a.W = op->y.w; a.C = op->y.c;
+        if (!a.lo || !a.skip || !a.y) return fail(HVN_E_ARG, "upadd: null pointer%s", "");
+        if (op->x.h * 2 != a.H || op->x.w * 2 != a.W || op->res.h != a.H || op->res.w != a.W || op->x.c != a.C || op->res.c != a.C)
+            return fail(HVN_E_ARG, "upadd: shape mismatch%s", "");
+        if (!aligned16(a.lo) || !aligned16(a.skip) || !aligned16(a.y) || ((a.lsx | a.lsy | a.lsn | a.ssx | a.ssy | a.ssn | a.ysx | a.ysy | a.ysn) & 3))
+            return fail(HVN_E_ARG, "upadd: views not 16-byte aligned%s", "");
+        return hvn_launch_upadd(a, s);
+    }
+    case HVN_OP_HEAD: {
+        HeadArgs a;
+        a.x = (const float *)op->x.base;
+        a.xsn = op->x.sn; a.xsy = op->x.sy; a.xsx = op->x.sx;
+        a.w = op->w; a.bias = op->bias;
+        a.y = (float *)op->y.base;
+        a.N = batch; a.H = op->x.h; a.W = op->x.w; a.Cout = op->cout;
+        if (op->x.c != 64 || !a.w || !a.bias || !a.x || !a.y) return fail(HVN_E_ARG, "head: expects 64 input channels, weights and bias%s", "");
+        if (!aligned16(a.x) || ((a.xsx | a.xsy | a.xsn) & 3)) return fail(HVN_E_ARG, "head: input view not 16-byte aligned%s", "");
+        return hvn_launch_head(a, s);
+    }
+    case HVN_OP_PREDMAP: {
+        PredMapArgs a;
+        a.np = (const float *)op->x.base;
+        a.hv = (const float *)op->res.base;
+        a.tp = op->w;
+        a.y = (float *)op->y.base;
+        a.N = batch; a.H = op->y.h; a.W = op->y.w; a.nr_types = op->cout;
+        if (!a.np || !a.hv || !a.y || (a.nr_types > 0 && !a.tp)) return fail(HVN_E_ARG, "predmap: null pointer%s", "");
+        if (a.nr_types > 0 && !aligned16(a.y)) return fail(HVN_E_ARG, "predmap: output not 16-byte aligned%s", "");
+        return hvn_launch_predmap(a, s);
+    }
+    default:
+        return fail(HVN_E_ARG, "unknown op kind %s%ld", "", op->kind);
+    }
+}
+
+int hvn_run_op(const hvn_op *op, int batch, void *stream)
+{
+    if (!op || batch <= 0) return fail(HVN_E_ARG, "run_op: bad arguments%s", "");
+    int rc = run_one(op, batch, (hipStream_t)stream);
+    if (rc == -2) return fail(HVN_E_LAUNCH, "launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int hvn_run_plan(const hvn_op *ops, int n_ops, int batch, void *stream)
+{
+    if (!ops || n_ops <= 0 || batch <= 0) return fail(HVN_E_ARG, "run_plan: bad arguments%s", "");
+    if (g_prof) g_ev_used = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        int rc = run_one(&ops[i], batch, (hipStream_t)stream);
+        if (rc == -2) return fail(HVN_E_LAUNCH, "launch failed at op %s%ld", "", i);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

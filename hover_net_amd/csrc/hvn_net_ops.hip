@@ -1,0 +1,170 @@
+// hvn_net_ops.hip -- the non-GEMM launches of the network plan (HBM-bound byte movers).
+//
+//   conv0    /root/reference/models/hovernet/net_desc.py:27-35,103 : uint8 image -> 7x7x3
+//            conv (1/255 and BN folded) + ReLU.  K = 147 is too thin for the matrix cores;
+//            done on the VALU with the taps streamed through the scalar cache (they are
+//            wave-uniform), the uint8 patch staged once in LDS.
+//   upadd    net_utils.py:284-294 + net_desc.py:133,136,139 : nearest 2x upsample + skip add
+//   head     net_desc.py:62-68 u0.conv : 64 -> {2..} logits + bias, written NCHW
+//   predmap  run_desc.py:185-194 : softmax(np)[1], argmax(softmax(tp)), concat
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvn_kernels.h"
+
+// ---------------------------------------------------------------------------------------
+#define C0_T 16              // output tile edge
+#define C0_P (C0_T + 6)      // patch edge
+template <typename T>
+__global__ __launch_bounds__(256) void hvn_conv0(const Conv0Args p)
+{
+    __shared__ float patch[C0_P][C0_P * 3 + 2];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * C0_T, ox0 = blockIdx.x * C0_T;
+    const T *img = (const T *)p.img + (long)n * p.isn;
+    for (int i = tid; i < C0_P * C0_P * 3; i += 256) {
+        const int py = i / (C0_P * 3), pr = i - py * (C0_P * 3);
+        const int px = pr / 3, ch = pr - px * 3;
+        const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = (float)img[(long)iy * p.isy + (long)ix * p.isx + (long)ch * p.isc];
+        patch[py][pr] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) acc[c] = p.bias[c];
+    for (int r = 0; r < 7; ++r) {
+        const float *prow = &patch[ty + r][tx * 3];
+        for (int s3 = 0; s3 < 21; ++s3) {
+            const float v = prow[s3];
+            const float *__restrict__ wp = p.w + (r * 21 + s3) * 64;  // wave-uniform -> s_load
+#pragma unroll
+            for (int c = 0; c < 64; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < p.Ho && ox < p.Wo) {
+        float *y = p.y + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4)
+            *(float4 *)(y + c) = make_float4(fmaxf(acc[c], 0.f), fmaxf(acc[c + 1], 0.f), fmaxf(acc[c + 2], 0.f), fmaxf(acc[c + 3], 0.f));
+    }
+}
+
+int hvn_launch_conv0(const Conv0Args &a, hipStream_t stream)
+{
+    dim3 grid((a.Wo + C0_T - 1) / C0_T, (a.Ho + C0_T - 1) / C0_T, a.N);
+    if (a.is_f32)
+        hipLaunchKernelGGL(hvn_conv0<float>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(hvn_conv0<uint8_t>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hvn_upadd(const UpAddArgs p, long total4)
+{
+    const int c4n = p.C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        long t = i / c4n;
+        const int x = (int)(t % p.W);
+        t /= p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const float4 a = *(const float4 *)(p.lo + (long)n * p.lsn + (long)(y >> 1) * p.lsy + (long)(x >> 1) * p.lsx + c4 * 4);
+        const float4 b = *(const float4 *)(p.skip + (long)n * p.ssn + (long)y * p.ssy + (long)x * p.ssx + c4 * 4);
+        *(float4 *)(p.y + (long)n * p.ysn + (long)y * p.ysy + (long)x * p.ysx + c4 * 4) =
+            make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+int hvn_launch_upadd(const UpAddArgs &a, hipStream_t stream)
+{
+    if (a.C % 4) return -1;
+    const long total4 = (long)a.N * a.H * a.W * (a.C / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(hvn_upadd, dim3((unsigned)blocks), dim3(256), 0, stream, a, total4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hvn_head(const HeadArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % p.W);
+    long t = i / p.W;
+    const int y = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
+    float v[64];
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+        const float4 q = *(const float4 *)(src + c);
+        v[c] = q.x;
+        v[c + 1] = q.y;
+        v[c + 2] = q.z;
+        v[c + 3] = q.w;
+    }
+    const long plane = (long)p.H * p.W;
+    float *dst = p.y + (long)n * p.Cout * plane + (long)y * p.W + x;
+    for (int co = 0; co < p.Cout; ++co) {
+        const float *__restrict__ w = p.w + co * 64;  // uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc = fmaf(v[c], w[c], acc);
+        dst[co * plane] = acc + p.bias[co];
+    }
+}
+
+int hvn_launch_head(const HeadArgs &a, hipStream_t stream)
+{
+    const long total = (long)a.N * a.H * a.W;
+    hipLaunchKernelGGL(hvn_head, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hvn_predmap(const PredMapArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long plane = (long)p.H * p.W;
+    const long n = i / plane, pix = i - n * plane;
+    const float l0 = p.np[(n * 2) * plane + pix], l1 = p.np[(n * 2 + 1) * plane + pix];
+    // torch softmax: exp(x - max) / sum
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float prob = e1 / (e0 + e1);
+    const float h = p.hv[(n * 2) * plane + pix], v = p.hv[(n * 2 + 1) * plane + pix];
+    if (p.nr_types > 0) {
+        // argmax(softmax(tp)) == argmax(tp) (softmax is monotone); first maximum wins like torch.argmax
+        int best = 0;
+        float bv = p.tp[(n * p.nr_types) * plane + pix];
+        for (int t = 1; t < p.nr_types; ++t) {
+            const float q = p.tp[(n * p.nr_types + t) * plane + pix];
+            if (q > bv) {
+                bv = q;
+                best = t;
+            }
+        }
+        *(float4 *)(p.y + i * 4) = make_float4((float)best, prob, h, v);
+    } else {
+        float *y = p.y + i * 3;
+        y[0] = prob;
+        y[1] = h;
+        y[2] = v;
+    }
+}
+
+int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream)
+{
+    const long total = (long)a.N * a.H * a.W;
+    hipLaunchKernelGGL(hvn_predmap, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

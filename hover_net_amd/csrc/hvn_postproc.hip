@@ -1,0 +1,755 @@
+// hvn_postproc.hip -- HoVer-Net instance separation on the GPU, batched over tiles.
+//
+// Stands behind /root/reference/models/hovernet/post_proc.py:26-90 (__proc_np_hv) and the
+// third-party arithmetic it calls (cv2.normalize / Sobel / GaussianBlur / morphologyEx,
+// scipy.ndimage label / binary_fill_holes, skimage watershed); the operation ORDER of every
+// floating-point stage is the one pinned by oracle/hvn_oracle.c, so results are bit-identical
+// (labels included).  Compiled with -ffp-contract=off: the only fused multiply-adds are the
+// explicit fma()/fmaf() calls.
+//
+// All stages are HBM/latency-bound byte movers over [n][H*W] planes; one launch handles all
+// n tiles (blockIdx.y = tile).  Connected components use a lock-free union-find with
+// atomicMin (root = smallest raster index, which is also what makes scipy's raster-order
+// label numbering a prefix count of root flags).  The marker-controlled watershed is
+// skimage's global priority flood, whose tie order depends on its binary-heap layout
+// (SURVEY.md Appendix B): it is replayed exactly, one tile per workgroup, lane 0 driving the
+// heap (in LDS when the tile's heap fits, else in HBM scratch); parallelism comes from the
+// tiles of the batch.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "../../include/hvn.h"
+
+#define PP_T 256
+
+// ---------------------------------------------------------------------------------------------
+// ordered-integer encodings for atomic min/max of floats / doubles
+__device__ __forceinline__ unsigned f2o(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(unsigned u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ unsigned long long d2o(double d)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double o2d(unsigned long long u)
+{
+    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+
+// cv::borderInterpolate(BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// OpenCV normalize(NORM_MINMAX, 0, 1, CV_32F) coefficients (oracle: hvn_o_norm_coeffs)
+__device__ __forceinline__ void norm_coeffs(double smin, double smax, float *a, float *b)
+{
+    double scale = 1.0 * ((smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0.);
+    scale = (double)(float)scale;
+    double shift = (double)((float)0.0 - (float)(smin * scale));
+    *a = (float)scale;
+    *b = (float)shift;
+}
+
+// per-tile reduction slots
+struct TileStat {
+    unsigned h_min, h_max, v_min, v_max;               // ordered-uint of float32
+    unsigned long long sh_min, sh_max, sv_min, sv_max;  // ordered-u64 of float64 sobel
+    int n_marker_roots;
+    int _pad;
+};
+
+struct PPBuf {
+    int n, H, W, C, c0;
+    long P;  // H*W
+    const float *pred;
+    int32_t *inst;
+    // planes of n*P elements
+    int32_t *blb, *par, *cnt, *mk, *par2, *lab;
+    float *hraw, *vraw;
+    double *rowh, *rowv, *sobh, *sobv, *overall, *dist, *blur;
+    uint8_t *m8a, *m8b;
+    TileStat *stat;
+    // watershed scratch
+    unsigned long long *heap;  // 2 x u64 per item, n*P items
+};
+
+// ---------------------------------------------------------------------------------------------
+// union-find on a plane (indices local to the tile)
+__device__ __forceinline__ int uf_load(const int32_t *par, int i)
+{
+    return __hip_atomic_load(par + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(const int32_t *par, int i)
+{
+    int p;
+    while ((p = uf_load(par, i)) != i) i = p;
+    return i;
+}
+__device__ void uf_union(int32_t *par, int a, int b)
+{
+    for (;;) {
+        a = uf_find(par, a);
+        b = uf_find(par, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        int old = atomicMin(par + a, b);  // attach the larger root under the smaller
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// K1: threshold, planar copies of h / v, min/max of h and v, union-find init
+__global__ __launch_bounds__(PP_T) void pp_init(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    float h = 0.f, v = 0.f;
+    const bool in = i < b.P;
+    if (in) {
+        const float *p = b.pred + ((long)n * b.P + i) * b.C + b.c0;
+        const int fg = p[0] >= 0.5f;  // post_proc.py:43
+        h = p[1];
+        v = p[2];
+        const long g = (long)n * b.P + i;
+        b.blb[g] = fg;
+        b.par[g] = fg ? (int)i : -1;
+        b.cnt[g] = 0;
+        b.hraw[g] = h;
+        b.vraw[g] = v;
+    }
+    unsigned hmin = in ? f2o(h) : 0xffffffffu, hmax = in ? f2o(h) : 0u;
+    unsigned vmin = in ? f2o(v) : 0xffffffffu, vmax = in ? f2o(v) : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+        hmin = min(hmin, (unsigned)__shfl_xor((int)hmin, o));
+        hmax = max(hmax, (unsigned)__shfl_xor((int)hmax, o));
+        vmin = min(vmin, (unsigned)__shfl_xor((int)vmin, o));
+        vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        TileStat *s = b.stat + n;
+        atomicMin(&s->h_min, hmin);
+        atomicMax(&s->h_max, hmax);
+        atomicMin(&s->v_min, vmin);
+        atomicMax(&s->v_max, vmax);
+    }
+}
+
+// generic CCL stages over a binary plane encoded in par (>=0 : foreground)
+__global__ __launch_bounds__(PP_T) void pp_ccl_merge(int32_t *par_all, int H, int W, long P)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= P) return;
+    int32_t *par = par_all + (long)n * P;
+    if (uf_load(par, (int)i) < 0) return;
+    const int y = (int)(i / W), x = (int)(i - (long)y * W);
+    if (x > 0 && uf_load(par, (int)i - 1) >= 0) uf_union(par, (int)i, (int)i - 1);
+    if (y > 0 && uf_load(par, (int)i - W) >= 0) uf_union(par, (int)i, (int)i - W);
+}
+
+__global__ __launch_bounds__(PP_T) void pp_ccl_flatten_count(int32_t *par_all, int32_t *cnt_all, long P)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= P) return;
+    int32_t *par = par_all + (long)n * P;
+    if (par[i] < 0) return;
+    const int r = uf_find(par, (int)i);
+    par[i] = r;  // racing writers all store a valid ancestor; the final state is the root
+    if (cnt_all) atomicAdd(cnt_all + (long)n * P + r, 1);
+}
+
+// K4: remove_small_objects(min_size=10) on the blob mask (post_proc.py:46-47) + prepare nothing else
+__global__ __launch_bounds__(PP_T) void pp_blb_filter(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const long g = (long)n * b.P + i;
+    const int r = b.par[g];
+    b.blb[g] = (r >= 0 && b.cnt[(long)n * b.P + uf_find(b.par + (long)n * b.P, r)] >= 10) ? 1 : 0;
+}
+
+// K6: Sobel-21 row pass of both maps (h: derivative taps, v: smoothing taps) on the
+// min-max-normalised inputs (post_proc.py:49-57), float64 accumulation in tap order
+__constant__ double c_kd[21] = {-1, -18, -152, -798, -2907, -7752, -15504, -23256, -25194, -16796, 0,
+                                16796, 25194, 23256, 15504, 7752, 2907, 798, 152, 18, 1};
+__constant__ double c_ks[21] = {1, 20, 190, 1140, 4845, 15504, 38760, 77520, 125970, 167960, 184756,
+                                167960, 125970, 77520, 38760, 15504, 4845, 1140, 190, 20, 1};
+
+__global__ __launch_bounds__(PP_T) void pp_sobel_row(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const TileStat *s = b.stat + n;
+    float ha, hb, va, vb;
+    norm_coeffs((double)o2f(s->h_min), (double)o2f(s->h_max), &ha, &hb);
+    norm_coeffs((double)o2f(s->v_min), (double)o2f(s->v_max), &va, &vb);
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    const float *hr = b.hraw + (long)n * b.P + (long)y * b.W;
+    const float *vr = b.vraw + (long)n * b.P + (long)y * b.W;
+    double sh = 0., sv = 0.;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) {
+        const int xx = reflect101(x - 10 + k, b.W);
+        const double hn = (double)fmaf(hr[xx], ha, hb);
+        const double vn = (double)fmaf(vr[xx], va, vb);
+        if (k == 0) {
+            sh = c_kd[0] * hn;
+            sv = c_ks[0] * vn;
+        } else {
+            sh += c_kd[k] * hn;
+            sv += c_ks[k] * vn;
+        }
+    }
+    b.rowh[(long)n * b.P + i] = sh;
+    b.rowv[(long)n * b.P + i] = sv;
+}
+
+// K7: column pass (h: symmetric smoothing, v: antisymmetric derivative) + min/max of both
+__global__ __launch_bounds__(PP_T) void pp_sobel_col(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    const bool in = i < b.P;
+    double sh = 0., sv = 0.;
+    if (in) {
+        const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+        const double *rh = b.rowh + (long)n * b.P + x;
+        const double *rv = b.rowv + (long)n * b.P + x;
+        sh = c_ks[10] * rh[(long)y * b.W] + 0.0;
+        sv = 0.0;
+#pragma unroll
+        for (int k = 1; k <= 10; ++k) {
+            const long ya = (long)reflect101(y + k, b.H) * b.W, yb = (long)reflect101(y - k, b.H) * b.W;
+            sh = fma(c_ks[10 + k], rh[ya] + rh[yb], sh);
+            sv = fma(c_kd[10 + k], rv[ya] - rv[yb], sv);
+        }
+        b.sobh[(long)n * b.P + i] = sh;
+        b.sobv[(long)n * b.P + i] = sv;
+    }
+    unsigned long long hmin = in ? d2o(sh) : ~0ull, hmax = in ? d2o(sh) : 0ull;
+    unsigned long long vmin = in ? d2o(sv) : ~0ull, vmax = in ? d2o(sv) : 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        hmin = min(hmin, (unsigned long long)__shfl_xor((long long)hmin, o));
+        hmax = max(hmax, (unsigned long long)__shfl_xor((long long)hmax, o));
+        vmin = min(vmin, (unsigned long long)__shfl_xor((long long)vmin, o));
+        vmax = max(vmax, (unsigned long long)__shfl_xor((long long)vmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        TileStat *s = b.stat + n;
+        atomicMin(&s->sh_min, hmin);
+        atomicMax(&s->sh_max, hmax);
+        atomicMin(&s->sv_min, vmin);
+        atomicMax(&s->sv_max, vmax);
+    }
+}
+
+// K8: 1 - normalize(sobel) (64f->32f), overall, dist (post_proc.py:59-74)
+__global__ __launch_bounds__(PP_T) void pp_combine(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const TileStat *s = b.stat + n;
+    float ha, hb, va, vb;
+    norm_coeffs(o2d(s->sh_min), o2d(s->sh_max), &ha, &hb);
+    norm_coeffs(o2d(s->sv_min), o2d(s->sv_max), &va, &vb);
+    const long g = (long)n * b.P + i;
+    const float nh = (float)fma(b.sobh[g], (double)ha, (double)hb);
+    const float nv = (float)fma(b.sobv[g], (double)va, (double)vb);
+    const float a = 1.0f - nh, c = 1.0f - nv;
+    const float m = a > c ? a : c;  // np.maximum
+    const int blb = b.blb[g];
+    double ov = (double)m - (double)(1 - blb);
+    if (ov < 0) ov = 0;
+    b.overall[g] = ov;
+    b.dist[g] = (1.0 - ov) * (double)blb;
+}
+
+// K9/K10: GaussianBlur 3x3 sigma 0 in float64 (post_proc.py:76), then the marker mask
+// (post_proc.py:78-81) and the union-find init of its BACKGROUND for binary_fill_holes
+__global__ __launch_bounds__(PP_T) void pp_gauss_row(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    const double *S = b.dist + (long)n * b.P + (long)y * b.W;
+    double s = 0.25 * S[reflect101(x - 1, b.W)];
+    s += 0.5 * S[x];
+    s += 0.25 * S[reflect101(x + 1, b.W)];
+    b.rowh[(long)n * b.P + i] = s;
+}
+
+__global__ __launch_bounds__(PP_T) void pp_gauss_col_marker(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    const double *R = b.rowh + (long)n * b.P + x;
+    double s = 0.5 * R[(long)y * b.W] + 0.0;
+    const double a = R[(long)reflect101(y + 1, b.H) * b.W], c = R[(long)reflect101(y - 1, b.H) * b.W];
+    s = fma(0.25, a + c, s);
+    const long g = (long)n * b.P + i;
+    b.blur[g] = -s;
+    const int ovb = b.overall[g] >= 0.4;
+    int m = b.blb[g] - ovb;
+    m = m < 0 ? 0 : m;
+    b.mk[g] = m;
+    b.par2[g] = m ? -1 : (int)i;  // background pixels form the union-find
+}
+
+// K11: binary_fill_holes: background components that do not reach the border are holes
+__global__ __launch_bounds__(PP_T) void pp_border_flag(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    if (y != 0 && x != 0 && y != b.H - 1 && x != b.W - 1) return;
+    const int r = b.par2[(long)n * b.P + i];
+    if (r >= 0) b.cnt[(long)n * b.P + r] = 1;  // cnt doubles as "component touches the border"
+}
+
+__global__ __launch_bounds__(PP_T) void pp_fill(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const long g = (long)n * b.P + i;
+    const int r = b.par2[g];
+    b.m8a[g] = (r < 0 || b.cnt[(long)n * b.P + r] == 0) ? 1 : 0;
+}
+
+// K12: MORPH_OPEN with the 5x5 ellipse 00100/11111x3/00100; pixels outside the image never
+// win the min (erode) nor the max (dilate)
+__device__ __forceinline__ bool ell5(int j, int i) { return (j != -2 && j != 2) || i == 0; }
+
+__global__ __launch_bounds__(PP_T) void pp_erode(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    const uint8_t *s = b.m8a + (long)n * b.P;
+    uint8_t m = 255;
+    for (int j = -2; j <= 2; ++j)
+        for (int k = -2; k <= 2; ++k) {
+            if (!ell5(j, k)) continue;
+            const int yy = y + j, xx = x + k;
+            if (yy < 0 || yy >= b.H || xx < 0 || xx >= b.W) continue;
+            const uint8_t v = s[(long)yy * b.W + xx];
+            if (v < m) m = v;
+        }
+    b.m8b[(long)n * b.P + i] = m;
+}
+
+__global__ __launch_bounds__(PP_T) void pp_dilate_init(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    const uint8_t *s = b.m8b + (long)n * b.P;
+    uint8_t m = 0;
+    for (int j = -2; j <= 2; ++j)
+        for (int k = -2; k <= 2; ++k) {
+            if (!ell5(j, k)) continue;
+            const int yy = y + j, xx = x + k;
+            if (yy < 0 || yy >= b.H || xx < 0 || xx >= b.W) continue;
+            const uint8_t v = s[(long)yy * b.W + xx];
+            if (v > m) m = v;
+        }
+    const long g = (long)n * b.P + i;
+    b.par[g] = m ? (int)i : -1;  // union-find over the opened marker (post_proc.py:85)
+    b.cnt[g] = 0;
+}
+
+// K13: scipy.ndimage.label numbering = 1 + number of component roots earlier in raster order
+// (root = first pixel of its component).  One workgroup per tile, chunked block scan.
+__global__ __launch_bounds__(1024) void pp_rank_roots(PPBuf b)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t *par = b.par + (long)n * b.P;
+    int32_t *lab = b.lab + (long)n * b.P;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (long base = 0; base < b.P; base += 1024) {
+        const long i = base + tid;
+        const int flag = (i < b.P && par[i] == (int)i) ? 1 : 0;
+        int v = flag;
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) wsum[wv] = v;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (i < b.P) lab[i] = flag ? off + v : 0;  // inclusive count = 1-based label at roots
+        __syncthreads();
+        if (tid == 1023) carry = off + v;
+        __syncthreads();
+    }
+}
+
+// marker labels after remove_small_objects(10) (post_proc.py:86); labels are NOT renumbered
+__global__ __launch_bounds__(PP_T) void pp_marker_labels(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const long g = (long)n * b.P + i;
+    const int r = b.par[g];
+    int l = 0;
+    if (r >= 0 && b.cnt[(long)n * b.P + r] >= 10) l = b.lab[(long)n * b.P + r];
+    b.mk[g] = l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K14: skimage.segmentation.watershed(dist, markers, mask=blb) replayed exactly.
+// Heap item = {value (double), age<<32 | index}.  Lane 0 of one wave per tile drives it.
+struct HItem {
+    double v;
+    unsigned long long ai;  // age (high 32) | index (low 32)
+};
+__device__ __forceinline__ bool h_smaller(const HItem &a, const HItem &b)
+{
+    if (a.v != b.v) return a.v < b.v;
+    return (a.ai >> 32) < (b.ai >> 32);
+}
+
+template <typename HP>
+__device__ void ws_flood(HP heap, const double *img, const int32_t *mask, int32_t *out, int H, int W)
+{
+    const long P = (long)H * W;
+    int hn = 0;
+    auto push = [&](HItem it) {
+        int child = hn++;
+        while (child > 0) {
+            const int parent = (child + 1) / 2 - 1;
+            HItem pv = heap[parent];
+            if (h_smaller(it, pv)) {
+                heap[child] = pv;
+                child = parent;
+            } else
+                break;
+        }
+        heap[child] = it;
+    };
+    for (long i = 0; i < P; ++i)
+        if (out[i]) push(HItem{img[i], (unsigned long long)(unsigned)i});
+    unsigned age = 0;
+    while (hn) {
+        const HItem top = heap[0];
+        --hn;
+        if (hn > 0) {
+            // move the last element to the root and sift it down (pop of heap_general.pxi)
+            const HItem last = heap[hn];
+            int i = 0;
+            for (;;) {
+                const int l = 2 * i + 1, r = l + 1;
+                if (l >= hn) break;
+                HItem lv = heap[l];
+                int s = i;
+                HItem sv = last;
+                if (h_smaller(lv, last)) {
+                    s = l;
+                    sv = lv;
+                }
+                if (r < hn) {
+                    HItem rv = heap[r];
+                    if (h_smaller(rv, sv)) {
+                        s = r;
+                        sv = rv;
+                    }
+                }
+                if (s == i) break;
+                heap[i] = sv;
+                i = s;
+            }
+            heap[i] = last;
+        }
+        const int idx = (int)(top.ai & 0xffffffffu);
+        const int y = idx / W, x = idx - y * W;
+        const int lab = out[idx];
+        // neighbour order of skimage: -W, -1, +1, +W
+        const int nb[4] = {idx - W, idx - 1, idx + 1, idx + W};
+        const bool ok[4] = {y > 0, x > 0, x < W - 1, y < H - 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int q = nb[k];
+            if (!mask[q] || out[q]) continue;
+            age += 1;
+            out[q] = lab;
+            push(HItem{img[q], ((unsigned long long)age << 32) | (unsigned)q});
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void pp_watershed(PPBuf b, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
+    const int n = blockIdx.x;
+    const long g0 = (long)n * b.P;
+    int32_t *out = b.inst + g0;
+    // out = markers * mask (_watershed.py:84)
+    for (long i = threadIdx.x; i < b.P; i += 64) out[i] = b.blb[g0 + i] ? b.mk[g0 + i] : 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (use_lds)
+        ws_flood((HItem *)ws_smem, b.blur + g0, b.blb + g0, out, b.H, b.W);
+    else
+        ws_flood((HItem *)(b.heap + 2 * g0), b.blur + g0, b.blb + g0, out, b.H, b.W);
+}
+
+// ---------------------------------------------------------------------------------------------
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t carve(PPBuf &b, unsigned char *base, int n, int H, int W)
+{
+    const size_t NP = (size_t)n * H * W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    };
+    b.stat = (TileStat *)take(sizeof(TileStat) * n);
+    b.blb = (int32_t *)take(NP * 4);
+    b.par = (int32_t *)take(NP * 4);
+    b.cnt = (int32_t *)take(NP * 4);
+    b.mk = (int32_t *)take(NP * 4);
+    b.par2 = (int32_t *)take(NP * 4);
+    b.lab = (int32_t *)take(NP * 4);
+    b.hraw = (float *)take(NP * 4);
+    b.vraw = (float *)take(NP * 4);
+    b.rowh = (double *)take(NP * 8);
+    b.rowv = (double *)take(NP * 8);
+    b.sobh = (double *)take(NP * 8);
+    b.sobv = (double *)take(NP * 8);
+    b.overall = (double *)take(NP * 8);
+    b.dist = (double *)take(NP * 8);
+    b.blur = (double *)take(NP * 8);
+    b.m8a = (uint8_t *)take(NP);
+    b.m8b = (uint8_t *)take(NP);
+    b.heap = (unsigned long long *)take(NP * 16);
+    return off;
+}
+
+__global__ void pp_stat_init(TileStat *s, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i].h_min = s[i].v_min = 0xffffffffu;
+    s[i].h_max = s[i].v_max = 0u;
+    s[i].sh_min = s[i].sv_min = ~0ull;
+    s[i].sh_max = s[i].sv_max = 0ull;
+    s[i].n_marker_roots = 0;
+}
+
+static thread_local char pp_err[256] = "";
+const char *hvn_pp_last_error() { return pp_err; }
+
+static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, int32_t *inst, int32_t *tap_blb,
+                         double *tap_dist, int32_t *tap_marker, void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    if (!pred || !inst || n <= 0 || h <= 0 || w <= 0 || c0 < 0 || c0 + 3 > c) return HVN_E_ARG;
+    if ((long)h * w >= (1L << 31)) return HVN_E_ARG;
+    PPBuf b;
+    const size_t need = carve(b, (unsigned char *)workspace, n, h, w);
+    if (!workspace || workspace_bytes < need) return HVN_E_SIZE;
+    b.n = n; b.H = h; b.W = w; b.C = c; b.c0 = c0; b.P = (long)h * w;
+    b.pred = pred; b.inst = inst;
+    const dim3 grid((unsigned)((b.P + PP_T - 1) / PP_T), n), blk(PP_T);
+    hipLaunchKernelGGL(pp_stat_init, dim3((n + 63) / 64), dim3(64), 0, s, b.stat, n);
+    hipLaunchKernelGGL(pp_init, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_ccl_merge, grid, blk, 0, s, b.par, h, w, b.P);
+    hipLaunchKernelGGL(pp_ccl_flatten_count, grid, blk, 0, s, b.par, b.cnt, b.P);
+    hipLaunchKernelGGL(pp_blb_filter, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_sobel_row, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_sobel_col, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_combine, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_gauss_row, grid, blk, 0, s, b);
+    hipMemsetAsync(b.cnt, 0, (size_t)n * b.P * 4, s);
+    hipLaunchKernelGGL(pp_gauss_col_marker, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_ccl_merge, grid, blk, 0, s, b.par2, h, w, b.P);
+    hipLaunchKernelGGL(pp_ccl_flatten_count, grid, blk, 0, s, b.par2, (int32_t *)nullptr, b.P);
+    hipLaunchKernelGGL(pp_border_flag, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_fill, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_erode, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_dilate_init, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(pp_ccl_merge, grid, blk, 0, s, b.par, h, w, b.P);
+    hipLaunchKernelGGL(pp_ccl_flatten_count, grid, blk, 0, s, b.par, b.cnt, b.P);
+    hipLaunchKernelGGL(pp_rank_roots, dim3(n), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(pp_marker_labels, grid, blk, 0, s, b);
+    const size_t heap_bytes = (size_t)b.P * 16;
+    const int use_lds = heap_bytes <= 150 * 1024;
+    if (use_lds) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void *)pp_watershed, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return HVN_E_LAUNCH;
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL(pp_watershed, dim3(n), dim3(64), use_lds ? heap_bytes : 0, s, b, use_lds);
+    const size_t NP = (size_t)n * b.P;
+    if (tap_blb) hipMemcpyAsync(tap_blb, b.blb, NP * 4, hipMemcpyDeviceToDevice, s);
+    if (tap_dist) hipMemcpyAsync(tap_dist, b.blur, NP * 8, hipMemcpyDeviceToDevice, s);
+    if (tap_marker) hipMemcpyAsync(tap_marker, b.mk, NP * 4, hipMemcpyDeviceToDevice, s);
+    return hipGetLastError() == hipSuccess ? HVN_OK : HVN_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-instance table: the array half of post_proc.py:119-181 process() (bbox of
+// misc/utils.py:18-28, cv2.moments m00/m10/m01 of the bbox crop, type majority vote).
+struct InstAcc {
+    int area, rmin, rmax, cmin, cmax, _pad;
+    unsigned long long sx, sy;
+};
+
+__global__ __launch_bounds__(PP_T) void it_init(InstAcc *acc, int32_t *hist, long n_acc, long n_hist)
+{
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i < n_acc) {
+        InstAcc a;
+        a.area = 0; a.rmin = 0x7fffffff; a.rmax = -1; a.cmin = 0x7fffffff; a.cmax = -1; a._pad = 0; a.sx = 0; a.sy = 0;
+        acc[i] = a;
+    }
+    if (i < n_hist) hist[i] = 0;
+}
+
+__global__ __launch_bounds__(PP_T) void it_accumulate(const int32_t *inst, const float *pred, int H, int W, int C,
+                                                      int nr_types, InstAcc *acc, int32_t *hist, int max_inst)
+{
+    const int n = blockIdx.y;
+    const long P = (long)H * W;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= P) return;
+    const int l = inst[(long)n * P + i];
+    if (l <= 0 || l > max_inst) return;
+    const int y = (int)(i / W), x = (int)(i - (long)y * W);
+    InstAcc *a = acc + (long)n * max_inst + (l - 1);
+    atomicAdd(&a->area, 1);
+    atomicMin(&a->rmin, y);
+    atomicMax(&a->rmax, y);
+    atomicMin(&a->cmin, x);
+    atomicMax(&a->cmax, x);
+    atomicAdd(&a->sx, (unsigned long long)x);
+    atomicAdd(&a->sy, (unsigned long long)y);
+    if (nr_types > 0) {
+        int t = (int)pred[((long)n * P + i) * C];  // pred_type.astype(int32), post_proc.py:112
+        if (t >= 0 && t < nr_types) atomicAdd(hist + ((long)n * max_inst + (l - 1)) * nr_types + t, 1);
+    }
+}
+
+__global__ __launch_bounds__(PP_T) void it_finalize(const InstAcc *acc, const int32_t *hist, int nr_types, int max_inst,
+                                                    hvn_inst_rec *rec, int32_t *counts)
+{
+    const int n = blockIdx.y;
+    const int j = blockIdx.x * PP_T + threadIdx.x;
+    if (j >= max_inst) return;
+    const InstAcc a = acc[(long)n * max_inst + j];
+    hvn_inst_rec r;
+    r.label = j + 1;
+    r.area = a.area;
+    r.rmin = a.rmin; r.rmax = a.rmax + 1;  // get_bounding_box: rmax += 1, cmax += 1
+    r.cmin = a.cmin; r.cmax = a.cmax + 1;
+    r.sum_x = (double)(long long)(a.sx - (unsigned long long)a.area * (unsigned long long)(a.area ? a.cmin : 0));
+    r.sum_y = (double)(long long)(a.sy - (unsigned long long)a.area * (unsigned long long)(a.area ? a.rmin : 0));
+    r.type = -1;
+    r.type_count = 0;
+    if (a.area > 0 && nr_types > 0) {
+        // sorted(by count, reverse=True) is stable over np.unique's ascending ids: ties -> smaller id
+        const int32_t *h = hist + ((long)n * max_inst + j) * nr_types;
+        int best = -1, bc = 0, best_nz = -1, bnz = 0, present = 0;
+        for (int t = 0; t < nr_types; ++t) {
+            const int c = h[t];
+            if (c <= 0) continue;
+            ++present;
+            if (c > bc) { bc = c; best = t; }
+            if (t != 0 && c > bnz) { bnz = c; best_nz = t; }
+        }
+        if (best == 0 && present > 1) { best = best_nz; bc = bnz; }  // post_proc.py:173-175
+        r.type = best;
+        r.type_count = bc;
+    }
+    rec[(long)n * max_inst + j] = r;
+    if (a.area > 0) atomicAdd(counts + n, 1);
+}
+
+extern "C" {
+
+size_t hvn_instance_table_workspace_bytes(int n, int max_inst, int nr_types)
+{
+    return align_up((size_t)n * max_inst * sizeof(InstAcc)) + align_up((size_t)n * max_inst * (nr_types > 0 ? nr_types : 1) * 4);
+}
+
+int hvn_instance_table(const int32_t *inst, const float *pred, int n, int h, int w, int c, int nr_types,
+                       hvn_inst_rec *records, int32_t *counts, int max_inst, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (!inst || !records || !counts || n <= 0 || h <= 0 || w <= 0 || max_inst <= 0 || nr_types < 0) return HVN_E_ARG;
+    if (nr_types > 0 && !pred) return HVN_E_ARG;
+    if (!workspace || workspace_bytes < hvn_instance_table_workspace_bytes(n, max_inst, nr_types)) return HVN_E_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    InstAcc *acc = (InstAcc *)workspace;
+    int32_t *hist = (int32_t *)((unsigned char *)workspace + align_up((size_t)n * max_inst * sizeof(InstAcc)));
+    const long n_acc = (long)n * max_inst, n_hist = n_acc * (nr_types > 0 ? nr_types : 1);
+    const long m = n_acc > n_hist ? n_acc : n_hist;
+    hipLaunchKernelGGL(it_init, dim3((unsigned)((m + PP_T - 1) / PP_T)), dim3(PP_T), 0, s, acc, hist, n_acc, n_hist);
+    hipMemsetAsync(counts, 0, (size_t)n * 4, s);
+    const long P = (long)h * w;
+    hipLaunchKernelGGL(it_accumulate, dim3((unsigned)((P + PP_T - 1) / PP_T), n), dim3(PP_T), 0, s, inst, pred, h, w, c,
+                       nr_types, acc, hist, max_inst);
+    hipLaunchKernelGGL(it_finalize, dim3((max_inst + PP_T - 1) / PP_T, n), dim3(PP_T), 0, s, acc, hist, nr_types, max_inst,
+                       records, counts);
+    return hipGetLastError() == hipSuccess ? HVN_OK : HVN_E_LAUNCH;
+}
+
+size_t hvn_postproc_workspace_bytes(int n, int h, int w)
+{
+    PPBuf b;
+    return carve(b, nullptr, n, h, w);
+}
+
+int hvn_postproc(const float *pred, int n, int h, int w, int c, int c0, int32_t *inst, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    return postproc_impl(pred, n, h, w, c, c0, inst, nullptr, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int hvn_postproc_taps(const float *pred, int n, int h, int w, int c, int c0, int32_t *inst, int32_t *blb, double *dist,
+                      int32_t *marker, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return postproc_impl(pred, n, h, w, c, c0, inst, blb, dist, marker, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

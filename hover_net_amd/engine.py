@@ -1,0 +1,157 @@
+"""Binds a launch plan (hover_net_amd.plan) to HBM and runs it through libhvn_hip.so.
+
+torch is used for exactly three things here: allocating device memory, naming the
+current HIP stream, and wrapping the outputs as tensors.  Weights are uploaded once
+(one flat fp32 slab, 256-byte aligned sub-arrays); activations live in one arena of
+`max_batch x arena_per_sample` floats that is re-used by every call (sized for HBM,
+not for reuse in cache: 160 MB/tile -> 5.1 GB at batch 32).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import plan as PL
+
+
+def _view_struct(v, base_ptr, sn, itemsize=4):
+    b = v.buf
+    sx = b.c
+    sy = b.w * b.c
+    s = L.hvn_view()
+    s.base = base_ptr + (v.y0 * sy + v.x0 * sx + v.c0) * itemsize
+    s.sn, s.sy, s.sx = sn, sy, sx
+    s.h, s.w, s.c, s.sc = v.h, v.w, v.c, 1
+    return s
+
+
+class Engine:
+    def __init__(self, plan, max_batch=32, device="cuda"):
+        L.require_gpu()
+        self.plan = plan
+        self.max_batch = int(max_batch)
+        self.device = torch.device(device)
+        self._upload_params()
+        self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32, device=self.device)
+        self.logits = {br: torch.empty((self.max_batch, b.c, b.h, b.w), dtype=torch.float32, device=self.device)
+                       for br, b in plan.logits.items()}
+        self.pred_map = None
+        if plan.pred_map is not None:
+            pm = plan.pred_map
+            self.pred_map = torch.empty((self.max_batch, pm.h, pm.w, pm.c), dtype=torch.float32, device=self.device)
+        self.ops = (L.hvn_op * len(plan.ops))()
+        self._bind()
+
+    # ---------------------------------------------------------------------------------
+    def _upload_params(self):
+        arrays, offs, total = [], {}, 0
+
+        def put(key, a):
+            nonlocal total
+            if a is None:
+                return
+            a = np.ascontiguousarray(a, np.float32).ravel()
+            offs[key] = total
+            arrays.append((total, a))
+            total += (a.size + 63) // 64 * 64
+
+        for i, op in enumerate(self.plan.ops):
+            put((i, "w"), op.w)
+            put((i, "bias"), op.bias)
+            if op.pre is not None:
+                put((i, "pre_s"), op.pre[0])
+                put((i, "pre_b"), op.pre[1])
+            if op.post is not None:
+                put((i, "post_s"), op.post[0])
+                put((i, "post_b"), op.post[1])
+        host = np.zeros(max(total, 64), np.float32)
+        for off, a in arrays:
+            host[off:off + a.size] = a
+        self.params = torch.from_numpy(host).to(self.device)
+        self._poff = offs
+
+    def _pptr(self, i, name):
+        off = self._poff.get((i, name))
+        return None if off is None else self.params.data_ptr() + 4 * off
+
+    def _bind(self):
+        P = self.plan
+        abase = self.arena.data_ptr()
+        sn = P.arena_per_sample
+        for i, op in enumerate(P.ops):
+            o = self.ops[i]
+            o.kind, o.kh, o.kw, o.stride = op.kind, op.kh, op.kw, op.stride
+            o.pad_t, o.pad_l, o.relu, o.cout, o.tile_n, o.x_dtype = op.pad_t, op.pad_l, op.relu, op.cout, op.tile_n, 0
+            if op.kind == PL.OP_PREDMAP:
+                o.x.base = self.logits["np"].data_ptr()
+                o.res.base = self.logits["hv"].data_ptr()
+                o.w = self.logits["tp"].data_ptr() if "tp" in self.logits else None
+                o.cout = P.nr_types or 0
+                o.y.base = self.pred_map.data_ptr()
+                o.y.h, o.y.w, o.y.c = P.pred_map.h, P.pred_map.w, P.pred_map.c
+                continue
+            for fld, v in (("x", op.x), ("res", op.res), ("y", op.y)):
+                if v is None:
+                    continue
+                if v.buf.offset >= 0:
+                    setattr(o, fld, _view_struct(v, abase + 4 * v.buf.offset, sn))
+            if op.kind == PL.OP_CONV0:
+                o.x.h, o.x.w, o.x.c = op.x.h, op.x.w, 3  # base / strides set per call
+            if op.kind == PL.OP_HEAD:
+                br = op.y.buf.name.split(".")[1]
+                o.y.base = self.logits[br].data_ptr()
+                o.y.h, o.y.w, o.y.c = op.y.h, op.y.w, op.y.c
+            o.w = self._pptr(i, "w")
+            o.bias = self._pptr(i, "bias")
+            o.pre_scale, o.pre_shift = self._pptr(i, "pre_s"), self._pptr(i, "pre_b")
+            o.post_scale, o.post_shift = self._pptr(i, "post_s"), self._pptr(i, "post_b")
+
+    # ---------------------------------------------------------------------------------
+    def _set_input(self, imgs):
+        o = self.ops[0]
+        assert self.plan.ops[0].kind == PL.OP_CONV0
+        n = imgs.shape[0]
+        if n > self.max_batch:
+            raise ValueError("batch %d exceeds the engine's max_batch %d" % (n, self.max_batch))
+        g = self.plan.geo["inp"]
+        if imgs.dtype == torch.uint8:       # infer_step hands uint8 NHWC (run_desc.py:176)
+            if tuple(imgs.shape[1:]) != (g, g, 3):
+                raise ValueError("expected uint8 [N,%d,%d,3] patches, got %s" % (g, g, tuple(imgs.shape)))
+            imgs = imgs.contiguous()
+            o.x_dtype = 0
+            o.x.sn, o.x.sy, o.x.sx, o.x.sc = g * g * 3, g * 3, 3, 1
+        elif imgs.dtype == torch.float32:   # HoVerNet.forward contract: float NCHW in 0..255
+            if tuple(imgs.shape[1:]) != (3, g, g):
+                raise ValueError("expected float32 [N,3,%d,%d] images, got %s" % (g, g, tuple(imgs.shape)))
+            imgs = imgs.contiguous()
+            o.x_dtype = 1
+            o.x.sn, o.x.sy, o.x.sx, o.x.sc = 3 * g * g, g, 1, g * g
+        else:
+            raise TypeError("images must be uint8 NHWC or float32 NCHW, got %s" % imgs.dtype)
+        if imgs.device != self.device:
+            imgs = imgs.to(self.device, non_blocking=True)
+        o.x.base = imgs.data_ptr()
+        return imgs, n
+
+    def run_raw(self, n):
+        """Run the bound plan on whatever the arena holds (per-kernel tests: no CONV0 input)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(L.lib().hvn_run_plan(ctypes.addressof(self.ops), len(self.ops), n, ctypes.c_void_p(stream)), "hvn_run_plan")
+
+    def run(self, imgs, upto=None):
+        """imgs: uint8 [N,H,W,3] or float32 [N,3,H,W] -> (logits dict of [N,C,h,w] views, pred_map [N,h,w,3|4] or None).
+        The returned tensors alias engine-owned buffers that the next call overwrites."""
+        imgs, n = self._set_input(imgs)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        n_ops = len(self.ops) if upto is None else upto
+        L.check(L.lib().hvn_run_plan(ctypes.addressof(self.ops), n_ops, n, ctypes.c_void_p(stream)), "hvn_run_plan")
+        self._keepalive = imgs
+        logits = {br: t[:n] for br, t in self.logits.items()}
+        return logits, (None if self.pred_map is None else self.pred_map[:n])
+
+    def buffer(self, view, n):
+        """Test hook: the activation window `view` of the first n samples as a tensor view."""
+        b = view.buf
+        t = self.arena[:n, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
+        return t[:, view.y0:view.y0 + view.h, view.x0:view.x0 + view.w, view.c0:view.c0 + view.c]

@@ -1,0 +1,94 @@
+"""ctypes binding of libhvn_hip.so (include/hvn.h).  No fallback: if the library is
+missing or no gfx950 device is visible, every entry point raises."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhvn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ("hvn_conv.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip")
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fvisibility=hidden", "-Wno-unused-value")
+
+
+class hvn_view(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_void_p), ("sn", ctypes.c_int64), ("sy", ctypes.c_int64), ("sx", ctypes.c_int64),
+                ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("c", ctypes.c_int32), ("sc", ctypes.c_int32)]
+
+
+class hvn_op(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("kind", "kh", "kw", "stride", "pad_t", "pad_l", "relu", "cout", "tile_n", "x_dtype")] + \
+               [("x", hvn_view), ("res", hvn_view), ("y", hvn_view)] + \
+               [(k, ctypes.c_void_p) for k in ("w", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift")]
+
+
+class hvn_inst_rec(ctypes.Structure):
+    _fields_ = [("label", ctypes.c_int32), ("area", ctypes.c_int32), ("rmin", ctypes.c_int32), ("rmax", ctypes.c_int32),
+                ("cmin", ctypes.c_int32), ("cmax", ctypes.c_int32), ("sum_x", ctypes.c_double), ("sum_y", ctypes.c_double),
+                ("type", ctypes.c_int32), ("type_count", ctypes.c_int32)]
+
+
+EXPORTS = (
+    "hvn_version", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
+    "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_postproc_workspace_bytes", "hvn_postproc",
+    "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table",
+)
+
+
+class HvnError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU (seconds)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "hvn_kernels.h"), os.path.join(os.path.dirname(_HERE), "include", "hvn.h")]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", *HIPCC_FLAGS, *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """The loaded library (ctypes.CDLL); raises HvnError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HvnError("libhvn_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HoVer-Net hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.hvn_last_error.restype = ctypes.c_char_p
+        L.hvn_profile_conv_ms.restype = ctypes.c_double
+        L.hvn_postproc_workspace_bytes.restype = ctypes.c_size_t
+        L.hvn_postproc_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.hvn_run_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.hvn_run_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.hvn_postproc.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.hvn_postproc_taps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.hvn_instance_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_void_p]
+        L.hvn_instance_table_workspace_bytes.restype = ctypes.c_size_t
+        L.hvn_instance_table_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HvnError("%s failed (%d): %s" % (what, rc, lib().hvn_last_error().decode()))
+
+
+def require_gpu():
+    if not lib().hvn_device_ok():
+        raise HvnError("no gfx950 (MI355X) device is current; the HoVer-Net hot path has no CPU fallback")

@@ -1,0 +1,113 @@
+"""Drop-in for `models.hovernet.net_desc` (/root/reference/models/hovernet/net_desc.py).
+
+Same public surface -- `create_model(mode, **kwargs)`, `HoVerNet(input_ch, nr_types,
+freeze, mode)` with attributes `.mode .freeze .nr_types .output_ch`, the exact
+`state_dict()` key set / shapes (checked with strict=True by infer/base.py:65-68), and
+`forward(imgs float32 NCHW 0..255) -> OrderedDict(tp?, np, hv)` of raw logits
+(net_desc.py:101-145) -- but the module holds no layer objects: parameters hang off a
+key-shaped tree, and `forward` lowers them once to the fused HIP launch plan
+(`hover_net_amd.plan`) executed by libhvn_hip.so.  There is no torch fallback: without
+the library or off a gfx950 device `forward` raises.
+
+Training-mode forward/backward (run_desc.train_step) is not built yet.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import arch
+
+
+class _Node(nn.Module):
+    """One path component of a checkpoint key ('d0', 'units', '0', 'conv1/bn', ...)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; HoVerNet.forward runs the fused HIP plan")
+
+
+def _attach(root, key, kind, shape, gen):
+    parts = key.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    leaf = parts[-1]
+    if kind in ("conv", "bias", "bn_w", "bn_b"):
+        t = torch.empty(shape, dtype=torch.float32)
+        if kind == "conv":      # Net.weights_init (net_utils.py:18-32): Kaiming normal, fan_out, relu
+            nn.init.kaiming_normal_(t, mode="fan_out", nonlinearity="relu", generator=gen)
+        elif kind == "bias":    # nn.Conv2d default bias init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), fan_in = 64
+            t.uniform_(-0.125, 0.125, generator=gen)
+        elif kind == "bn_w":
+            t.fill_(1.0)
+        else:
+            t.zero_()
+        node.register_parameter(leaf, nn.Parameter(t))
+    elif kind == "bn_rm":
+        node.register_buffer(leaf, torch.zeros(shape))
+    elif kind == "bn_rv":
+        node.register_buffer(leaf, torch.ones(shape))
+    elif kind == "bn_nbt":
+        node.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+    elif kind == "ones":
+        node.register_buffer(leaf, torch.ones(shape))
+    else:  # pragma: no cover
+        raise KeyError(kind)
+
+
+class HoVerNet(nn.Module):
+    """Initialise HoVer-Net (interface of net_desc.py:14-99)."""
+
+    def __init__(self, input_ch=3, nr_types=None, freeze=False, mode="original"):
+        super().__init__()
+        self.mode = mode
+        self.freeze = freeze
+        self.nr_types = nr_types
+        self.output_ch = 3 if nr_types is None else 4
+        assert mode == "original" or mode == "fast", \
+            "Unknown mode `%s` for HoVerNet. Only support `original` or `fast`." % mode
+        if input_ch != 3:
+            raise ValueError("the HIP conv0 kernel is built for 3-channel (RGB) input, got input_ch=%d" % input_ch)
+        for key, (kind, shape) in arch.param_table(mode, nr_types, input_ch).items():
+            _attach(self, key, kind, shape, None)
+        self._engine = None
+        self._engine_key = None
+        self.max_batch = 32
+
+    # -- plan lifetime ---------------------------------------------------------------------
+    def _weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def engine(self, batch):
+        """(Re)lower the checkpoint when the weights changed or a larger batch arrives."""
+        from . import engine as E
+        from . import plan as PL
+
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("HoVerNet runs on MI355X only: call .to('cuda') first (no CPU fallback)")
+        key = (self._weights_version(), str(dev))
+        if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+            plan = PL.build_plan(sd, self.mode, self.nr_types)
+            self._engine = None  # free the old arena first
+            self._engine = E.Engine(plan, max(self.max_batch, batch), dev)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, imgs):
+        if self.training:
+            raise NotImplementedError(
+                "training-mode forward (batch-statistics BN + autograd) is not built in this round; call .eval()")
+        eng = self.engine(imgs.shape[0])
+        logits, _ = eng.run(imgs)
+        # fresh tensors: the engine's buffers are overwritten by the next call
+        return OrderedDict((k, v.clone()) for k, v in logits.items())
+
+
+def create_model(mode=None, **kwargs):
+    if mode not in ["original", "fast"]:
+        assert "Unknown Model Mode %s" % mode
+    return HoVerNet(mode=mode, **kwargs)

@@ -1,0 +1,310 @@
+"""Lowering of a HoVer-Net checkpoint to the fused-kernel launch plan (host logic, numpy only).
+
+The reference executes ~360 separate torch ops per forward
+(/root/reference/models/hovernet/net_desc.py:101-145).  Here the same function is
+lowered ONCE, at checkpoint-load time, to ~150 launches of five kernel kinds over
+channels-last (NHWC) fp32 activations that stay resident in HBM:
+
+  CONV0    uint8 NHWC image -> 7x7 conv (1/255 and BN folded into the taps) + ReLU
+  CONV     implicit-GEMM conv on fp32 MFMA with
+             prologue : relu(x*ps + pb) per input channel   (pre-activation BN that
+                        cannot be folded: its input is a residual sum / a concat)
+             epilogue : + bias (folded BN shift), ReLU, + residual, then optional
+                        relu(y*qs + qb) per output channel   (block-closing BN-ReLU)
+             strided input / output views, so dense-block concats and centre crops
+             are address arithmetic, never copies
+  UPADD    nearest 2x upsample + (cropped) skip add
+  HEAD     1x1 conv to the 2..6 logits (+bias), written NCHW (the forward() contract)
+  PREDMAP  infer_step's softmax / argmax / concat (run_desc.py:185-194)
+
+A plan is pure data (`Plan.ops`, numpy weights, symbolic buffers) so it can be
+interpreted by any executor: the product binds it to device memory and hands it to
+libhvn_hip.so (`hover_net_amd.lib`); the tests interpret the same plan with torch CPU ops
+to prove the lowering itself (folding, crops, concat offsets) against the oracle.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import arch
+
+OP_CONV0, OP_CONV, OP_UPADD, OP_HEAD, OP_PREDMAP = 1, 2, 3, 4, 5
+
+
+@dataclass
+class Buf:
+    name: str
+    h: int
+    w: int
+    c: int
+    dtype: str = "f32"          # per-sample element count = h*w*c
+    offset: int = -1            # per-sample float offset inside the arena, set by Plan.pack()
+    first: int = 10 ** 9
+    last: int = -1
+
+    @property
+    def size(self):
+        return self.h * self.w * self.c
+
+
+@dataclass
+class View:
+    buf: Buf
+    y0: int = 0
+    x0: int = 0
+    h: int = -1
+    w: int = -1
+    c0: int = 0
+    c: int = -1
+
+    def __post_init__(self):
+        if self.h < 0:
+            self.h = self.buf.h - self.y0
+        if self.w < 0:
+            self.w = self.buf.w - self.x0
+        if self.c < 0:
+            self.c = self.buf.c - self.c0
+        assert 0 <= self.y0 and self.y0 + self.h <= self.buf.h
+        assert 0 <= self.x0 and self.x0 + self.w <= self.buf.w
+        assert 0 <= self.c0 and self.c0 + self.c <= self.buf.c
+
+    def crop(self, m):
+        return View(self.buf, self.y0 + m, self.x0 + m, self.h - 2 * m, self.w - 2 * m, self.c0, self.c)
+
+    def chans(self, c0, c):
+        return View(self.buf, self.y0, self.x0, self.h, self.w, self.c0 + c0, c)
+
+
+@dataclass
+class Op:
+    kind: int
+    name: str
+    x: View = None
+    y: View = None
+    res: View = None
+    w: np.ndarray = None        # CONV: [cout_pad, kh*kw, cin]; CONV0: [7,7,3,64]; HEAD: [cout, 64]
+    bias: np.ndarray = None
+    pre: tuple = None           # (scale[cin], shift[cin])
+    post: tuple = None          # (scale[cout], shift[cout])
+    kh: int = 1
+    kw: int = 1
+    stride: int = 1
+    pad_t: int = 0
+    pad_l: int = 0
+    relu: int = 0
+    cout: int = 0
+    tile_n: int = 0
+    extra: dict = field(default_factory=dict)
+
+    def flops(self):
+        if self.kind == OP_CONV:
+            return 2.0 * self.y.h * self.y.w * self.cout * self.kh * self.kw * self.extra.get("cin_real", self.x.c)
+        if self.kind == OP_CONV0:
+            return 2.0 * self.y.h * self.y.w * 64 * 147
+        if self.kind == OP_HEAD:
+            return 2.0 * self.y.h * self.y.w * self.cout * 64
+        return 0.0
+
+
+def _f64(sd, key):
+    v = sd[key]
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v, np.float64)
+
+
+def _bn_affine(sd, key):
+    """BatchNorm2d(eval) as y = x*s + b   (torch semantics, eps 1e-5)."""
+    s = _f64(sd, key + ".weight") / np.sqrt(_f64(sd, key + ".running_var") + arch.BN_EPS)
+    b = _f64(sd, key + ".bias") - _f64(sd, key + ".running_mean") * s
+    return s, b
+
+
+def _tf_same(size, k, s):
+    """TFSamepaddingLayer (net_utils.py:52-63) -> (pad_lo, pad_hi)."""
+    pad = max(k - s, 0) if size % s == 0 else max(k - (size % s), 0)
+    return pad // 2, pad - pad // 2
+
+
+def _tile_n(cout):
+    return 128 if cout >= 128 else (64 if cout >= 64 else 32)
+
+
+def _pack_conv(wt, out_scale=None, groups=1):
+    """[cout, cin/groups, kh, kw] (torch) -> [cout_pad, kh*kw, cin] fp32, BN scale folded in
+    float64, grouped convs expanded to block-diagonal dense."""
+    cout, cin_g, kh, kw = wt.shape
+    if out_scale is not None:
+        wt = wt * out_scale[:, None, None, None]
+    cin = cin_g * groups
+    tn = _tile_n(cout)
+    cout_pad = (cout + tn - 1) // tn * tn
+    packed = np.zeros((cout_pad, kh * kw, cin), np.float64)
+    og = cout // groups
+    for g in range(groups):
+        blk = wt[g * og:(g + 1) * og]                                  # [og, cin_g, kh, kw]
+        packed[g * og:(g + 1) * og, :, g * cin_g:(g + 1) * cin_g] = blk.transpose(0, 2, 3, 1).reshape(og, kh * kw, cin_g)
+    return np.ascontiguousarray(packed, np.float32), tn
+
+
+class Plan:
+    def __init__(self, mode, nr_types):
+        self.mode = mode
+        self.nr_types = nr_types
+        self.geo = arch.geometry(mode)
+        self.ops = []
+        self.bufs = []
+        self.logits = {}        # branch -> Buf (NCHW, c=out_ch)
+        self.pred_map = None    # Buf [h, w, 3|4]
+        self.image = Buf("image", self.geo["inp"], self.geo["inp"], 3, "u8")
+        self.arena_per_sample = 0
+
+    # -- construction helpers -------------------------------------------------
+    def buf(self, name, h, w, c):
+        b = Buf(name, h, w, c)
+        self.bufs.append(b)
+        return b
+
+    def add(self, op):
+        i = len(self.ops)
+        for v in (op.x, op.y, op.res):
+            if v is not None and v.buf.dtype == "f32":
+                v.buf.first = min(v.buf.first, i)
+                v.buf.last = max(v.buf.last, i)
+        for b in op.extra.get("reads", ()):
+            b.first = min(b.first, i)
+            b.last = max(b.last, i)
+        self.ops.append(op)
+        return op
+
+    def conv(self, name, x, y, wt, *, stride=1, pad=(0, 0), bn=None, relu=0, pre=None, res=None, post=None, groups=1, bias=None):
+        s = b = None
+        if bn is not None:
+            s, b = bn
+        w, tn = _pack_conv(wt, s, groups)
+        cout, _cin_g, kh, kw = wt.shape
+        assert x.c == w.shape[2] and y.c == cout, (name, x.c, w.shape, y.c, cout)
+        assert y.h == (x.h + pad[0] + pad[1] - kh) // stride + 1, (name, x.h, y.h)
+        if bias is not None:
+            b = bias if b is None else b + bias
+        op = Op(OP_CONV, name, x=x, y=y, res=res, w=w, kh=kh, kw=kw, stride=stride, pad_t=pad[0], pad_l=pad[0],
+                relu=relu, cout=cout, tile_n=tn)
+        op.bias = None if b is None else np.asarray(b, np.float32)
+        op.pre = None if pre is None else (np.asarray(pre[0], np.float32), np.asarray(pre[1], np.float32))
+        op.post = None if post is None else (np.asarray(post[0], np.float32), np.asarray(post[1], np.float32))
+        op.extra["cin_real"] = x.c // groups
+        return self.add(op)
+
+    # -- memory planning --------------------------------------------------------
+    def pack(self, align=64):
+        """Greedy interval packing of the per-sample activation arena (floats)."""
+        live = [b for b in self.bufs if b.last >= 0]
+        placed = []
+        for b in sorted(live, key=lambda t: -t.size):
+            sz = (b.size + align - 1) // align * align
+            busy = sorted((p.offset, p.offset + (p.size + align - 1) // align * align) for p in placed
+                          if not (p.last < b.first or b.last < p.first))
+            off = 0
+            for lo, hi in busy:
+                if off + sz <= lo:
+                    break
+                off = max(off, hi)
+            b.offset = off
+            placed.append(b)
+        self.arena_per_sample = max((p.offset + (p.size + align - 1) // align * align) for p in placed)
+        return self.arena_per_sample
+
+    def total_flops(self):
+        return sum(o.flops() for o in self.ops)
+
+
+def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
+    """sd: reference-format state_dict (torch tensors or numpy arrays)."""
+    P = Plan(mode, nr_types)
+    g = P.geo
+    k = g["k"]
+    W = lambda key: _f64(sd, key)          # noqa: E731
+    BN = lambda key: _bn_affine(sd, key)   # noqa: E731
+
+    # conv0: /255 and BN folded -> [7,7,3,64] taps, bias, ReLU   (net_desc.py:27-35,103)
+    s, b = BN("conv0.bn")
+    w0 = W("conv0./.weight") * (s / 255.0)[:, None, None, None]
+    d_sz = g["d"]
+    x = P.buf("conv0", d_sz[0], d_sz[0], 64)
+    op = Op(OP_CONV0, "conv0", x=View(P.image), y=View(x), w=np.ascontiguousarray(w0.transpose(2, 3, 1, 0), np.float32),
+            bias=np.asarray(b, np.float32), kh=7, kw=7, pad_t=g["conv0_pad"], pad_l=g["conv0_pad"], relu=1, cout=64)
+    P.add(op)
+    x = View(x)
+
+    # encoder: four pre-activation residual blocks   (net_utils.py:155-266)
+    skips = []
+    for bi, (name, in_ch, (c1, c2, c3), units, stride) in enumerate(arch.RES_BLOCKS):
+        hi, ho = x.h, d_sz[bi]
+        acc = View(P.buf(name + ".sum", ho, ho, c3))
+        P.conv(name + ".shortcut", x, acc, W(name + ".shortcut.weight"), stride=stride)
+        cur = x
+        for i in range(units):
+            p = "%s.units.%d." % (name, i)
+            st = stride if i == 0 else 1
+            t1 = View(P.buf(p + "t1", cur.h, cur.w, c1))
+            P.conv(p + "conv1", cur, t1, W(p + "conv1.weight"), bn=BN(p + "conv1/bn"), relu=1,
+                   pre=None if i == 0 else BN(p + "preact/bn"))
+            t2 = View(P.buf(p + "t2", ho, ho, c2))
+            P.conv(p + "conv2", t1, t2, W(p + "conv2.weight"), stride=st, pad=_tf_same(t1.h, 3, st),
+                   bn=BN(p + "conv2/bn"), relu=1)
+            last = i == units - 1
+            out = View(P.buf(name + ".out", ho, ho, c3)) if last else acc
+            P.conv(p + "conv3", t2, out, W(p + "conv3.weight"), res=acc,
+                   post=BN(name + ".blk_bna.bn") if last else None)
+            cur = acc
+        x = out
+        skips.append(out)
+        del hi
+    d3 = View(P.buf("conv_bot", d_sz[3], d_sz[3], 1024))
+    P.conv("conv_bot", skips[3], d3, W("conv_bot.weight"))
+
+    # decoder: the u3 input is branch-independent (net_desc.py:133) -> computed once
+    u3in = View(P.buf("u3.in", d_sz[2], d_sz[2], 1024))
+    P.add(Op(OP_UPADD, "u3.upadd", x=d3, res=skips[2], y=u3in))
+    d1c = skips[1].crop(g["crop1"])
+    d0c = skips[0].crop(g["crop0"])
+    cm = (k - 1) // 2
+    heads = {}
+    for br in arch.branch_names(nr_types):
+        pb = "decoder.%s." % br
+        cur_in = u3in
+        for uname, cmid, units, cat_sz, skip in (("u3", 256, 8, g["u3_cat"], d1c), ("u2", 128, 4, g["u2_cat"], d0c)):
+            p = pb + uname + "."
+            ctot = cmid + units * arch.DENSE_GROWTH
+            cat = View(P.buf(p + "cat", cat_sz, cat_sz, ctot))
+            P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
+            c = cmid
+            win = cat
+            for i in range(units):
+                q = p + "dense.units.%d." % i
+                t1 = View(P.buf(q + "t1", win.h, win.w, arch.DENSE_MID))
+                P.conv(q + "conv1", win.chans(0, c), t1, W(q + "conv1.weight"), bn=BN(q + "conv1/bn"), relu=1,
+                       pre=BN(q + "preact_bna/bn"))
+                win = win.crop(cm)          # crop_to_shape + cat (net_utils.py:147-148) == shrink the window
+                P.conv(q + "conv2", t1, win.chans(c, arch.DENSE_GROWTH), W(q + "conv2.weight"), groups=arch.DENSE_GROUPS)
+                c += arch.DENSE_GROWTH
+            uo = View(P.buf(p + "out", win.h, win.w, ctot))
+            P.conv(p + "convf", win.chans(0, ctot), uo, W(p + "convf.weight"), pre=BN(p + "dense.blk_bna.bn"))
+            nxt = View(P.buf(p + "up", 2 * win.h, 2 * win.w, ctot))
+            P.add(Op(OP_UPADD, p + "upadd", x=uo, res=skip, y=nxt))
+            cur_in = nxt
+        u1 = View(P.buf(pb + "u1", g["out"], g["out"], 64))
+        P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
+               bn=BN(pb + "u0.bn"), relu=1)
+        oc = arch.branch_out_ch(br, nr_types)
+        lg = Buf("logits." + br, g["out"], g["out"], oc)
+        P.logits[br] = lg
+        heads[br] = P.add(Op(OP_HEAD, pb + "u0.conv", x=u1, y=View(lg),
+                             w=np.ascontiguousarray(W(pb + "u0.conv.weight").reshape(oc, 64), np.float32),
+                             bias=np.asarray(W(pb + "u0.conv.bias"), np.float32), cout=oc))
+    if with_predmap:
+        pm = Buf("pred_map", g["out"], g["out"], 3 if nr_types is None else 4)
+        P.pred_map = pm
+        P.add(Op(OP_PREDMAP, "infer_step.epilogue", y=View(pm), extra={"branches": list(arch.branch_names(nr_types))}))
+    P.pack()
+    return P

@@ -1,0 +1,128 @@
+"""Drop-in for `models.hovernet.post_proc.process`
+(/root/reference/models/hovernet/post_proc.py:94-186) on the GPU.
+
+* `process(pred_map, nr_types=None, return_centroids=False)` keeps the reference's
+  signature and return contract `(pred_inst int32 [H,W], inst_info_dict | None)` for one
+  host map; it is a thin wrapper over the batched device path.
+* `process_batch_device(pred_dev, nr_types)` is the north-star path: `[N,h,w,3|4]` float32
+  maps already in HBM (straight from `run_desc.infer_step_device`) -> int32 instance maps
+  and the per-instance table in HBM, no CPU round trip per tile.
+
+Instance separation (`__proc_np_hv`, post_proc.py:26-90) and the array half of the
+per-instance loop (bbox / centroid / type vote, post_proc.py:119-181) are HIP kernels in
+libhvn_hip.so.  Contour tracing (`cv2.findContours`, post_proc.py:132-135) is not built yet:
+`contour` is None in the returned dict.  No CPU fallback exists.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+class PostProc:
+    """Owns the device workspace for `n` maps of `h x w` (grown on demand)."""
+
+    def __init__(self, device="cuda"):
+        L.require_gpu()
+        self.device = torch.device(device)
+        self._ws = None
+        self._tws = None
+
+    def _workspace(self, n, h, w):
+        need = L.lib().hvn_postproc_workspace_bytes(n, h, w)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def separate(self, pred, taps=False):
+        """pred: float32 device tensor [N,h,w,3|4] -> int32 device tensor [N,h,w]
+        (+ (blb, dist, marker) stage taps when taps=True)."""
+        assert pred.dtype == torch.float32 and pred.dim() == 4 and pred.is_cuda
+        pred = pred.contiguous()
+        n, h, w, c = pred.shape
+        if c not in (3, 4):
+            raise ValueError("prediction map must have 3 ([p,h,v]) or 4 ([type,p,h,v]) channels, got %d" % c)
+        ws = self._workspace(n, h, w)
+        inst = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if not taps:
+            L.check(L.lib().hvn_postproc(pred.data_ptr(), n, h, w, c, c - 3, inst.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                    "hvn_postproc")
+            return inst
+        blb = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
+        dist = torch.empty((n, h, w), dtype=torch.float64, device=self.device)
+        marker = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
+        L.check(L.lib().hvn_postproc_taps(pred.data_ptr(), n, h, w, c, c - 3, inst.data_ptr(), blb.data_ptr(), dist.data_ptr(),
+                                          marker.data_ptr(), ws.data_ptr(), ws.numel(), stream), "hvn_postproc_taps")
+        return inst, blb, dist, marker
+
+    def table(self, inst, pred, nr_types):
+        """-> (records uint8 view [N,max_inst,sizeof(rec)], counts int32 [N]) on the device."""
+        n, h, w = inst.shape
+        max_inst = h * w // 13 + 1   # an opened marker component holds at least one 13-px element
+        nt = int(nr_types or 0)
+        need = L.lib().hvn_instance_table_workspace_bytes(n, max_inst, nt)
+        if self._tws is None or self._tws.numel() < need:
+            self._tws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        rec = torch.empty((n, max_inst, ctypes.sizeof(L.hvn_inst_rec)), dtype=torch.uint8, device=self.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(L.lib().hvn_instance_table(inst.data_ptr(), pred.data_ptr() if nt else None, n, h, w, pred.shape[-1], nt,
+                                           rec.data_ptr(), counts.data_ptr(), max_inst, self._tws.data_ptr(),
+                                           self._tws.numel(), stream), "hvn_instance_table")
+        return rec, counts
+
+
+_REC_DTYPE = np.dtype([("label", "<i4"), ("area", "<i4"), ("rmin", "<i4"), ("rmax", "<i4"), ("cmin", "<i4"), ("cmax", "<i4"),
+                       ("sum_x", "<f8"), ("sum_y", "<f8"), ("type", "<i4"), ("type_count", "<i4")])
+assert _REC_DTYPE.itemsize == ctypes.sizeof(L.hvn_inst_rec)
+
+_DEFAULT = {}
+
+
+def _pp(device):
+    key = str(device)
+    if key not in _DEFAULT:
+        _DEFAULT[key] = PostProc(device)
+    return _DEFAULT[key]
+
+
+def process_batch_device(pred_dev, nr_types=None, return_centroids=False):
+    """pred_dev [N,h,w,3|4] float32 on the GPU -> (inst int32 [N,h,w] device tensor,
+    records device tensor | None, counts device tensor | None)."""
+    pp = _pp(pred_dev.device)
+    inst = pp.separate(pred_dev)
+    if return_centroids or nr_types is not None:
+        rec, counts = pp.table(inst, pred_dev.contiguous(), nr_types)
+        return inst, rec, counts
+    return inst, None, None
+
+
+def records_to_dict(rec_host, nr_types):
+    """One tile's records (numpy structured array) -> the reference's inst_info_dict."""
+    out = {}
+    for r in rec_host[rec_host["area"] > 0]:
+        bbox = np.array([[r["rmin"], r["cmin"]], [r["rmax"], r["cmax"]]])
+        cx = r["sum_x"] / float(r["area"]) + r["cmin"]   # m10/m00 on the crop, then + offset (post_proc.py:145-152)
+        cy = r["sum_y"] / float(r["area"]) + r["rmin"]
+        out[int(r["label"])] = {
+            "bbox": bbox,
+            "centroid": np.array([cx, cy]),
+            "contour": None,
+            "type_prob": None if nr_types is None else float(r["type_count"] / (r["area"] + 1.0e-6)),
+            "type": None if nr_types is None else int(r["type"]),
+        }
+    return out
+
+
+def process(pred_map, nr_types=None, return_centroids=False):
+    """Reference signature (post_proc.py:94): one host map [H,W,3|4] float32."""
+    pred = torch.from_numpy(np.ascontiguousarray(pred_map, np.float32)).unsqueeze(0).to("cuda")
+    inst, rec, _ = process_batch_device(pred, nr_types, return_centroids)
+    pred_inst = inst[0].cpu().numpy()
+    info = None
+    if rec is not None:
+        info = records_to_dict(rec[0].cpu().numpy().view(_REC_DTYPE).reshape(-1), nr_types)
+    return pred_inst, info

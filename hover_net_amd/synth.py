@@ -69,3 +69,54 @@ def synth_pred_maps(n, H=80, W=80, nr_types=None, seed=0, k_lo=5, k_hi=40, noise
     lo, hi = max(1, int(k_lo * scale)), max(1, int(k_hi * scale))
     maps, insts = zip(*[_one_map(rng, H, W, nr_types, lo, hi, noise) for _ in range(n)])
     return np.stack(maps), np.stack(insts)
+
+
+_GAINS = (("conv3.weight", 0.35), ("shortcut.weight", 0.6), ("conv_bot.weight", 0.6), ("conva.weight", 0.6),
+          ("convf.weight", 0.6), ("u0.conv.weight", 1.5))
+
+
+def _conv_gain(key):
+    for suffix, g in _GAINS:
+        if key.endswith(suffix):
+            return g
+    return 1.0
+
+
+def synth_state_dict(mode="original", nr_types=None, seed=0, as_torch=True):
+    """Seeded, platform-independent (numpy PCG64) checkpoint in the reference's key
+    format: Kaiming fan_out convs like `Net.weights_init`
+    (/root/reference/models/hovernet/net_utils.py:18-32) but with NON-trivial BatchNorm
+    affine + running statistics so that BN folding / prologues are really exercised."""
+    from .arch import param_table
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for key, (kind, shape) in param_table(mode, nr_types).items():
+        if kind == "conv":
+            # He-normal over fan_in, with the residual / skip-summing convs damped so that
+            # activations (and the logits) stay O(1..10) through the ~50 layers; absolute
+            # tolerances on logits are only meaningful at that scale.
+            fan_in = shape[1] * shape[2] * shape[3]
+            a = rng.normal(0.0, np.sqrt(2.0 / fan_in) * _conv_gain(key), shape)
+        elif kind == "bias":
+            a = rng.normal(0.0, 0.1, shape)
+        elif kind == "bn_w":
+            a = rng.uniform(0.6, 1.4, shape)
+        elif kind == "bn_b":
+            a = rng.normal(0.0, 0.2, shape)
+        elif kind == "bn_rm":
+            a = rng.normal(0.0, 0.2, shape)
+        elif kind == "bn_rv":
+            a = rng.uniform(0.5, 1.5, shape)
+        elif kind == "bn_nbt":
+            a = np.array(0, np.int64)
+        elif kind == "ones":
+            a = np.ones(shape)
+        else:
+            raise KeyError(kind)
+        sd[key] = a.astype(np.int64 if kind == "bn_nbt" else np.float32)
+    if as_torch:
+        import torch
+
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    return sd

@@ -1,0 +1,111 @@
+/*
+ * hvn.h -- C ABI of libhvn_hip.so, the MI355X (gfx950) HoVer-Net hot path.
+ *
+ * The reference (vqdang/hover_net) is pure Python and has no FFI; its boundary for
+ * this path is three duck-typed callables looked up by module name
+ * (/root/reference/infer/base.py:56-78).  Each entry point below names the
+ * reference interface it stands behind.  All pointers marked `dev` are device (HBM)
+ * addresses owned by the caller; `stream` is a hipStream_t passed as void*; every
+ * function returns 0 on success or a negative hvn_status and never throws.  One host
+ * thread per stream.  See INTEGRATION.md for the ctypes binding.
+ */
+#ifndef HVN_H
+#define HVN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVN_API __attribute__((visibility("default")))
+
+typedef enum hvn_status {
+    HVN_OK = 0,
+    HVN_E_ARG = -1,      /* malformed descriptor (alignment, channel multiple, kind) */
+    HVN_E_LAUNCH = -2,   /* hipLaunch / hipGetLastError failure (hvn_last_error() has the text) */
+    HVN_E_NOGPU = -3,    /* no gfx950 device visible */
+    HVN_E_SIZE = -4      /* workspace too small */
+} hvn_status;
+
+/* Strided view: element (n,y,x,c) lives at base[n*sn + y*sy + x*sx + c*sc].  Every kernel but
+ * CONV0 requires channels-last (sc = 1; 0 is read as 1). */
+typedef struct hvn_view {
+    void   *base;        /* dev */
+    int64_t sn, sy, sx;  /* strides in elements */
+    int32_t h, w, c;     /* window extent */
+    int32_t sc;          /* channel stride in elements (CONV0 input only, e.g. h*w for NCHW) */
+} hvn_view;
+
+enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN_OP_PREDMAP = 5 };
+
+/*
+ * One fused launch of the network plan (hover_net_amd/plan.py lowers
+ * /root/reference/models/hovernet/net_desc.py:101-145 to an array of these).
+ *   CONV0   x = image, uint8 (x_dtype 0; infer_step hands NHWC bytes) or float32 0..255 (x_dtype 1;
+ *           HoVerNet.forward's NCHW contract), w = [kh][kw][3][64] taps (1/255 and BN folded), bias, relu
+ *   CONV    y = epi( conv( pro(x) ) ):  pro = relu(x*pre_scale+pre_shift) if pre_scale,
+ *           w = [cout_pad][kh*kw][x.c] fp32 (cout_pad = multiple of tile_n),
+ *           epi = (+bias) (relu) (+res) (relu(.*post_scale+post_shift) if post_scale)
+ *   UPADD   y = nearest2x(x) + res
+ *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
+ *   PREDMAP y.base = [n][h][w][3|4] = [argmax(tp)?, softmax(np)[1], hv0, hv1]
+ *           (run_desc.py:185-194); x.base = np logits, res.base = hv logits, w = tp logits or NULL,
+ *           cout = nr_types (0 if none)
+ */
+typedef struct hvn_op {
+    int32_t kind, kh, kw, stride, pad_t, pad_l, relu, cout, tile_n, x_dtype;
+    hvn_view x, res, y;
+    const float *w, *bias, *pre_scale, *pre_shift, *post_scale, *post_shift; /* dev */
+} hvn_op;
+
+/* -- library ---------------------------------------------------------------------- */
+HVN_API int         hvn_version(void);
+HVN_API const char *hvn_last_error(void);
+HVN_API int         hvn_device_ok(void);  /* 1 if a gfx950 device is current */
+
+/* -- network: HoVerNet.forward (net_desc.py:101-145) + infer_step epilogue (run_desc.py:171-197) */
+HVN_API int hvn_run_plan(const hvn_op *ops, int n_ops, int batch, void *stream);
+/* single launches, used by the per-kernel parity tests */
+HVN_API int hvn_run_op(const hvn_op *op, int batch, void *stream);
+/* timing of the last hvn_run_plan on `stream` measured with hipEvents around every CONV launch:
+ * returns total CONV milliseconds (sync point); <0 if profiling was not enabled */
+HVN_API int    hvn_profile_enable(int on);
+HVN_API double hvn_profile_conv_ms(void);
+HVN_API int    hvn_profile_conv_launches(void);
+
+/* -- instance separation: post_proc.py:26-90 __proc_np_hv ---------------------------- */
+/* bytes of device workspace needed for `n` maps of h x w */
+HVN_API size_t hvn_postproc_workspace_bytes(int n, int h, int w);
+/* pred: dev float32 [n][h][w][c] with [p, h, v] at channels c0..c0+2 (c0 = 1 when a type
+ * channel leads, post_proc.py:109-114); inst: dev int32 [n][h][w].  Labels equal the
+ * reference's (scipy raster-order numbering of the marker components). */
+HVN_API int hvn_postproc(const float *pred, int n, int h, int w, int c, int c0,
+                         int32_t *inst, void *workspace, size_t workspace_bytes, void *stream);
+/* stage taps for tests (any may be NULL): blb int32, dist float64 (negated blur), marker int32 */
+HVN_API int hvn_postproc_taps(const float *pred, int n, int h, int w, int c, int c0, int32_t *inst,
+                              int32_t *blb, double *dist, int32_t *marker,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* -- per-instance table: post_proc.py:119-181 process() (bbox, centroid, type vote) ----- */
+typedef struct hvn_inst_rec {
+    int32_t label;              /* value in the inst map */
+    int32_t area;
+    int32_t rmin, rmax, cmin, cmax; /* get_bounding_box semantics (misc/utils.py:18-28): max is exclusive */
+    double  sum_x, sum_y;       /* cv2.moments m10, m01 over the bbox crop (offsets re-added): centroid = sum/area */
+    int32_t type;               /* majority type, runner-up if 0 (post_proc.py:170-177); -1 if no type channel */
+    int32_t type_count;         /* pixels of that type: type_prob = type_count / (area + 1e-6) */
+} hvn_inst_rec;
+/* records: dev [n][max_inst], slot j describes label j+1 (area 0 = label absent; labels above
+ * max_inst are ignored); counts: dev int32 [n] = number of labels present; pred may be NULL when
+ * nr_types == 0, else its channel 0 is the type map (post_proc.py:109-112). */
+HVN_API size_t hvn_instance_table_workspace_bytes(int n, int max_inst, int nr_types);
+HVN_API int hvn_instance_table(const int32_t *inst, const float *pred, int n, int h, int w, int c,
+                               int nr_types, hvn_inst_rec *records, int32_t *counts, int max_inst,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVN_H */

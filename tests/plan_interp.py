@@ -1,0 +1,109 @@
+"""Torch-CPU interpreter of a `hover_net_amd.plan.Plan` -- TEST INFRASTRUCTURE ONLY.
+
+Executes the very same op list the product hands to libhvn_hip.so, but with plain
+torch fp32 ops on NHWC tensors, honouring every view / stride / prologue / epilogue
+field.  Used (a) on CPU to prove the lowering (BN folding, concat-by-offset, crops,
+block-diagonal grouped convs, arena packing) against oracle/net_torch.py, and (b) on
+the GPU box as the per-op reference for the HIP kernels.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from hover_net_amd import plan as PL
+
+
+class Arena:
+    """Backs every plan buffer by a slice of ONE flat tensor per sample-batch, at the
+    offsets Plan.pack() assigned -- so lifetime-overlap bugs in the packing show up."""
+
+    def __init__(self, plan, n):
+        self.n = n
+        self.flat = torch.full((n, plan.arena_per_sample), float("nan"))
+        self.ext = {}
+
+    def tensor(self, buf):
+        if buf.offset < 0:  # image / logits / pred_map live outside the arena
+            if buf.name not in self.ext:
+                self.ext[buf.name] = torch.full((self.n, buf.h, buf.w, buf.c), float("nan"))
+            return self.ext[buf.name]
+        return self.flat[:, buf.offset:buf.offset + buf.size].view(self.n, buf.h, buf.w, buf.c)
+
+    def view(self, v):
+        t = self.tensor(v.buf)
+        return t[:, v.y0:v.y0 + v.h, v.x0:v.x0 + v.w, v.c0:v.c0 + v.c]
+
+
+def conv_ref(op, x, res=None):
+    """x: [N,h,w,cin] NHWC view tensor -> [N,ho,wo,cout]."""
+    if op.pre is not None:
+        x = F.relu(x * torch.from_numpy(op.pre[0]) + torch.from_numpy(op.pre[1]))
+    cout_pad, taps, cin = op.w.shape
+    w = torch.from_numpy(op.w[:op.cout]).view(op.cout, op.kh, op.kw, cin).permute(0, 3, 1, 2)
+    xin = x.permute(0, 3, 1, 2)
+    ho, wo = op.y.h, op.y.w
+    pad_b = (ho - 1) * op.stride + op.kh - x.shape[1] - op.pad_t
+    pad_r = (wo - 1) * op.stride + op.kw - x.shape[2] - op.pad_l
+    xin = F.pad(xin, (op.pad_l, max(pad_r, 0), op.pad_t, max(pad_b, 0)))
+    y = F.conv2d(xin, w, stride=op.stride)[:, :, :ho, :wo].permute(0, 2, 3, 1)
+    if op.bias is not None:
+        y = y + torch.from_numpy(op.bias)
+    if op.relu:
+        y = F.relu(y)
+    if res is not None:
+        y = y + res
+    if op.post is not None:
+        y = F.relu(y * torch.from_numpy(op.post[0]) + torch.from_numpy(op.post[1]))
+    return y
+
+
+def conv0_ref(op, img_u8):
+    x = img_u8.float().permute(0, 3, 1, 2)
+    w = torch.from_numpy(op.w).permute(3, 2, 0, 1)  # [7,7,3,64] -> [64,3,7,7]
+    x = F.pad(x, (op.pad_l, op.pad_l, op.pad_t, op.pad_t))
+    y = F.conv2d(x, w) + torch.from_numpy(op.bias).view(1, -1, 1, 1)
+    return F.relu(y).permute(0, 2, 3, 1)
+
+
+def upadd_ref(lo, skip):
+    return lo.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) + skip
+
+
+def head_ref(op, x):
+    y = x @ torch.from_numpy(op.w).t() + torch.from_numpy(op.bias)
+    return y.permute(0, 3, 1, 2).contiguous()  # NCHW logits
+
+
+def predmap_ref(logits, branches):
+    ch = []
+    if "tp" in branches:
+        ch.append(torch.argmax(logits["tp"], dim=1).unsqueeze(-1).float())
+    l = logits["np"]
+    ch.append(torch.softmax(l, dim=1)[:, 1].unsqueeze(-1))
+    ch.append(logits["hv"].permute(0, 2, 3, 1))
+    return torch.cat(ch, -1)
+
+
+def run(plan, imgs_u8, taps=None):
+    """imgs_u8: uint8 [N,H,W,3] tensor -> (logits dict NCHW, pred_map or None)."""
+    n = imgs_u8.shape[0]
+    A = Arena(plan, n)
+    logits = {}
+    pred = None
+    with torch.no_grad():
+        for op in plan.ops:
+            if op.kind == PL.OP_CONV0:
+                A.view(op.y).copy_(conv0_ref(op, imgs_u8))
+            elif op.kind == PL.OP_CONV:
+                res = A.view(op.res).clone() if op.res is not None else None
+                A.view(op.y).copy_(conv_ref(op, A.view(op.x).clone(), res))
+            elif op.kind == PL.OP_UPADD:
+                A.view(op.y).copy_(upadd_ref(A.view(op.x), A.view(op.res)))
+            elif op.kind == PL.OP_HEAD:
+                logits[op.y.buf.name.split(".")[1]] = head_ref(op, A.view(op.x))
+            elif op.kind == PL.OP_PREDMAP:
+                pred = predmap_ref(logits, op.extra["branches"])
+            if taps is not None and op.name in taps:
+                taps[op.name] = A.view(op.y).clone()
+            assert op.kind in (PL.OP_HEAD, PL.OP_PREDMAP) or not torch.isnan(A.view(op.y)).any(), op.name
+    return logits, pred

@@ -1,0 +1,116 @@
+"""-m gpu: the fused implicit-GEMM conv kernel (hover_net_amd/csrc/hvn_conv.hip) through the
+C ABI, against the torch-CPU interpretation of the same descriptor, on every conv class of
+SURVEY.md 2.2(i) at small spatial sizes.  fp32 MFMA is an exact fmaf chain, so the only
+difference to torch is summation order: tolerance 2e-4 abs on O(1) outputs (K up to 25.6k)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+def _check(got, want, tol=TOL):
+    assert got.shape == want.shape
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err <= tol, "max abs err %g" % err
+
+
+def _case(**kw):
+    from gpu_util import run_conv_case
+
+    return run_conv_case(**kw)
+
+
+def _w(cout, cin_g, k, seed=1):
+    from gpu_util import rand_conv_weight
+
+    return rand_conv_weight(np.random.default_rng(seed), cout, cin_g, k)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 256), (256, 64), (128, 512), (2048, 1024), (32, 32), (288, 128)])
+def test_conv1x1(cin, cout):
+    n, s = 2, 13  # M = 338: exercises the M tail (not a multiple of 128)
+    got, want = _case(n=n, xbuf_shape=(s, s, cin), xview=(0, 0, s, s, 0, cin), ybuf_shape=(s, s, cout),
+                      yview=(0, 0, s, s, 0, cout), wt=_w(cout, cin, 1), bn=True, relu=1)
+    _check(got, want)
+
+
+def test_conv1x1_prologue_residual_post():
+    # residual-unit conv3 with the block-closing BN-ReLU, conv1 with a pre-activation prologue
+    n, s = 2, 17
+    got, want = _case(n=n, xbuf_shape=(s, s, 64), xview=(0, 0, s, s, 0, 64), ybuf_shape=(s, s, 256),
+                      yview=(0, 0, s, s, 0, 256), wt=_w(256, 64, 1), res=True, post=True)
+    _check(got, want)
+    got, want = _case(n=n, xbuf_shape=(s, s, 256), xview=(0, 0, s, s, 0, 256), ybuf_shape=(s, s, 64),
+                      yview=(0, 0, s, s, 0, 64), wt=_w(64, 256, 1), pre=True, bn=True, relu=1)
+    _check(got, want)
+
+
+def test_conv1x1_inplace_residual():
+    n, s = 1, 20
+    got, want = _case(n=n, xbuf_shape=(s, s, 64), xview=(0, 0, s, s, 0, 64), ybuf_shape=(s, s, 128),
+                      yview=(0, 0, s, s, 0, 128), wt=_w(128, 64, 1), res=True, inplace_res=True)
+    _check(got, want)
+
+
+def test_conv1x1_stride2_shortcut():
+    n, s = 2, 24
+    got, want = _case(n=n, xbuf_shape=(s, s, 256), xview=(0, 0, s, s, 0, 256), ybuf_shape=(12, 12, 512),
+                      yview=(0, 0, 12, 12, 0, 512), wt=_w(512, 256, 1), stride=2)
+    _check(got, want)
+
+
+@pytest.mark.parametrize("stride,pad,s,so", [(1, (1, 1), 18, 18), (2, (0, 1), 18, 9)])
+def test_conv3x3_tf_same(stride, pad, s, so):
+    n = 2
+    got, want = _case(n=n, xbuf_shape=(s, s, 128), xview=(0, 0, s, s, 0, 128), ybuf_shape=(so, so, 128),
+                      yview=(0, 0, so, so, 0, 128), wt=_w(128, 128, 3), stride=stride, pad=pad, bn=True, relu=1)
+    _check(got, want)
+
+
+def test_conv5x5_valid_big_k():
+    # u3.conva class: 1024 -> 256, K = 25600
+    n, s = 1, 12
+    got, want = _case(n=n, xbuf_shape=(s, s, 1024), xview=(0, 0, s, s, 0, 1024), ybuf_shape=(8, 8, 512),
+                      yview=(0, 0, 8, 8, 0, 256), wt=_w(256, 1024, 5))
+    _check(got, want)
+
+
+def test_conv5x5_same_pad():
+    n, s = 1, 14
+    got, want = _case(n=n, xbuf_shape=(s, s, 256), xview=(0, 0, s, s, 0, 256), ybuf_shape=(s, s, 64),
+                      yview=(0, 0, s, s, 0, 64), wt=_w(64, 256, 5), pad=(2, 2), bn=True, relu=1)
+    _check(got, want)
+
+
+@pytest.mark.parametrize("k", [5, 3])
+def test_dense_unit_views(k):
+    # dense-block conv1 reads a cropped window of the concat buffer (first 288 of 512 channels),
+    # the grouped conv2 (block-diagonal packed) writes 32 channels at offset 288 of a smaller window
+    n, s = 2, 16
+    c = (k - 1) // 2
+    got, want = _case(n=n, xbuf_shape=(s, s, 512), xview=(2, 2, s - 4, s - 4, 0, 288), ybuf_shape=(s - 4, s - 4, 128),
+                      yview=(0, 0, s - 4, s - 4, 0, 128), wt=_w(128, 288, 1), pre=True, bn=True, relu=1)
+    _check(got, want)
+    so = s - 4 - (k - 1)
+    got, want = _case(n=n, xbuf_shape=(s - 4, s - 4, 128), xview=(0, 0, s - 4, s - 4, 0, 128), ybuf_shape=(s, s, 512),
+                      yview=(2 + c, 2 + c, so, so, 288, 32), wt=_w(32, 32, k), groups=4)
+    _check(got, want)
+    # nothing outside the 32-channel window may have been touched
+    assert torch.equal(got[..., :288], want[..., :288]) and torch.equal(got[..., 320:], want[..., 320:])
+
+
+def test_descriptor_validation():
+    import ctypes
+
+    from hover_net_amd import lib as L
+
+    op = L.hvn_op()
+    op.kind = 2
+    assert L.lib().hvn_run_op(ctypes.addressof(op), 1, None) == -1
+    assert b"conv" in L.lib().hvn_last_error()
+    op.kind = 99
+    assert L.lib().hvn_run_op(ctypes.addressof(op), 1, None) == -1

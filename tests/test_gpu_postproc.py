@@ -1,0 +1,107 @@
+"""-m gpu: on-GPU instance separation (hover_net_amd/csrc/hvn_postproc.hip) through the C ABI
+against (a) the golden instance maps made by the reference's own post_proc.py and (b) the C
+oracle stage by stage.  Integer work: BIT-EXACT, label values included."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pp_*.npz")))
+
+
+def _pp():
+    from hover_net_amd.post_proc import PostProc
+
+    return PostProc("cuda")
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[3:-4] for p in CASES])
+def test_matches_reference_golden(path):
+    z = np.load(path)
+    pred, inst = z["pred"], z["inst"]
+    got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, inst)
+
+
+def test_stage_taps_match_oracle():
+    from hover_net_amd.synth import synth_pred_maps
+    from oracle import postproc as O
+
+    pred = synth_pred_maps(6, 80, 80, 5, seed=41)[0]
+    inst, blb, dist, marker = [t.cpu().numpy() for t in _pp().separate(torch.from_numpy(pred).to("cuda"), taps=True)]
+    for i in range(pred.shape[0]):
+        o_inst, o_blb, o_dist, o_marker = O.proc_np_hv(pred[i][..., 1:], taps=True)
+        np.testing.assert_array_equal(blb[i], o_blb)
+        np.testing.assert_array_equal(dist[i], o_dist)      # float64, bit for bit
+        np.testing.assert_array_equal(marker[i], o_marker)
+        np.testing.assert_array_equal(inst[i], o_inst)
+
+
+def test_full_batch_32_tiles_and_properties():
+    """BASELINE size (32 maps of 80x80): oracle equality + size-independent properties."""
+    from hover_net_amd.synth import synth_pred_maps
+    from oracle import postproc as O
+
+    pred = synth_pred_maps(32, 80, 80, 5, seed=42)[0]
+    dev = torch.from_numpy(pred).to("cuda")
+    pp = _pp()
+    inst = pp.separate(dev).cpu().numpy()
+    np.testing.assert_array_equal(inst, O.proc_batch(pred))
+    # idempotent / deterministic, and independent of a tile's position in the batch
+    np.testing.assert_array_equal(pp.separate(dev).cpu().numpy(), inst)
+    perm = np.random.default_rng(0).permutation(32)
+    np.testing.assert_array_equal(pp.separate(dev[torch.from_numpy(perm)]).cpu().numpy(), inst[perm])
+    # every instance lies inside the thresholded blob mask
+    assert ((inst > 0) <= (pred[..., 1] >= 0.5)).all()
+
+
+def test_large_tile_uses_hbm_heap():
+    from hover_net_amd.synth import synth_pred_maps
+    from oracle import postproc as O
+
+    pred = synth_pred_maps(2, 300, 277, None, seed=43)[0]
+    got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
+    np.testing.assert_array_equal(got, O.proc_batch(pred))
+
+
+def test_process_contract_and_instance_table():
+    from hover_net_amd import post_proc
+    from hover_net_amd.synth import synth_pred_maps
+    from oracle import postproc as O
+
+    pred = synth_pred_maps(1, 80, 80, 5, seed=44)[0][0]
+    inst, info = post_proc.process(pred, nr_types=5, return_centroids=True)
+    want = O.proc_np_hv(pred[..., 1:])
+    np.testing.assert_array_equal(inst, want)
+    ids = [i for i in np.unique(want) if i > 0]
+    assert sorted(info.keys()) == ids
+    tmap = pred[..., 0].astype(np.int32)
+    for i in ids:
+        m = want == i
+        ys, xs = np.nonzero(m)
+        e = info[i]
+        assert e["bbox"].tolist() == [[ys.min(), xs.min()], [ys.max() + 1, xs.max() + 1]]  # misc/utils.py:18-28
+        cx = (xs - xs.min()).sum() / float(m.sum()) + xs.min()
+        cy = (ys - ys.min()).sum() / float(m.sum()) + ys.min()
+        assert e["centroid"].tolist() == [cx, cy]
+        tl, tc = np.unique(tmap[m], return_counts=True)
+        order = sorted(zip(tl, tc), key=lambda t: t[1], reverse=True)   # post_proc.py:168-177
+        t = order[0][0]
+        if t == 0 and len(order) > 1:
+            t = order[1][0]
+        assert e["type"] == int(t)
+        assert e["type_prob"] == float(dict(order)[t] / (m.sum() + 1.0e-6))
+    inst2, info2 = post_proc.process(pred[..., 1:], nr_types=None, return_centroids=False)
+    np.testing.assert_array_equal(inst2, want)
+    assert info2 is None
+
+
+def test_empty_and_full_maps():
+    e = np.zeros((3, 40, 40, 3), np.float32)
+    e[1, ..., 0] = 1.0
+    got = _pp().separate(torch.from_numpy(e).to("cuda")).cpu().numpy()
+    assert (got[0] == 0).all()

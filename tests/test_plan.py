@@ -1,0 +1,98 @@
+"""CPU: the lowering (hover_net_amd/plan.py) interpreted with torch ops equals the oracle --
+BN folding, concat-by-offset, crops, block-diagonal grouped convs, arena packing -- and the
+host-side mirror of the reference interface keeps its contract."""
+import numpy as np
+import pytest
+import torch
+
+import plan_interp
+from hover_net_amd import arch
+from hover_net_amd import plan as PL
+from hover_net_amd.synth import synth_state_dict, synth_tiles
+from oracle import net_torch
+
+
+@pytest.mark.parametrize("mode,nt,gflop", [("original", 5, 392.17), ("fast", 6, 297.87), ("original", None, 322.22)])
+def test_plan_matches_oracle(mode, nt, gflop):
+    sd = synth_state_dict(mode, nt, seed=3)
+    P = PL.build_plan(sd, mode, nt)
+    assert abs(P.total_flops() / 1e9 - gflop) < 0.01  # SURVEY.md 2.2(i) totals
+    imgs = torch.from_numpy(synth_tiles(1, P.geo["inp"], seed=5))
+    ref = net_torch.forward(sd, imgs.permute(0, 3, 1, 2).float(), mode)
+    got, pred = plan_interp.run(P, imgs)
+    for k in ref:
+        assert float((ref[k] - got[k]).abs().max()) < 1e-4
+    pr = net_torch.infer_epilogue(ref)
+    assert float((pr[..., -3:] - pred[..., -3:]).abs().max()) < 1e-4
+
+
+def test_arena_packing_has_no_live_overlap():
+    P = PL.build_plan(synth_state_dict("original", 5, seed=1), "original", 5)
+    live = [b for b in P.bufs if b.last >= 0]
+    for i, a in enumerate(live):
+        assert a.offset % 64 == 0 and a.offset + a.size <= P.arena_per_sample
+        for b in live[i + 1:]:
+            if a.last < b.first or b.last < a.first:
+                continue
+            assert a.offset + a.size <= b.offset or b.offset + b.size <= a.offset, (a.name, b.name)
+    assert P.arena_per_sample * 4 < 200e6  # ~160 MB / tile
+
+
+def test_every_conv_is_kernel_legal():
+    for mode, nt in (("original", 5), ("fast", 6)):
+        P = PL.build_plan(synth_state_dict(mode, nt, seed=1), mode, nt)
+        for op in P.ops:
+            if op.kind != PL.OP_CONV:
+                continue
+            assert op.x.c % 32 == 0 and op.x.c0 % 4 == 0 and op.y.c0 % 4 == 0, op.name
+            assert op.w.shape[0] % op.tile_n == 0 and op.w.shape[2] == op.x.c
+            assert op.tile_n in (32, 64, 128)
+
+
+def test_param_table_counts():
+    # 632 keys seg-only / 798 with the tp branch; 45.03 M / 54.74 M / 37.64 M params
+    def count(t):
+        return sum(int(np.prod(s)) for k, (kind, s) in t.items() if kind in ("conv", "bias", "bn_w", "bn_b"))
+
+    assert len(arch.param_table("original", None)) == 632
+    assert len(arch.param_table("original", 5)) == 798
+    assert abs(count(arch.param_table("original", None)) / 1e6 - 45.03) < 0.01
+    assert abs(count(arch.param_table("original", 5)) / 1e6 - 54.74) < 0.01
+    assert abs(count(arch.param_table("fast", 6)) / 1e6 - 37.64) < 0.01
+
+
+def test_module_contract_cpu():
+    from hover_net_amd import net_desc
+
+    net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
+    assert (net.mode, net.freeze, net.nr_types, net.output_ch) == ("original", False, 5, 4)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(arch.param_table("original", 5).keys())
+    assert sd["conv0./.weight"].shape == (64, 3, 7, 7) and sd["upsample2x.unpool_mat"].shape == (2, 2)
+    assert sd["d0.units.1.preact/bn.num_batches_tracked"].dtype == torch.long
+    net.load_state_dict(synth_state_dict("original", 5, seed=2), strict=True)
+    with pytest.raises(RuntimeError):  # missing key must fail like the reference's strict load
+        bad = dict(synth_state_dict("original", 5, seed=2))
+        bad.pop("conv_bot.weight")
+        net.load_state_dict(bad, strict=True)
+    net.eval()
+    with pytest.raises(RuntimeError):  # no CPU fallback
+        net(torch.zeros(1, 3, 270, 270))
+    with pytest.raises(AssertionError):
+        net_desc.HoVerNet(mode="bogus")
+    seg = net_desc.create_model(mode="fast", nr_types=None)
+    assert seg.output_ch == 3 and len(seg.state_dict()) == 632
+
+
+def test_abi_exports_every_declared_symbol():
+    import re
+    import os
+    from hover_net_amd import lib as L
+
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "hvn.h")).read()
+    declared = set(re.findall(r"HVN_API\s+[\w\s\*]+?\b(hvn_\w+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hvn_version() == 100
