@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""bench.py -- tiles/sec of the HoVer-Net hot path on MI355X (BASELINE.json metric).
+
+One *step* = one pass of the whole hot path over one batch of synthetic input already resident
+in HBM: 32 uint8 270x270 tiles -> HIP network (original mode, 5 types, fp32) -> infer_step
+epilogue -> on-GPU instance separation (Sobel/threshold/CC/watershed) + per-instance table.
+No host round trip inside the step.  N > 1: one process per GPU (torch.distributed / RCCL for
+the barrier and the max-over-ranks clock only); tiles are independent units, so every rank
+processes its own batches and there is no data-path collective ("weak" scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fp32-MFMA
+implicit-GEMM conv): algorithmic conv FLOPs of one step / summed duration of that step's conv
+launches, measured with HIP events on the launch stream in an extra, untimed step.
+`cpu_baseline` (N=1 only) times the CPU oracle (torch fp32 restatement + C post-proc port) on
+a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--mode", default="original")
+    ap.add_argument("--nr-types", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from hover_net_amd import lib as L
+    from hover_net_amd import net_desc, post_proc, run_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+
+    nt = args.nr_types if args.nr_types > 0 else None
+    size = 270 if args.mode == "original" else 256
+    sd = synth_state_dict(args.mode, nt, seed=0)
+    net = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
+    net.load_state_dict(sd, strict=True)
+    net.max_batch = args.batch
+    net = net.to(dev).eval()
+    tiles = torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank)).to(dev)  # resident in HBM
+
+    def step():
+        pred = run_desc.infer_step_device(tiles, net)
+        return post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_inst = int(out[2].sum().item())
+
+    result = {
+        "metric": "tiles/sec (270x270, batch 32) end-to-end incl. watershed",
+        "value": world * args.batch * args.steps / dt,
+        "unit": "tiles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "fp32",
+        "data": "synthetic",
+        "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 tiles per GPU, "
+                               "random-init checkpoint (seeded), network + infer_step epilogue + on-GPU watershed post-proc"
+                               % (args.mode, nt, args.batch, size, size),
+                   "global_batch": world * args.batch, "instances_last_step": n_inst, "parallelism": "tile-sharded x%d" % world},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        eng = net.engine(args.batch)
+        conv_flops = sum(o.flops() for o in eng.plan.ops if o.kind == 2) * args.batch
+        L.lib().hvn_profile_enable(1)
+        run_desc.infer_step_device(tiles, net)
+        ms = L.lib().hvn_profile_conv_ms()
+        launches = L.lib().hvn_profile_conv_launches()
+        L.lib().hvn_profile_enable(0)
+        achieved = conv_flops / (ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "hvn_conv_igemm_f32", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                              "launches_per_step": launches, "conv_ms_per_step": ms, "conv_gflop_per_step": conv_flops / 1e9}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import net_torch
+        from oracle import postproc as O
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cpu_tiles = tiles.cpu()
+
+        def cpu_pass(k):
+            x = cpu_tiles[:k].permute(0, 3, 1, 2).float()
+            pm = net_torch.infer_epilogue(net_torch.forward(sd, x, args.mode)).numpy()
+            return O.proc_batch(pm)
+
+        t1 = time.perf_counter()
+        cpu_pass(1)
+        one = time.perf_counter() - t1
+        k = int(max(1, min(args.batch, round(args.cpu_seconds / max(one, 1e-3)))))
+        t1 = time.perf_counter()
+        cpu_pass(k)
+        cdt = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": k / cdt, "unit": "tiles/s", "cores": cores, "kind": "port",
+                                  "sample": "%d of the same %d tiles: oracle/net_torch.py (torch-CPU fp32, %d threads) + "
+                                            "oracle/hvn_oracle.c post-proc (1 thread)" % (k, args.batch, cores)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
