@@ -55,7 +55,7 @@ def main():
 
     from hover_net_amd import lib as L
     from hover_net_amd import net_desc, post_proc, run_desc
-    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    from hover_net_amd.synth import synth_pred_maps, synth_state_dict, synth_tiles
 
     nt = args.nr_types if args.nr_types > 0 else None
     size = 270 if args.mode == "original" else 256
@@ -65,10 +65,17 @@ def main():
     net.max_batch = args.batch
     net = net.to(dev).eval()
     tiles = torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank)).to(dev)  # resident in HBM
+    # A random-init network emits maps without nuclei (0 instances -> the watershed has nothing to
+    # flood).  So that the step carries a realistic instance-separation load it ALSO post-processes a
+    # resident batch of structured synthetic maps (painted elliptical nuclei, ~5..40 per 80x80 map,
+    # hover_net_amd.synth.synth_pred_maps): post-proc runs twice per step, which over-counts its cost.
+    out_hw = net.engine(args.batch).plan.geo["out"]
+    structured = torch.from_numpy(synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank)[0]).to(dev)
 
     def step():
         pred = run_desc.infer_step_device(tiles, net)
-        return post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True)
+        post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True)
+        return post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -104,10 +111,23 @@ def main():
         "dtype": "fp32",
         "data": "synthetic",
         "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 tiles per GPU, "
-                               "random-init checkpoint (seeded), network + infer_step epilogue + on-GPU watershed post-proc"
+                               "random-init checkpoint (seeded), network + infer_step epilogue + on-GPU watershed post-proc "
+                               "(of the network output AND of a resident batch of structured synthetic maps, see bench.py)"
                                % (args.mode, nt, args.batch, size, size),
                    "global_batch": world * args.batch, "instances_last_step": n_inst, "parallelism": "tile-sharded x%d" % world},
     }
+
+    if rank == 0:
+        # split of one step (untimed extra passes, torch events on the launch stream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        pred = run_desc.infer_step_device(tiles, net)
+        ev[1].record()
+        post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True)
+        ev[2].record()
+        torch.cuda.synchronize(dev)
+        result["config"]["network_ms"] = ev[0].elapsed_time(ev[1])
+        result["config"]["postproc_structured_ms"] = ev[1].elapsed_time(ev[2])
 
     if rank == 0 and not args.no_roofline:
         eng = net.engine(args.batch)
@@ -126,7 +146,19 @@ def main():
         from oracle import net_torch
         from oracle import postproc as O
 
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # torch-CPU does not scale to every hardware thread of a big host: pick the thread count that
+        # runs one mid-size conv fastest, and report it as `cores`
+        import torch.nn.functional as F
+        xx, ww = torch.randn(2, 256, 66, 66), torch.randn(256, 256, 3, 3)
+        best = (1e9, 1)
+        for th in sorted({t for t in (8, 16, 32, 64, 96, 128, cores) if t <= cores}):
+            torch.set_num_threads(th)
+            F.conv2d(xx, ww, padding=1)
+            t1 = time.perf_counter()
+            F.conv2d(xx, ww, padding=1)
+            best = min(best, (time.perf_counter() - t1, th))
+        cores = best[1]
         torch.set_num_threads(cores)
         cpu_tiles = tiles.cpu()
 
