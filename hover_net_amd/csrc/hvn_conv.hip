@@ -5,9 +5,11 @@
 // logit heads (hvn_net_ops.hip).
 //
 // GEMM view:  D[m][co] = sum_k A[m][k] * Wt[co][k],   m = (n, oy, ox) output pixel,
-//             k = (tap, ci) with ci fastest.  Activations are channels-last, so one
+//             k = (32-channel slab, tap, ci).  Activations are channels-last, so one
 //             k-chunk of 32 is 128 contiguous bytes of A; weights are pre-packed
-//             [cout_pad][taps][cin] so the same holds for B.
+//             [cout_pad][cin/32][taps][32] so the same holds for B.  All taps of one slab
+//             are walked before the next slab: the shifted windows of a 5x5 / 3x3 filter
+//             re-read the same ~50 KB of input from L1/L2 instead of HBM.
 // Tile:       128 pixels x {128,64,32} output channels per 256-thread workgroup,
 //             BK = 32, double-buffered LDS.  The global loads of k-step t+1 are issued
 //             RAW before the MFMAs of step t and only touched (prologue BN+ReLU, zero
@@ -27,6 +29,9 @@
 //             cout tile) get the same blockIdx % 8, i.e. the same XCD L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "hvn_kernels.h"
 
@@ -36,7 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #define BK 32
 #define LDS_LD 36  // padded row length in floats
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -63,32 +68,43 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     const unsigned m0 = (unsigned)m_tile * BM;
     const int n0 = n_tile * BN;
     const unsigned M = (unsigned)p.M;
+    // De-phase the two workgroups that share a CU (dispatched 256 apart): in lockstep their
+    // barrier / staging phases coincide and leave the matrix pipe idle; half a k-step apart one
+    // wave's MFMAs cover the other's staging.  Pure timing, no effect on results.
+    if (p.stagger && ((blockIdx.x >> 8) & 1))
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks each
 
     // ---- per-thread staging coordinates --------------------------------------------
+    // Addressing is split into a wave-UNIFORM 64-bit base that moves with the k-step (scalar ALU)
+    // and a per-thread 32-bit byte offset that never changes (global_load saddr + voffset form):
+    // the k-loop then carries no vector address arithmetic at all.
     const int srow = tid >> 3;      // 0..31
     const int scol = (tid & 7) * 4; // float offset inside the 32-wide k chunk
     const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
-    long a_off[PA];
+    const unsigned n_blk = m0 / HoWo;                                        // sample of the tile's first row
+    const long padoff = (long)p.pad_t * p.xsy + (long)p.pad_l * p.xsx;       // keeps every thread offset >= 0
+    unsigned a_voff[PA];
     int a_iy[PA], a_ix[PA];
+    unsigned rowmask = 0;
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const unsigned m = m0 + srow + 32 * j;
-        if (m < M) {
-            const unsigned n = m / HoWo;
-            const unsigned rem = m - n * HoWo;
-            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
-            a_iy[j] = (int)oy * p.stride - p.pad_t;
-            a_ix[j] = (int)ox * p.stride - p.pad_l;
-            a_off[j] = (long)n * p.xsn + (long)a_iy[j] * p.xsy + (long)a_ix[j] * p.xsx + scol;
-        } else {
-            a_iy[j] = -(1 << 28);
-            a_ix[j] = -(1 << 28);
-            a_off[j] = 0;
-        }
+        const bool ok = m < M;
+        const unsigned mm = ok ? m : m0;
+        const unsigned n = mm / HoWo;
+        const unsigned rem = mm - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        a_iy[j] = ok ? (int)oy * p.stride - p.pad_t : -(1 << 28);
+        a_ix[j] = ok ? (int)ox * p.stride - p.pad_l : -(1 << 28);
+        a_voff[j] = (unsigned)(((long)(n - n_blk) * p.xsn + (long)(oy * p.stride) * p.xsy + (long)(ox * p.stride) * p.xsx + scol) * 4);
+        rowmask |= ok ? (1u << j) : 0u;
     }
+    const unsigned safe_voff = (unsigned)(padoff * 4) + scol * 4;            // -> tap-shifted pixel (0,0) of sample n_blk
+    const float *xblk = p.x + (long)n_blk * p.xsn - padoff;
     const long Ktot = (long)p.KH * p.KW * p.Cin;
-    const float *wrow0 = p.w + (long)(n0 + srow) * Ktot + scol;
-    const long wstep = 32 * Ktot;  // 32 weight rows further per staging pass
+    unsigned w_voff[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) w_voff[j] = (unsigned)(((long)(n0 + srow + 32 * j) * Ktot + scol) * 4);
 
     const int kchunks = p.Cin / BK;
     const int KT = p.KH * p.KW * kchunks;
@@ -97,48 +113,62 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     const float pre_lo = has_pre ? 0.f : -__builtin_inff();
     const float *pre_s = has_pre ? p.pre_s : p.w;  // any valid address; value unused when !has_pre
     const float *pre_b = has_pre ? p.pre_b : p.w;
+    const int pre_step = has_pre ? BK : 0;
 
-    f32x4 ra[PA], rb[PB], rps, rpb;
-    unsigned okmask = 0;
-    int ld_r = 0, ld_s = 0, ld_c = 0;  // tap row / col / channel-chunk of the NEXT load
+    // two register stages: the loads of k-step t+2 are issued while step t computes and are first
+    // touched in the tail of step t+1 (>= one full step of matrix work hides HBM / Infinity-Cache latency)
+    struct Stage {
+        f32x4 ra[PA], rb[PB], rps, rpb;
+        unsigned okmask;
+    };
+    Stage s0, s1;
+    s0.okmask = s1.okmask = rowmask;
+    int ld_r = 0, ld_s = 0, ld_c = 0;  // tap row / col / channel slab of the NEXT load
 
     // issue the raw loads of one k-step (nothing here waits on memory)
-    auto load_global = [&](int kt) {
-        const long tap_off = (long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BK;
-        rps = *(const f32x4 *)(pre_s + (has_pre ? ld_c * BK + scol : 0));
-        rpb = *(const f32x4 *)(pre_b + (has_pre ? ld_c * BK + scol : 0));
-        okmask = 0;
+    auto load_global = [&](Stage &st, int kt) {
+        // uniform bases (SALU)
+        const char *abase = (const char *)(xblk + (long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BK);
+        const char *wbase = (const char *)(p.w + (long)kt * BK);
+        const char *sbase = (const char *)(pre_s + ld_c * pre_step);
+        const char *bbase = (const char *)(pre_b + ld_c * pre_step);
+        st.rps = *(const f32x4 *)(sbase + (unsigned long)(unsigned)(scol * 4));
+        st.rpb = *(const f32x4 *)(bbase + (unsigned long)(unsigned)(scol * 4));
+        if constexpr (PADDED) st.okmask = 0;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const bool ok = (unsigned)(a_iy[j] + ld_r) < (unsigned)p.H && (unsigned)(a_ix[j] + ld_s) < (unsigned)p.W;
-            const float *src = ok ? (p.x + a_off[j] + tap_off) : p.x;  // out-of-image taps read a safe address
-            ra[j] = *(const f32x4 *)src;
-            okmask |= ok ? (1u << j) : 0u;
+            unsigned vo = a_voff[j];
+            if constexpr (PADDED) {
+                const bool ok = (unsigned)(a_iy[j] + ld_r) < (unsigned)p.H && (unsigned)(a_ix[j] + ld_s) < (unsigned)p.W;
+                vo = ok ? vo : safe_voff;  // out-of-image taps read a safe address and are zeroed later
+                st.okmask |= ok ? (1u << j) : 0u;
+            }
+            st.ra[j] = *(const f32x4 *)(abase + (unsigned long)vo);
         }
 #pragma unroll
-        for (int j = 0; j < PB; ++j) rb[j] = *(const f32x4 *)(wrow0 + j * wstep + (long)kt * BK);
-        // advance (ci fastest, then tap column, then tap row)
-        if (++ld_c == kchunks) {
-            ld_c = 0;
-            if (++ld_s == p.KW) {
-                ld_s = 0;
-                ++ld_r;
+        for (int j = 0; j < PB; ++j) st.rb[j] = *(const f32x4 *)(wbase + (unsigned long)w_voff[j]);
+        // advance: tap column, tap row, then the next 32-channel slab
+        if (++ld_s == p.KW) {
+            ld_s = 0;
+            if (++ld_r == p.KH) {
+                ld_r = 0;
+                ++ld_c;
             }
         }
     };
     // first touch of the loaded registers: pre-activation BN+ReLU, zero padding, park in LDS
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](Stage &st, int buf) {
         float *a = As + buf * BM * LDS_LD;
         float *b = Bs + buf * BN * LDS_LD;
-        f32x4 ps = rps, pb = rpb;
+        f32x4 ps = st.rps, pb = st.rpb;
         if (!has_pre) {
             ps = (f32x4){1.f, 1.f, 1.f, 1.f};
             pb = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const bool ok = (okmask >> j) & 1u;
-            f32x4 v = ra[j];
+            const bool ok = (st.okmask >> j) & 1u;
+            f32x4 v = st.ra[j];
             v.x = fmaxf(fmaf(v.x, ps.x, pb.x), pre_lo);
             v.y = fmaxf(fmaf(v.y, ps.y, pb.y), pre_lo);
             v.z = fmaxf(fmaf(v.z, ps.z, pb.z), pre_lo);
@@ -150,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
             *(f32x4 *)(a + (srow + 32 * j) * LDS_LD + scol) = v;
         }
 #pragma unroll
-        for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * LDS_LD + scol) = rb[j];
+        for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * LDS_LD + scol) = st.rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -161,11 +191,13 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int cur) {
+    // MFMAs of the k-sub-chunks [Q0, Q1) (8 reduction indices each) of LDS buffer `cur`
+    auto compute = [&](int cur, auto q0c, auto q1c) {
+        constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
         const float *a = As + cur * BM * LDS_LD + (wm * WM + l31) * LDS_LD + 4 * lh;
         const float *b = Bs + cur * BN * LDS_LD + (wn * WN + l31) * LDS_LD + 4 * lh;
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
+        for (int q = Q0; q < Q1; ++q) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4 *)(a + i * 32 * LDS_LD + q * 8);
@@ -182,19 +214,71 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
                 }
         }
     };
+    using std::integral_constant;
+    constexpr int NQ = BK / 8;
+    constexpr int QT = (16 / (TM * TN * 4)) > 0 ? ((16 / (TM * TN * 4)) < NQ ? (16 / (TM * TN * 4)) : NQ) : 1;  // tail sub-chunks (>= 16 MFMAs)
+    constexpr int TAIL_MFMA = QT * TM * TN * 4;
 
-    load_global(0);
-    store_lds(0);
+    // one k-step: (1) optionally issue the loads two steps ahead, (2) the bulk of the MFMAs with only
+    // LDS reads riding along, (3) the last >=16 MFMAs cover the first touch of the stage loaded one step
+    // ago -- prologue BN+ReLU, padding select and ds_writes sit in the 64-cycle shadow of each MFMA
+    auto step = [&](Stage &ld, Stage &stg, int kt, auto do_load) {
+        if constexpr (decltype(do_load)::value && ABL < 1) load_global(ld, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABL == 3) {
+            f32x4 fa0 = stg.ra[0], fb0 = stg.rb[0];  // pure MFMA: fragments held in registers
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.x, fb0.x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.y, fb0.y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.z, fb0.z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.w, fb0.w, acc[i][j], 0, 0, 0);
+                    }
+        } else {
+            compute(kt & 1, integral_constant<int, 0>{}, integral_constant<int, NQ - QT>{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt & 1, integral_constant<int, NQ - QT>{}, integral_constant<int, NQ>{});
+        }
+        if constexpr (ABL < 2) {
+            store_lds(stg, (kt + 1) & 1);
+#pragma unroll
+            for (int g = 0; g < TAIL_MFMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            }
+            __syncthreads();
+        }
+    };
+    const std::true_type LOAD{};
+    const std::false_type NOLOAD{};
+
+    // data of k-step j travels in stage (j & 1)
+    load_global(s0, 0);
+    store_lds(s0, 0);
+    if (KT > 1) load_global(s1, 1);
     __syncthreads();
-    // steady state: issue the global loads of step kt+1, run the MFMAs of step kt out of
-    // LDS buffer kt&1, then park the loaded registers in the other buffer; one barrier per step
-    for (int kt = 0; kt < KT - 1; ++kt) {
-        load_global(kt + 1);
-        compute(kt & 1);
-        store_lds((kt + 1) & 1);
-        __syncthreads();
+    int kt = 0;
+    for (; kt + 3 < KT; kt += 2) {  // steps kt (even) and kt+1 (odd), both with a load two ahead
+        step(s0, s1, kt, LOAD);
+        step(s1, s0, kt + 1, LOAD);
     }
-    compute((KT - 1) & 1);
+    if (kt + 2 < KT) {              // one more loading step (kt even)
+        step(s0, s1, kt, LOAD);
+        ++kt;
+        if (kt + 1 < KT) {          // step KT-2 (odd): stage of step KT-1 is s0
+            step(s1, s0, kt, NOLOAD);
+            ++kt;
+        }
+    } else if (kt + 1 < KT) {       // step KT-2 (even): stage of step KT-1 is s1
+        step(s0, s1, kt, NOLOAD);
+        ++kt;
+    }
+    compute((KT - 1) & 1, integral_constant<int, 0>{}, integral_constant<int, NQ>{});
     __syncthreads();
 
     // ---- epilogue ------------------------------------------------------------------
@@ -266,15 +350,21 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0>
 static int launch_conv(const ConvArgs &a, hipStream_t stream)
 {
     ConvArgs p = a;
+    static int stagger = -1;
+    if (stagger < 0) {
+        const char *e = getenv("HVN_CONV_STAGGER");
+        stagger = e ? atoi(e) : 0;
+    }
+    p.stagger = stagger;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
-    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N>;
+    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
@@ -291,10 +381,26 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
 {
     if (a.Cin % BK != 0 || a.Cin <= 0 || a.Cout % 4 != 0) return -1;
     if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;  // 32-bit pixel index arithmetic in the kernel
+    // 32-bit per-thread byte offsets: a tile spans at most two consecutive samples of the input view
+    const long span = 2 * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
+    if (span < 0 || span * 4 >= (1L << 32)) return -1;
+    if ((long)(a.Cout + 128) * a.KH * a.KW * a.Cin * 4 >= (1L << 32)) return -1;
+    // "padded" = some tap of some output pixel falls outside the input window
+    const bool padded = a.pad_t > 0 || a.pad_l > 0 || (a.Ho - 1) * a.stride - a.pad_t + a.KH > a.H ||
+                        (a.Wo - 1) * a.stride - a.pad_l + a.KW > a.W;
+    static int abl = -1;
+    if (abl < 0) {
+        const char *e = getenv("HVN_CONV_ABLATE");
+        abl = e ? atoi(e) : 0;
+    }
     switch (tile_n) {
-    case 128: return launch_conv<128, 128, 2, 2>(a, stream);
-    case 64: return launch_conv<128, 64, 4, 1>(a, stream);
-    case 32: return launch_conv<128, 32, 4, 1>(a, stream);
+    case 128:
+        if (abl == 1) return launch_conv<128, 128, 2, 2, true, 1>(a, stream);
+        if (abl == 2) return launch_conv<128, 128, 2, 2, true, 2>(a, stream);
+        if (abl == 3) return launch_conv<128, 128, 2, 2, true, 3>(a, stream);
+        return padded ? launch_conv<128, 128, 2, 2, true>(a, stream) : launch_conv<128, 128, 2, 2, false>(a, stream);
+    case 64: return padded ? launch_conv<128, 64, 4, 1, true>(a, stream) : launch_conv<128, 64, 4, 1, false>(a, stream);
+    case 32: return padded ? launch_conv<128, 32, 4, 1, true>(a, stream) : launch_conv<128, 32, 4, 1, false>(a, stream);
     default: return -1;
     }
 }

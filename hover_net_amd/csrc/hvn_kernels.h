@@ -17,6 +17,7 @@ struct ConvArgs {
     long M;
     long m_tiles;
     int n_tiles;
+    int stagger;
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);

@@ -82,7 +82,7 @@ class Op:
     x: View = None
     y: View = None
     res: View = None
-    w: np.ndarray = None        # CONV: [cout_pad, kh*kw, cin]; CONV0: [7,7,3,64]; HEAD: [cout, 64]
+    w: np.ndarray = None        # CONV: [cout_pad, cin/32, kh*kw, 32]; CONV0: [7,7,3,64]; HEAD: [cout, 64]
     bias: np.ndarray = None
     pre: tuple = None           # (scale[cin], shift[cin])
     post: tuple = None          # (scale[cout], shift[cout])
@@ -131,20 +131,30 @@ def _tile_n(cout):
 
 
 def _pack_conv(wt, out_scale=None, groups=1):
-    """[cout, cin/groups, kh, kw] (torch) -> [cout_pad, kh*kw, cin] fp32, BN scale folded in
-    float64, grouped convs expanded to block-diagonal dense."""
+    """[cout, cin/groups, kh, kw] (torch) -> [cout_pad, cin/32, kh*kw, 32] fp32: BN scale folded in
+    float64, grouped convs expanded to block-diagonal dense, and the reduction index ordered
+    (channel chunk of 32, tap, channel) -- the kernel walks all taps of one 32-channel slab before the
+    next slab, so the shifted input windows of the taps are re-read from L1/L2 instead of HBM."""
     cout, cin_g, kh, kw = wt.shape
     if out_scale is not None:
         wt = wt * out_scale[:, None, None, None]
     cin = cin_g * groups
+    assert cin % 32 == 0
     tn = _tile_n(cout)
     cout_pad = (cout + tn - 1) // tn * tn
-    packed = np.zeros((cout_pad, kh * kw, cin), np.float64)
+    dense = np.zeros((cout_pad, kh * kw, cin), np.float64)
     og = cout // groups
     for g in range(groups):
         blk = wt[g * og:(g + 1) * og]                                  # [og, cin_g, kh, kw]
-        packed[g * og:(g + 1) * og, :, g * cin_g:(g + 1) * cin_g] = blk.transpose(0, 2, 3, 1).reshape(og, kh * kw, cin_g)
+        dense[g * og:(g + 1) * og, :, g * cin_g:(g + 1) * cin_g] = blk.transpose(0, 2, 3, 1).reshape(og, kh * kw, cin_g)
+    packed = dense.reshape(cout_pad, kh * kw, cin // 32, 32).transpose(0, 2, 1, 3)
     return np.ascontiguousarray(packed, np.float32), tn
+
+
+def unpack_conv(w, cout):
+    """Inverse of the packing for interpreters: -> [cout, cin, taps] float32."""
+    cout_pad, chunks, taps, _ = w.shape
+    return np.ascontiguousarray(w[:cout].transpose(0, 1, 3, 2).reshape(cout, chunks * 32, taps))
 
 
 class Plan:
@@ -183,7 +193,7 @@ class Plan:
             s, b = bn
         w, tn = _pack_conv(wt, s, groups)
         cout, _cin_g, kh, kw = wt.shape
-        assert x.c == w.shape[2] and y.c == cout, (name, x.c, w.shape, y.c, cout)
+        assert x.c == w.shape[1] * 32 and y.c == cout, (name, x.c, w.shape, y.c, cout)
         assert y.h == (x.h + pad[0] + pad[1] - kh) // stride + 1, (name, x.h, y.h)
         if bias is not None:
             b = bias if b is None else b + bias

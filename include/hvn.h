@@ -46,7 +46,8 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *   CONV0   x = image, uint8 (x_dtype 0; infer_step hands NHWC bytes) or float32 0..255 (x_dtype 1;
  *           HoVerNet.forward's NCHW contract), w = [kh][kw][3][64] taps (1/255 and BN folded), bias, relu
  *   CONV    y = epi( conv( pro(x) ) ):  pro = relu(x*pre_scale+pre_shift) if pre_scale,
- *           w = [cout_pad][kh*kw][x.c] fp32 (cout_pad = multiple of tile_n),
+ *           w = [cout_pad][x.c/32][kh*kw][32] fp32 (cout_pad = multiple of tile_n; reduction order =
+ *           32-channel slab, tap, channel),
  *           epi = (+bias) (relu) (+res) (relu(.*post_scale+post_shift) if post_scale)
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]

@@ -38,8 +38,8 @@ def conv_ref(op, x, res=None):
     """x: [N,h,w,cin] NHWC view tensor -> [N,ho,wo,cout]."""
     if op.pre is not None:
         x = F.relu(x * torch.from_numpy(op.pre[0]) + torch.from_numpy(op.pre[1]))
-    cout_pad, taps, cin = op.w.shape
-    w = torch.from_numpy(op.w[:op.cout]).view(op.cout, op.kh, op.kw, cin).permute(0, 3, 1, 2)
+    w = torch.from_numpy(PL.unpack_conv(op.w, op.cout))
+    w = w.view(op.cout, w.shape[1], op.kh, op.kw)
     xin = x.permute(0, 3, 1, 2)
     ho, wo = op.y.h, op.y.w
     pad_b = (ho - 1) * op.stride + op.kh - x.shape[1] - op.pad_t
