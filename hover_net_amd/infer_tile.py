@@ -1,0 +1,168 @@
+"""Tile inference over one node's GPUs -- the data-parallel core of
+`infer/tile.py:InferManager.process_file_list` (/root/reference/infer/tile.py:150-387).
+
+What is kept from the reference: the patch geometry of `_prepare_patching`
+(infer/tile.py:46-94: reflect padding, `step = mask_size`, patch order), the stitching of
+`_post_process_patches` (infer/tile.py:98-131: sort by (y, x), reshape/transpose, crop to the
+source shape) and `post_proc.process` on the stitched map.
+
+What is different by design: the reference wraps the model in `nn.DataParallel`
+(infer/base.py:69: one process, weights re-broadcast every forward, outputs gathered on GPU 0)
+and post-processes in a CPU process pool.  Here there is ONE PROCESS PER GPU
+(torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests):
+patches are sharded by contiguous ranges over the ranks, weights stay resident per rank, the
+per-patch prediction maps (102 KB each) are exchanged with a single all_gather per call, images
+are then dealt round-robin to the ranks for stitching + on-GPU instance separation, and only
+int32 instance maps travel back.  Tiles are independent, so this is the only collective.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+# --------------------------------------------------------------------------------------------
+# geometry (host logic, numpy)
+def prepare_patching(img, window_size, mask_size):
+    """-> (reflect-padded image, patch_info int32 [P,4] = [y, x, row, col]) with the reference's
+    padding rule and patch order (infer/tile.py:60-90: x outer, y inner)."""
+    step = mask_size
+    im_h, im_w = img.shape[0], img.shape[1]
+
+    def last_step(length):
+        nr = math.ceil((length - mask_size) / step)
+        return int((nr + 1) * step), int(nr + 1)
+
+    last_h, nr_h = last_step(im_h)
+    last_w, nr_w = last_step(im_w)
+    pad_tl = (window_size - step) // 2
+    padded = np.pad(img, ((pad_tl, last_h + window_size - im_h), (pad_tl, last_w + window_size - im_w), (0, 0)), "reflect")
+    ys = np.arange(0, last_h, step, dtype=np.int32)
+    xs = np.arange(0, last_w, step, dtype=np.int32)
+    info = np.empty((nr_w * nr_h, 4), np.int32)
+    k = 0
+    for ci, x in enumerate(xs):
+        for ri, y in enumerate(ys):
+            info[k] = (y, x, ri, ci)
+            k += 1
+    return padded, info
+
+
+def extract_patches(padded, info, window_size):
+    """uint8 [P, win, win, 3] (infer_loader.py:59-72 without the worker processes)."""
+    out = np.empty((info.shape[0], window_size, window_size, padded.shape[2]), padded.dtype)
+    for k, (y, x, _r, _c) in enumerate(info):
+        out[k] = padded[y:y + window_size, x:x + window_size]
+    return out
+
+
+def stitch(patch_maps, info, src_shape):
+    """patch_maps: tensor/array [P, h, w, C] in `info` order -> [src_h, src_w, C]
+    (infer/tile.py:111-131).  Works on torch tensors (device) and numpy alike."""
+    order = sorted(range(info.shape[0]), key=lambda k: (int(info[k][0]), int(info[k][1])))
+    nr_row = int(info[:, 2].max()) + 1
+    nr_col = int(info[:, 3].max()) + 1
+    h, w, c = patch_maps.shape[1:]
+    pm = patch_maps[torch.as_tensor(order, device=patch_maps.device)] if torch.is_tensor(patch_maps) else patch_maps[order]
+    pm = pm.reshape(nr_row, nr_col, h, w, c)
+    pm = pm.permute(0, 2, 1, 3, 4) if torch.is_tensor(pm) else pm.transpose(0, 2, 1, 3, 4)
+    pm = pm.reshape(nr_row * h, nr_col * w, c)
+    return pm[:src_shape[0], :src_shape[1]]
+
+
+# --------------------------------------------------------------------------------------------
+# rank sharding (torch.distributed; no collective when world == 1)
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced partition: the first n % world ranks take one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def gather_shards(local, n_items):
+    """local: this rank's [n_local, ...] slice (shard_range order) -> the full [n_items, ...] on
+    EVERY rank with one all_gather (shards padded to equal length)."""
+    dist, rank, world = _dist()
+    if world == 1:
+        return local
+    per = -(-n_items // world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_items, r, world)
+        parts.append(out[r * per:r * per + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def run_sharded(items, step_fn, batch_size):
+    """Apply `step_fn(batch) -> tensor [b, ...]` to this rank's contiguous share of `items`
+    ([P, ...] tensor) in batches and return the result for ALL items on every rank."""
+    _, rank, world = _dist()
+    lo, hi = shard_range(items.shape[0], rank, world)
+    outs = []
+    for b0 in range(lo, hi, batch_size):
+        outs.append(step_fn(items[b0:min(b0 + batch_size, hi)]).clone())
+    if outs:
+        local = torch.cat(outs, 0)
+    else:  # more ranks than items: contribute an empty slice of the right trailing shape
+        probe = step_fn(items[:1])
+        local = probe[:0].clone()
+    return gather_shards(local, items.shape[0])
+
+
+# --------------------------------------------------------------------------------------------
+def process_images(images, model, nr_types=None, batch_size=32, return_centroids=True):
+    """images: list of uint8 [H,W,3] arrays (RGB).  Returns, on every rank, a list of
+    (pred_inst int32 [H,W] numpy, inst_info_dict | None) in input order.
+
+    Pipeline per call: host patch extraction -> sharded HIP network (`run_desc.infer_step_device`)
+    -> one all_gather of the per-patch maps -> per-image stitch on the GPU -> on-GPU instance
+    separation + instance table (`post_proc.process_batch_device`) for the images this rank owns
+    -> all_gather of the int32 instance maps."""
+    from . import post_proc, run_desc
+
+    net = model.module if hasattr(model, "module") and not hasattr(model, "engine") else model
+    win = 270 if net.mode == "original" else 256
+    msk = 80 if net.mode == "original" else 164   # run_infer.py:145-150
+    dev = next(net.parameters()).device
+    infos, patches, owners = [], [], []
+    for i, img in enumerate(images):
+        padded, info = prepare_patching(img, win, msk)
+        infos.append(info)
+        patches.append(extract_patches(padded, info, win))
+        owners += [i] * info.shape[0]
+    all_patches = torch.from_numpy(np.concatenate(patches, 0))
+    pred = run_sharded(all_patches, lambda b: run_desc.infer_step_device(b.to(dev), model), batch_size)
+    _, rank, world = _dist()
+    results = [None] * len(images)
+    k = 0
+    for i, img in enumerate(images):
+        n = infos[i].shape[0]
+        if i % world == rank:
+            full = stitch(pred[k:k + n], infos[i], img.shape).contiguous()
+            inst, rec, _ = post_proc.process_batch_device(full.unsqueeze(0), nr_types, return_centroids)
+            info = None
+            if rec is not None:
+                info = post_proc.records_to_dict(rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1), nr_types)
+            results[i] = (inst[0].cpu().numpy(), info)
+        k += n
+    if world > 1:
+        import torch.distributed as dist
+
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {i: r for i, r in enumerate(results) if r is not None})
+        for part in gathered:
+            for i, r in part.items():
+                results[i] = r
+    return results

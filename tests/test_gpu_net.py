@@ -89,3 +89,25 @@ def test_stage_taps_match_interpreter():
         got = eng.buffer(op.y, 1).cpu()
         err = (got - taps[op.name]).abs().max().item()
         assert err <= 2e-4, (op.name, err)
+
+
+def test_process_images_tile_pipeline():
+    """infer/tile.py route (mode B of SURVEY 8d): one 270x270 image -> 16 patches -> stitched map ->
+    on-GPU instance separation; equals the step-by-step pipeline and the C oracle on the same map."""
+    from hover_net_amd import infer_tile, post_proc, run_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    from oracle import postproc as O
+
+    sd = synth_state_dict("original", 5, seed=51)
+    net = _model("original", 5, sd)
+    img = synth_tiles(1, 300, seed=52)[0][:, :283]      # ragged, non-square source image
+    (inst, info), = infer_tile.process_images([img], net, nr_types=5, batch_size=8)
+    assert inst.shape == img.shape[:2] and inst.dtype == np.int32
+    padded, pinfo = infer_tile.prepare_patching(img, 270, 80)
+    patches = torch.from_numpy(infer_tile.extract_patches(padded, pinfo, 270))
+    maps = np.concatenate([run_desc.infer_step(patches[i:i + 8], net) for i in range(0, patches.shape[0], 8)])
+    full = infer_tile.stitch(maps, pinfo, img.shape)
+    np.testing.assert_array_equal(inst, O.proc_np_hv(np.ascontiguousarray(full[..., 1:])))
+    inst2, info2 = post_proc.process(np.ascontiguousarray(full), nr_types=5, return_centroids=True)
+    np.testing.assert_array_equal(inst, inst2)
+    assert sorted(info.keys()) == sorted(info2.keys())
