@@ -3,7 +3,8 @@
 
 One *step* = one pass of the whole hot path over one batch of synthetic input already resident
 in HBM: 32 uint8 270x270 tiles -> HIP network (original mode, 5 types, fp32) -> infer_step
-epilogue -> on-GPU instance separation (Sobel/threshold/CC/watershed) + per-instance table.
+epilogue -> on-GPU instance separation (Sobel/threshold/CC/watershed) + per-instance table, the
+latter on a side stream so that it overlaps the next step's network (hover_net_amd/pipeline.py).
 No host round trip inside the step.  N > 1: one process per GPU (torch.distributed / RCCL for
 the barrier and the max-over-ranks clock only); tiles are independent units, so every rank
 processes its own batches and there is no data-path collective ("weak" scaling).
@@ -72,10 +73,13 @@ def main():
     out_hw = net.engine(args.batch).plan.geo["out"]
     structured = torch.from_numpy(synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank)[0]).to(dev)
 
+    from hover_net_amd.pipeline import TilePipeline
+
+    # network of step i+1 (main stream) overlaps the post-processing of step i (side stream)
+    pipe = TilePipeline(net, nr_types=nt, return_centroids=True)
+
     def step():
-        pred = run_desc.infer_step_device(tiles, net)
-        post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True)
-        return post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True)
+        return pipe.submit(tiles, extra_maps=structured)
 
     def fence():
         torch.cuda.synchronize(dev)

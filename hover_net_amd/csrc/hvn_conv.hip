@@ -219,12 +219,17 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     constexpr int QT = (16 / (TM * TN * 4)) > 0 ? ((16 / (TM * TN * 4)) < NQ ? (16 / (TM * TN * 4)) : NQ) : 1;  // tail sub-chunks (>= 16 MFMAs)
     constexpr int TAIL_MFMA = QT * TM * TN * 4;
 
-    // one k-step: (1) optionally issue the loads two steps ahead, (2) the bulk of the MFMAs with only
-    // LDS reads riding along, (3) the last >=16 MFMAs cover the first touch of the stage loaded one step
-    // ago -- prologue BN+ReLU, padding select and ds_writes sit in the 64-cycle shadow of each MFMA
+    // one k-step, three scheduling segments (sched_barrier pins their order, sched_group_barrier the
+    // interleave inside):
+    //   (1) first MFMAs of the step, each followed by one of the global loads for step kt+2
+    //       (a VMEM issue stalls its wave for tens of cycles: hidden in the 64-cycle MFMA shadow)
+    //   (2) middle MFMAs carrying the first touch of the stage loaded one step ago: prologue BN+ReLU,
+    //       padding select, ds_write into the other LDS buffer
+    //   (3) remaining MFMAs; by the barrier every wave's LDS writes are long retired
     auto step = [&](Stage &ld, Stage &stg, int kt, auto do_load) {
-        if constexpr (decltype(do_load)::value && ABL < 1) load_global(ld, kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PER_Q = TM * TN * 4;                       // MFMAs per k-sub-chunk of 8
+        constexpr int Q1 = (NQ >= 4 && PER_Q >= 8) ? 1 : NQ / 2;  // sub-chunks in segment 1
+        constexpr int Q2 = (NQ >= 4 && PER_Q >= 8) ? 3 : NQ;      // end of segment 2
         if constexpr (ABL == 3) {
             f32x4 fa0 = stg.ra[0], fb0 = stg.rb[0];  // pure MFMA: fragments held in registers
 #pragma unroll
@@ -238,21 +243,33 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.z, fb0.z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.w, fb0.w, acc[i][j], 0, 0, 0);
                     }
-        } else {
-            compute(kt & 1, integral_constant<int, 0>{}, integral_constant<int, NQ - QT>{});
-            __builtin_amdgcn_sched_barrier(0);
-            compute(kt & 1, integral_constant<int, NQ - QT>{}, integral_constant<int, NQ>{});
+            return;
         }
+        // ---- segment 1 ----
+        compute(kt & 1, integral_constant<int, 0>{}, integral_constant<int, Q1>{});
+        if constexpr (decltype(do_load)::value && ABL < 1) load_global(ld, kt + 2);
+#pragma unroll
+        for (int g = 0; g < Q1 * PER_Q; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);  // VALU | SALU (address of the next load)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- segment 2 ----
+        compute(kt & 1, integral_constant<int, Q1>{}, integral_constant<int, Q2>{});
         if constexpr (ABL < 2) {
             store_lds(stg, (kt + 1) & 1);
 #pragma unroll
-            for (int g = 0; g < TAIL_MFMA; ++g) {
+            for (int g = 0; g < (Q2 - Q1) * PER_Q; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
             }
-            __syncthreads();
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- segment 3 ----
+        if constexpr (Q2 < NQ) compute(kt & 1, integral_constant<int, Q2>{}, integral_constant<int, NQ>{});
+        if constexpr (ABL < 2) __syncthreads();
     };
     const std::true_type LOAD{};
     const std::false_type NOLOAD{};

@@ -27,11 +27,18 @@ def _view_struct(v, base_ptr, sn, itemsize=4):
 
 
 class Engine:
-    def __init__(self, plan, max_batch=32, device="cuda"):
+    def __init__(self, plan, max_batch=32, device="cuda", n_split=None):
         L.require_gpu()
         self.plan = plan
         self.max_batch = int(max_batch)
         self.device = torch.device(device)
+        # A forward is a dependent chain of ~150 launches, many of which fill the 512 workgroup slots
+        # of the chip only 1.5-4.x times (tail quantisation up to 29 %).  Splitting the batch into
+        # independent sub-batches on their own HIP streams lets the tail of one chain be filled by
+        # the other's workgroups.
+        import os
+        self.n_split = int(os.environ.get("HVN_SPLIT", "2")) if n_split is None else int(n_split)
+        self._streams = None
         self._upload_params()
         self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32, device=self.device)
         self.logits = {br: torch.empty((self.max_batch, b.c, b.h, b.w), dtype=torch.float32, device=self.device)
@@ -42,6 +49,7 @@ class Engine:
             self.pred_map = torch.empty((self.max_batch, pm.h, pm.w, pm.c), dtype=torch.float32, device=self.device)
         self.ops = (L.hvn_op * len(plan.ops))()
         self._bind()
+        self._sub_ops = {}
 
     # ---------------------------------------------------------------------------------
     def _upload_params(self):
@@ -139,13 +147,62 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         L.check(L.lib().hvn_run_plan(ctypes.addressof(self.ops), len(self.ops), n, ctypes.c_void_p(stream)), "hvn_run_plan")
 
+    def _shifted_ops(self, first):
+        """A copy of the bound descriptors whose per-sample views start at sample `first`."""
+        key = first
+        if key not in self._sub_ops:
+            ops = (L.hvn_op * len(self.ops))()
+            ctypes.memmove(ops, self.ops, ctypes.sizeof(self.ops))
+            for i, op in enumerate(self.plan.ops):
+                o = ops[i]
+                for fld in ("x", "res", "y"):
+                    v = getattr(o, fld)
+                    if v.base:
+                        if op.kind == PL.OP_HEAD and fld == "y":
+                            v.base += 4 * first * op.y.c * op.y.h * op.y.w
+                        elif op.kind == PL.OP_PREDMAP:
+                            c = {"x": 2, "res": 2, "y": self.plan.pred_map.c}[fld]
+                            v.base += 4 * first * c * self.plan.pred_map.h * self.plan.pred_map.w
+                        elif op.kind == PL.OP_CONV0 and fld == "x":
+                            pass  # set per call
+                        else:
+                            v.base += 4 * first * v.sn
+                if op.kind == PL.OP_PREDMAP and o.w:
+                    o.w += 4 * first * (self.plan.nr_types or 0) * self.plan.pred_map.h * self.plan.pred_map.w
+            self._sub_ops[key] = ops
+        return self._sub_ops[key]
+
     def run(self, imgs, upto=None):
         """imgs: uint8 [N,H,W,3] or float32 [N,3,H,W] -> (logits dict of [N,C,h,w] views, pred_map [N,h,w,3|4] or None).
         The returned tensors alias engine-owned buffers that the next call overwrites."""
         imgs, n = self._set_input(imgs)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        main = torch.cuda.current_stream(self.device)
         n_ops = len(self.ops) if upto is None else upto
-        L.check(L.lib().hvn_run_plan(ctypes.addressof(self.ops), n_ops, n, ctypes.c_void_p(stream)), "hvn_run_plan")
+        split = self.n_split if (n >= 2 * self.n_split and self.n_split > 1) else 1
+        if split == 1:
+            L.check(L.lib().hvn_run_plan(ctypes.addressof(self.ops), n_ops, n, ctypes.c_void_p(main.cuda_stream)), "hvn_run_plan")
+        else:
+            if self._streams is None or len(self._streams) < split - 1:
+                self._streams = [torch.cuda.Stream(self.device) for _ in range(split - 1)]
+            o0 = self.ops[0]
+            esz = 1 if o0.x_dtype == 0 else 4
+            fork = torch.cuda.Event()
+            fork.record(main)
+            bounds = [n * k // split for k in range(split + 1)]
+            for k in range(split):
+                first, cnt = bounds[k], bounds[k + 1] - bounds[k]
+                ops = self._shifted_ops(first)
+                ops[0].x = o0.x
+                ops[0].x_dtype = o0.x_dtype
+                ops[0].x.base = o0.x.base + esz * first * o0.x.sn
+                st = main if k == 0 else self._streams[k - 1]
+                if k:
+                    st.wait_event(fork)
+                L.check(L.lib().hvn_run_plan(ctypes.addressof(ops), n_ops, cnt, ctypes.c_void_p(st.cuda_stream)), "hvn_run_plan")
+                if k:
+                    join = torch.cuda.Event()
+                    join.record(st)
+                    main.wait_event(join)
         self._keepalive = imgs
         logits = {br: t[:n] for br, t in self.logits.items()}
         return logits, (None if self.pred_map is None else self.pred_map[:n])

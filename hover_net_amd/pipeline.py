@@ -1,0 +1,65 @@
+"""Two-stream tile pipeline: the instance separation of batch i runs on a side HIP stream while the
+network of batch i+1 runs on the main stream.
+
+The reference overlaps these two stages with a CPU process pool next to the GPU loop
+(/root/reference/infer/tile.py:232-234, 361-386).  Here both stages are on the GPU: the network
+saturates the matrix cores, the post-processing is a chain of small latency-bound launches (its
+watershed uses one workgroup per tile), so running them concurrently hides the latter almost entirely.
+Hand-over is a 3.3 MB device copy of the prediction maps into one of two ping-pong buffers, ordered with
+HIP events (no host sync anywhere in `submit`).
+"""
+import torch
+
+from . import post_proc, run_desc
+
+
+class TilePipeline:
+    def __init__(self, model, nr_types=None, return_centroids=True, device=None):
+        self.model = model
+        self.nr_types = nr_types
+        self.return_centroids = return_centroids
+        net = model.module if hasattr(model, "module") and not hasattr(model, "engine") else model
+        self.device = torch.device(device) if device is not None else next(net.parameters()).device
+        self.side = torch.cuda.Stream(self.device)
+        self._pp = post_proc.PostProc(self.device)   # own workspace: used on the side stream only
+        self._buf = [None, None]
+        self._free = [None, None]                    # event: the side stream is done reading _buf[k]
+        self._n = 0
+        self._last = None
+
+    def submit(self, tiles_u8, extra_maps=None):
+        """Network on the current stream, post-processing on the side stream.  Returns
+        (inst, records, counts) device tensors that are valid after `wait()` (or after the side
+        stream is otherwise synchronised).  `extra_maps`: optional additional [N,h,w,C] maps to
+        post-process in the same side-stream slot (bench.py's structured workload)."""
+        main = torch.cuda.current_stream(self.device)
+        k = self._n & 1
+        self._n += 1
+        pred = run_desc.infer_step_device(tiles_u8, self.model)       # aliases the engine's buffer
+        if self._free[k] is not None:
+            main.wait_event(self._free[k])                             # ping-pong slot k is free again
+        if self._buf[k] is None or self._buf[k].shape != pred.shape:
+            self._buf[k] = torch.empty_like(pred)
+        self._buf[k].copy_(pred)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            out = self._run_pp(self._buf[k])
+            if extra_maps is not None:
+                out = self._run_pp(extra_maps)
+            self._free[k] = torch.cuda.Event()
+            self._free[k].record(self.side)
+        self._last = out
+        return out
+
+    def _run_pp(self, maps):
+        inst = self._pp.separate(maps)
+        if self.return_centroids or self.nr_types is not None:
+            rec, counts = self._pp.table(inst, maps, self.nr_types)
+            return inst, rec, counts
+        return inst, None, None
+
+    def wait(self):
+        self.side.synchronize()
+        return self._last
