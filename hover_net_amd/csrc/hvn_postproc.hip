@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/hvn.h"
 
@@ -69,7 +70,9 @@ __device__ __forceinline__ void norm_coeffs(double smin, double smax, float *a, 
 struct TileStat {
     unsigned h_min, h_max, v_min, v_max;               // ordered-uint of float32
     unsigned long long sh_min, sh_max, sv_min, sv_max;  // ordered-u64 of float64 sobel
-    int n_marker_roots;
+    int n_comp;      // mask components that hold at least one marker
+    int heap_top;    // bump pointer into the HBM heap plane (oversized components)
+    int tie;         // a component saw two equal-valued age-0 heap items: replay the tile globally
     int _pad;
 };
 
@@ -79,7 +82,7 @@ struct PPBuf {
     const float *pred;
     int32_t *inst;
     // planes of n*P elements
-    int32_t *blb, *par, *cnt, *mk, *par2, *lab;
+    int32_t *blb, *par, *cnt, *mk, *par2, *lab, *broot, *bsz;
     float *hraw, *vraw;
     double *rowh, *rowv, *sobh, *sobv, *overall, *dist, *blur;
     uint8_t *m8a, *m8b;
@@ -186,7 +189,11 @@ __global__ __launch_bounds__(PP_T) void pp_blb_filter(PPBuf b)
     if (i >= b.P) return;
     const long g = (long)n * b.P + i;
     const int r = b.par[g];
-    b.blb[g] = (r >= 0 && b.cnt[(long)n * b.P + uf_find(b.par + (long)n * b.P, r)] >= 10) ? 1 : 0;
+    const int sz = r >= 0 ? b.cnt[(long)n * b.P + r] : 0;
+    const int keep = sz >= 10;
+    b.blb[g] = keep;
+    b.broot[g] = keep ? r : -1;   // component id of the watershed mask = smallest raster index
+    b.bsz[g] = keep ? sz : 0;
 }
 
 // K6: Sobel-21 row pass of both maps (h: derivative taps, v: smoothing taps) on the
@@ -444,6 +451,7 @@ __device__ __forceinline__ bool h_smaller(const HItem &a, const HItem &b)
     return (a.ai >> 32) < (b.ai >> 32);
 }
 
+// Whole-tile replay (exact for any input; serial): used when a tile reports a marker tie.
 template <typename HP>
 __device__ void ws_flood(HP heap, const double *img, const int32_t *mask, int32_t *out, int H, int W)
 {
@@ -513,20 +521,214 @@ __device__ void ws_flood(HP heap, const double *img, const int32_t *mask, int32_
     }
 }
 
-__global__ __launch_bounds__(64) void pp_watershed(PPBuf b, int use_lds)
+// Per-component replay.  The flood never crosses a 4-connected component of the mask, and inside one
+// component the (value, age) order of its own heap items is the same whether the other components'
+// items are interleaved or not -- EXCEPT among age-0 items (the initial markers) of equal value, whose
+// order is an artefact of the global heap layout.  So every component is replayed
+// by its own workgroup, out of LDS, over its bounding box; a component that ever pops an age-0 item while
+// an equal (value, age 0) item is the new top raises the tile's `tie` flag and the tile is redone by the
+// whole-tile replay above.  VAL / OUT index the bounding-box window [bh][bw]; OUT is -1 outside the component.
+template <typename HP, typename VP, typename OP>
+__device__ bool ws_flood_window(HP heap, VP val, OP out, int bh, int bw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
+    const int A = bh * bw;
+    int hn = 0;
+    bool tie = false;
+    auto push = [&](HItem it) {
+        int child = hn++;
+        while (child > 0) {
+            const int parent = (child + 1) / 2 - 1;
+            HItem pv = heap[parent];
+            if (h_smaller(it, pv)) {
+                heap[child] = pv;
+                child = parent;
+            } else
+                break;
+        }
+        heap[child] = it;
+    };
+    for (int i = 0; i < A; ++i)
+        if (out[i] > 0) push(HItem{val[i], (unsigned long long)(unsigned)i});
+    unsigned age = 0;
+    while (hn) {
+        const HItem top = heap[0];
+        --hn;
+        if (hn > 0) {
+            const HItem last = heap[hn];
+            int i = 0;
+            for (;;) {
+                const int l = 2 * i + 1, r = l + 1;
+                if (l >= hn) break;
+                HItem lv = heap[l];
+                int s = i;
+                HItem sv = last;
+                if (h_smaller(lv, last)) {
+                    s = l;
+                    sv = lv;
+                }
+                if (r < hn) {
+                    HItem rv = heap[r];
+                    if (h_smaller(rv, sv)) {
+                        s = r;
+                        sv = rv;
+                    }
+                }
+                if (s == i) break;
+                heap[i] = sv;
+                i = s;
+            }
+            heap[i] = last;
+            if ((top.ai >> 32) == 0) {
+                const HItem nt = heap[0];
+                if ((nt.ai >> 32) == 0 && nt.v == top.v) tie = true;
+            }
+        }
+        const int idx = (int)(top.ai & 0xffffffffu);
+        const int y = idx / bw, x = idx - y * bw;
+        const int lab = out[idx];
+        const int nb[4] = {idx - bw, idx - 1, idx + 1, idx + bw};
+        const bool ok[4] = {y > 0, x > 0, x < bw - 1, y < bh - 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int q = nb[k];
+            if (out[q] != 0) continue;  // -1: not this component, >0: already labelled
+            age += 1;
+            out[q] = lab;
+            push(HItem{val[q], ((unsigned long long)age << 32) | (unsigned)q});
+        }
+    }
+    return tie;
+}
+
+#define WS_AMAX 2048  // largest bounding-box area replayed out of LDS (28 B per pixel)
+
+// planes that are dead by now are re-used: par2 = ymin, hraw = ymax, vraw = xmin, cnt = xmax,
+// lab = "component holds a marker", par = component list
+__global__ __launch_bounds__(PP_T) void ws_init(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const long g = (long)n * b.P + i;
+    b.inst[g] = 0;
+    b.par2[g] = 0x7fffffff;
+    ((int32_t *)b.hraw)[g] = -1;
+    ((int32_t *)b.vraw)[g] = 0x7fffffff;
+    b.cnt[g] = -1;
+    b.lab[g] = 0;
+}
+
+__global__ __launch_bounds__(PP_T) void ws_bbox(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const long g0 = (long)n * b.P;
+    const int r = b.broot[g0 + i];
+    if (r < 0) return;
+    const int y = (int)(i / b.W), x = (int)(i - (long)y * b.W);
+    atomicMin(b.par2 + g0 + r, y);
+    atomicMax((int32_t *)b.hraw + g0 + r, y);
+    atomicMin((int32_t *)b.vraw + g0 + r, x);
+    atomicMax(b.cnt + g0 + r, x);
+    if (b.mk[g0 + i] > 0) b.lab[g0 + r] = 1;
+}
+
+__global__ __launch_bounds__(PP_T) void ws_list(PPBuf b)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * PP_T + threadIdx.x;
+    if (i >= b.P) return;
+    const long g0 = (long)n * b.P;
+    if (b.broot[g0 + i] != (int)i || !b.lab[g0 + i]) return;
+    const int slot = atomicAdd(&b.stat[n].n_comp, 1);
+    b.par[g0 + slot] = (int)i;
+}
+
+__global__ __launch_bounds__(64) void ws_component(PPBuf b)
+{
+    __shared__ __attribute__((aligned(16))) HItem s_heap[WS_AMAX];
+    __shared__ double s_val[WS_AMAX];
+    __shared__ int32_t s_out[WS_AMAX];
+    __shared__ int s_flag;
+    const int n = blockIdx.y;
+    const long g0 = (long)n * b.P;
+    const int ncomp = b.stat[n].n_comp;
+    for (int k = blockIdx.x; k < ncomp; k += gridDim.x) {
+        const int root = b.par[g0 + k];
+        const int y0 = b.par2[g0 + root], y1 = ((const int32_t *)b.hraw)[g0 + root];
+        const int x0 = ((const int32_t *)b.vraw)[g0 + root], x1 = b.cnt[g0 + root];
+        const int bh = y1 - y0 + 1, bw = x1 - x0 + 1, A = bh * bw;
+        __syncthreads();  // previous iteration's LDS fully consumed
+        if (A <= WS_AMAX) {
+            for (int t = threadIdx.x; t < A; t += 64) {
+                const int yy = t / bw, xx = t - yy * bw;
+                const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
+                const bool member = b.broot[gi] == root;
+                s_out[t] = member ? b.mk[gi] : -1;
+                s_val[t] = b.blur[gi];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_flag = ws_flood_window(s_heap, s_val, s_out, bh, bw) ? 1 : 0;
+            __syncthreads();
+            for (int t = threadIdx.x; t < A; t += 64) {
+                const int v = s_out[t];
+                if (v > 0) {
+                    const int yy = t / bw, xx = t - yy * bw;
+                    b.inst[g0 + (long)(y0 + yy) * b.W + (x0 + xx)] = v;
+                }
+            }
+            if (threadIdx.x == 0 && s_flag) b.stat[n].tie = 1;
+        } else {
+            // oversized component: same replay with the window, the labels and the heap in HBM scratch
+            // (dist plane = window values, overall plane = window labels, both dead by now)
+            if (threadIdx.x == 0) s_flag = atomicAdd(&b.stat[n].heap_top, A);
+            __syncthreads();
+            const long off = s_flag;  // sum of window areas may exceed P: checked below
+            if (off + A > b.P) {
+                if (threadIdx.x == 0) b.stat[n].tie = 1;  // no scratch left: let the whole-tile replay do it
+                continue;
+            }
+            double *wv = b.dist + g0 + off;
+            int32_t *wo = (int32_t *)(b.overall + g0) + off;
+            HItem *wh = (HItem *)(b.heap + 2 * (g0 + off));
+            for (int t = threadIdx.x; t < A; t += 64) {
+                const int yy = t / bw, xx = t - yy * bw;
+                const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
+                wo[t] = b.broot[gi] == root ? b.mk[gi] : -1;
+                wv[t] = b.blur[gi];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (ws_flood_window(wh, wv, wo, bh, bw)) b.stat[n].tie = 1;
+                __threadfence();
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < A; t += 64) {
+                const int v = wo[t];
+                if (v > 0) {
+                    const int yy = t / bw, xx = t - yy * bw;
+                    b.inst[g0 + (long)(y0 + yy) * b.W + (x0 + xx)] = v;
+                }
+            }
+        }
+    }
+}
+
+// tiles that reported a tie: exact whole-tile replay (lane 0; heap in HBM)
+__global__ __launch_bounds__(64) void ws_fallback(PPBuf b, int force)
+{
     const int n = blockIdx.x;
+    if (!force && !b.stat[n].tie) return;
     const long g0 = (long)n * b.P;
     int32_t *out = b.inst + g0;
-    // out = markers * mask (_watershed.py:84)
-    for (long i = threadIdx.x; i < b.P; i += 64) out[i] = b.blb[g0 + i] ? b.mk[g0 + i] : 0;
+    for (long i = threadIdx.x; i < b.P; i += 64) out[i] = b.blb[g0 + i] ? b.mk[g0 + i] : 0;  // markers * mask
     __syncthreads();
     if (threadIdx.x != 0) return;
-    if (use_lds)
-        ws_flood((HItem *)ws_smem, b.blur + g0, b.blb + g0, out, b.H, b.W);
-    else
-        ws_flood((HItem *)(b.heap + 2 * g0), b.blur + g0, b.blb + g0, out, b.H, b.W);
+    __threadfence();
+    ws_flood((HItem *)(b.heap + 2 * g0), b.blur + g0, b.blb + g0, out, b.H, b.W);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,6 +750,8 @@ static size_t carve(PPBuf &b, unsigned char *base, int n, int H, int W)
     b.mk = (int32_t *)take(NP * 4);
     b.par2 = (int32_t *)take(NP * 4);
     b.lab = (int32_t *)take(NP * 4);
+    b.broot = (int32_t *)take(NP * 4);
+    b.bsz = (int32_t *)take(NP * 4);
     b.hraw = (float *)take(NP * 4);
     b.vraw = (float *)take(NP * 4);
     b.rowh = (double *)take(NP * 8);
@@ -571,7 +775,9 @@ __global__ void pp_stat_init(TileStat *s, int n)
     s[i].h_max = s[i].v_max = 0u;
     s[i].sh_min = s[i].sv_min = ~0ull;
     s[i].sh_max = s[i].sv_max = 0ull;
-    s[i].n_marker_roots = 0;
+    s[i].n_comp = 0;
+    s[i].heap_top = 0;
+    s[i].tie = 0;
 }
 
 static thread_local char pp_err[256] = "";
@@ -609,21 +815,23 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
     hipLaunchKernelGGL(pp_ccl_flatten_count, grid, blk, 0, s, b.par, b.cnt, b.P);
     hipLaunchKernelGGL(pp_rank_roots, dim3(n), dim3(1024), 0, s, b);
     hipLaunchKernelGGL(pp_marker_labels, grid, blk, 0, s, b);
-    const size_t heap_bytes = (size_t)b.P * 16;
-    const int use_lds = heap_bytes <= 150 * 1024;
-    if (use_lds) {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void *)pp_watershed, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-                return HVN_E_LAUNCH;
-            attr = true;
-        }
+    // taps first: the watershed stage recycles dead planes
+    if (tap_marker) hipMemcpyAsync(tap_marker, b.mk, (size_t)n * b.P * 4, hipMemcpyDeviceToDevice, s);
+    static int ws_mode = -1;  // HVN_WS_GLOBAL=1 forces the whole-tile replay everywhere (tests)
+    if (ws_mode < 0) {
+        const char *e = getenv("HVN_WS_GLOBAL");
+        ws_mode = (e && atoi(e)) ? 1 : 0;
     }
-    hipLaunchKernelGGL(pp_watershed, dim3(n), dim3(64), use_lds ? heap_bytes : 0, s, b, use_lds);
+    hipLaunchKernelGGL(ws_init, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(ws_bbox, grid, blk, 0, s, b);
+    hipLaunchKernelGGL(ws_list, grid, blk, 0, s, b);
+    long maxc = b.P / 10 + 1;
+    if (maxc > 2048) maxc = 2048;
+    if (!ws_mode) hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(ws_fallback, dim3(n), dim3(64), 0, s, b, ws_mode);
     const size_t NP = (size_t)n * b.P;
     if (tap_blb) hipMemcpyAsync(tap_blb, b.blb, NP * 4, hipMemcpyDeviceToDevice, s);
     if (tap_dist) hipMemcpyAsync(tap_dist, b.blur, NP * 8, hipMemcpyDeviceToDevice, s);
-    if (tap_marker) hipMemcpyAsync(tap_marker, b.mk, NP * 4, hipMemcpyDeviceToDevice, s);
     return hipGetLastError() == hipSuccess ? HVN_OK : HVN_E_LAUNCH;
 }
 

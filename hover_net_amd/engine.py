@@ -38,6 +38,7 @@ class Engine:
         # the other's workgroups.
         import os
         self.n_split = int(os.environ.get("HVN_SPLIT", "2")) if n_split is None else int(n_split)
+        self.n_lane_streams = int(os.environ.get("HVN_LANES", "2"))  # extra streams for the decoder branches
         self._streams = None
         self._upload_params()
         self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32, device=self.device)
@@ -172,6 +173,36 @@ class Engine:
             self._sub_ops[key] = ops
         return self._sub_ops[key]
 
+    def _launch(self, ops, n_ops, cnt, stream, lane_streams):
+        """One sub-batch: encoder on `stream`, decoder branches fanned out over `lane_streams`."""
+        lib = L.lib()
+        base = ctypes.addressof(ops)
+        osz = ctypes.sizeof(L.hvn_op)
+        lanes = getattr(self.plan, "lanes", None)
+        if not lanes or not lane_streams or n_ops != len(self.ops):
+            L.check(lib.hvn_run_plan(base, n_ops, cnt, ctypes.c_void_p(stream.cuda_stream)), "hvn_run_plan")
+            return
+        branch_i = 0
+        pending = []
+        for lane, lo, hi in lanes:
+            if lane == "main":
+                for ev in pending:          # join before the shared epilogue
+                    stream.wait_event(ev)
+                pending = []
+                L.check(lib.hvn_run_plan(base + lo * osz, hi - lo, cnt, ctypes.c_void_p(stream.cuda_stream)), "hvn_run_plan")
+            else:
+                st = stream if branch_i == 0 else lane_streams[(branch_i - 1) % len(lane_streams)]
+                if st is not stream:
+                    fork = torch.cuda.Event()
+                    fork.record(stream)
+                    st.wait_event(fork)
+                L.check(lib.hvn_run_plan(base + lo * osz, hi - lo, cnt, ctypes.c_void_p(st.cuda_stream)), "hvn_run_plan")
+                if st is not stream:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    pending.append(ev)
+                branch_i += 1
+
     def run(self, imgs, upto=None):
         """imgs: uint8 [N,H,W,3] or float32 [N,3,H,W] -> (logits dict of [N,C,h,w] views, pred_map [N,h,w,3|4] or None).
         The returned tensors alias engine-owned buffers that the next call overwrites."""
@@ -179,11 +210,14 @@ class Engine:
         main = torch.cuda.current_stream(self.device)
         n_ops = len(self.ops) if upto is None else upto
         split = self.n_split if (n >= 2 * self.n_split and self.n_split > 1) else 1
+        n_lane = self.n_lane_streams
+        need = (split - 1) + split * n_lane
+        if self._streams is None or len(self._streams) < need:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(need)]
+        lane_pool = self._streams[split - 1:]
         if split == 1:
-            L.check(L.lib().hvn_run_plan(ctypes.addressof(self.ops), n_ops, n, ctypes.c_void_p(main.cuda_stream)), "hvn_run_plan")
+            self._launch(self.ops, n_ops, n, main, lane_pool[:n_lane])
         else:
-            if self._streams is None or len(self._streams) < split - 1:
-                self._streams = [torch.cuda.Stream(self.device) for _ in range(split - 1)]
             o0 = self.ops[0]
             esz = 1 if o0.x_dtype == 0 else 4
             fork = torch.cuda.Event()
@@ -198,7 +232,7 @@ class Engine:
                 st = main if k == 0 else self._streams[k - 1]
                 if k:
                     st.wait_event(fork)
-                L.check(L.lib().hvn_run_plan(ctypes.addressof(ops), n_ops, cnt, ctypes.c_void_p(st.cuda_stream)), "hvn_run_plan")
+                self._launch(ops, n_ops, cnt, st, lane_pool[k * n_lane:(k + 1) * n_lane])
                 if k:
                     join = torch.cuda.Event()
                     join.record(st)

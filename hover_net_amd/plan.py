@@ -168,6 +168,7 @@ class Plan:
         self.pred_map = None    # Buf [h, w, 3|4]
         self.image = Buf("image", self.geo["inp"], self.geo["inp"], 3, "u8")
         self.arena_per_sample = 0
+        self.lanes = None
 
     # -- construction helpers -------------------------------------------------
     def buf(self, name, h, w, c):
@@ -316,5 +317,25 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
         pm = Buf("pred_map", g["out"], g["out"], 3 if nr_types is None else 4)
         P.pred_map = pm
         P.add(Op(OP_PREDMAP, "infer_step.epilogue", y=View(pm), extra={"branches": list(arch.branch_names(nr_types))}))
+    # launch lanes: the decoder branches are independent between the shared u3 input and the
+    # epilogue, so the engine may run them on concurrent streams (small dense-unit launches of one
+    # branch then fill the chip together with the others')
+    lanes, cur, start = [], None, 0
+    for i, op in enumerate(P.ops):
+        lane = op.name.split(".")[1] if op.name.startswith("decoder.") else "main"
+        if lane != cur:
+            if cur is not None:
+                lanes.append((cur, start, i))
+            cur, start = lane, i
+    lanes.append((cur, start, len(P.ops)))
+    # concurrent lanes must not share arena space: every buffer touched inside the branch region
+    # stays live for the whole region
+    br = [(lo, hi) for lane, lo, hi in lanes if lane != "main"]
+    if br:
+        r0, r1 = br[0][0], br[-1][1] - 1
+        for b in P.bufs:
+            if b.last >= r0 and b.first <= r1:
+                b.first, b.last = min(b.first, r0), max(b.last, r1)
     P.pack()
+    P.lanes = lanes
     return P

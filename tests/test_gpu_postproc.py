@@ -105,3 +105,43 @@ def test_empty_and_full_maps():
     e[1, ..., 0] = 1.0
     got = _pp().separate(torch.from_numpy(e).to("cuda")).cpu().numpy()
     assert (got[0] == 0).all()
+
+
+def test_component_replay_equals_whole_tile_replay():
+    """The per-component watershed (default) and the forced whole-tile replay (HVN_WS_GLOBAL=1, a fresh
+    process because the switch is read once) agree on structured, noisy and tie-heavy maps."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from hover_net_amd.post_proc import PostProc\n"
+        "z = np.load(%r); out = PostProc('cuda').separate(torch.from_numpy(z['pred']).to('cuda')).cpu().numpy()\n"
+        "assert np.array_equal(out, z['inst']), 'whole-tile replay differs from golden'\n"
+    )
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("pp_quant80.npz", "pp_s80.npz", "pp_noise80.npz"):
+        path = os.path.join(repo, "tests", "golden", name)
+        env = dict(os.environ, HVN_WS_GLOBAL="1")
+        r = subprocess.run([sys.executable, "-c", code % (repo, path)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_oversized_component_uses_hbm_window():
+    """One blob far larger than the LDS window limit (2048 px), with several markers inside."""
+    from oracle import postproc as O
+
+    H = W = 120
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    pred = np.zeros((1, H, W, 3), np.float32)
+    pred[0, ..., 0] = ((yy - 60) ** 2 + (xx - 60) ** 2 < 55 ** 2) * 0.9 + 0.05
+    rng = np.random.default_rng(5)
+    cx = np.array([30, 60, 90, 45, 75]); cy = np.array([40, 35, 45, 80, 85])
+    d = np.stack([np.hypot(yy - cy[i], xx - cx[i]) for i in range(5)])
+    k = d.argmin(0)
+    pred[0, ..., 1] = np.clip((xx - cx[k]) / 25.0, -1, 1) + rng.normal(0, 0.01, (H, W))
+    pred[0, ..., 2] = np.clip((yy - cy[k]) / 25.0, -1, 1) + rng.normal(0, 0.01, (H, W))
+    want = O.proc_batch(pred)
+    assert len(np.unique(want)) > 2          # several instances inside one connected blob
+    got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
+    np.testing.assert_array_equal(got, want)

@@ -35,7 +35,7 @@ def test_arena_packing_has_no_live_overlap():
             if a.last < b.first or b.last < a.first:
                 continue
             assert a.offset + a.size <= b.offset or b.offset + b.size <= a.offset, (a.name, b.name)
-    assert P.arena_per_sample * 4 < 200e6  # ~160 MB / tile
+    assert P.arena_per_sample * 4 < 300e6  # ~260 MB / tile (decoder branches keep their buffers live: concurrent lanes)
 
 
 def test_every_conv_is_kernel_legal():
