@@ -68,10 +68,12 @@ def main():
     tiles = torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank)).to(dev)  # resident in HBM
     # A random-init network emits maps without nuclei (0 instances -> the watershed has nothing to
     # flood).  So that the step carries a realistic instance-separation load it ALSO post-processes a
-    # resident batch of structured synthetic maps (painted elliptical nuclei, ~5..40 per 80x80 map,
+    # resident batch of structured synthetic maps (painted, partly touching elliptical nuclei,
     # hover_net_amd.synth.synth_pred_maps): post-proc runs twice per step, which over-counts its cost.
+    # Density: CoNSeP has 24 319 nuclei in 41 images of 1000x1000 px = 3.8 per 80x80 output tile; the
+    # structured maps carry 2..8 (mean 5) per 80x80, scaled by area for other output sizes.
     out_hw = net.engine(args.batch).plan.geo["out"]
-    structured = torch.from_numpy(synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank)[0]).to(dev)
+    structured = torch.from_numpy(synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank, k_lo=2, k_hi=8)[0]).to(dev)
 
     from hover_net_amd.pipeline import TilePipeline
 

@@ -73,7 +73,7 @@ struct TileStat {
     int n_comp;      // mask components that hold at least one marker
     int heap_top;    // bump pointer into the HBM heap plane (oversized components)
     int tie;         // a component saw two equal-valued age-0 heap items: replay the tile globally
-    int _pad;
+    int max_area;    // largest component bounding box of the tile
 };
 
 struct PPBuf {
@@ -440,168 +440,135 @@ __global__ __launch_bounds__(PP_T) void pp_marker_labels(PPBuf b)
 
 // ---------------------------------------------------------------------------------------------
 // K14: skimage.segmentation.watershed(dist, markers, mask=blb) replayed exactly.
-// Heap item = {value (double), age<<32 | index}.  Lane 0 of one wave per tile drives it.
-struct HItem {
-    double v;
-    unsigned long long ai;  // age (high 32) | index (low 32)
-};
-__device__ __forceinline__ bool h_smaller(const HItem &a, const HItem &b)
-{
-    if (a.v != b.v) return a.v < b.v;
-    return (a.ai >> 32) < (b.ai >> 32);
-}
-
-// Whole-tile replay (exact for any input; serial): used when a tile reports a marker tie.
-template <typename HP>
-__device__ void ws_flood(HP heap, const double *img, const int32_t *mask, int32_t *out, int H, int W)
-{
-    const long P = (long)H * W;
-    int hn = 0;
-    auto push = [&](HItem it) {
-        int child = hn++;
-        while (child > 0) {
-            const int parent = (child + 1) / 2 - 1;
-            HItem pv = heap[parent];
-            if (h_smaller(it, pv)) {
-                heap[child] = pv;
-                child = parent;
-            } else
-                break;
-        }
-        heap[child] = it;
-    };
-    for (long i = 0; i < P; ++i)
-        if (out[i]) push(HItem{img[i], (unsigned long long)(unsigned)i});
-    unsigned age = 0;
-    while (hn) {
-        const HItem top = heap[0];
-        --hn;
-        if (hn > 0) {
-            // move the last element to the root and sift it down (pop of heap_general.pxi)
-            const HItem last = heap[hn];
-            int i = 0;
-            for (;;) {
-                const int l = 2 * i + 1, r = l + 1;
-                if (l >= hn) break;
-                HItem lv = heap[l];
-                int s = i;
-                HItem sv = last;
-                if (h_smaller(lv, last)) {
-                    s = l;
-                    sv = lv;
-                }
-                if (r < hn) {
-                    HItem rv = heap[r];
-                    if (h_smaller(rv, sv)) {
-                        s = r;
-                        sv = rv;
-                    }
-                }
-                if (s == i) break;
-                heap[i] = sv;
-                i = s;
-            }
-            heap[i] = last;
-        }
-        const int idx = (int)(top.ai & 0xffffffffu);
-        const int y = idx / W, x = idx - y * W;
-        const int lab = out[idx];
-        // neighbour order of skimage: -W, -1, +1, +W
-        const int nb[4] = {idx - W, idx - 1, idx + 1, idx + W};
-        const bool ok[4] = {y > 0, x > 0, x < W - 1, y < H - 1};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) continue;
-            const int q = nb[k];
-            if (!mask[q] || out[q]) continue;
-            age += 1;
-            out[q] = lab;
-            push(HItem{img[q], ((unsigned long long)age << 32) | (unsigned)q});
-        }
-    }
-}
-
 // Per-component replay.  The flood never crosses a 4-connected component of the mask, and inside one
 // component the (value, age) order of its own heap items is the same whether the other components'
 // items are interleaved or not -- EXCEPT among age-0 items (the initial markers) of equal value, whose
 // order is an artefact of the global heap layout.  So every component is replayed
 // by its own workgroup, out of LDS, over its bounding box; a component that ever pops an age-0 item while
-// an equal (value, age 0) item is the new top raises the tile's `tie` flag and the tile is redone by the
-// whole-tile replay above.  VAL / OUT index the bounding-box window [bh][bw]; OUT is -1 outside the component.
-template <typename HP, typename VP, typename OP>
-__device__ bool ws_flood_window(HP heap, VP val, OP out, int bh, int bw)
+// an equal (value, age 0) item is the new top raises the tile's `tie` flag and the tile is redone as ONE
+// window (= skimage's global run).  VAL / OUT index the window [bh][bw]; OUT is -1 outside the mask
+// (component).  Heap items are 8 bytes (age << 32 | window index): the value is looked up in VAL, which
+// keeps the whole state at 20 B per pixel so that an 80x80 tile (or a 7.6k-pixel blob) fits the 160 KB LDS.
+struct HItem {  // heap item with its value inline: one dependent LDS read per heap level
+    double v;
+    unsigned long long ai;  // age << 32 | window index
+};
+
+// Returns the number of tie events seen (saturating at 2).  `swap_first_tie`: at the first tie event pop the
+// OTHER tied item first -- used to prove a 2-way tie harmless (both orders give the same labels).
+template <bool INLINE_VAL, typename VP, typename OP>
+__device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, bool swap_first_tie)
 {
+    typedef unsigned long long u64;
+    HItem *h16 = (HItem *)heap_raw;
+    u64 *h8 = (u64 *)heap_raw;
     const int A = bh * bw;
     int hn = 0;
-    bool tie = false;
-    auto push = [&](HItem it) {
+    int ties = 0;
+    auto less = [](double va, u64 a, double vb, u64 b) { return va != vb ? va < vb : (a >> 32) < (b >> 32); };
+    auto get = [&](int i, u64 &it, double &v) {
+        if constexpr (INLINE_VAL) {
+            const HItem t = h16[i];
+            it = t.ai;
+            v = t.v;
+        } else {
+            it = h8[i];
+            v = val[(unsigned)it];
+        }
+    };
+    auto put = [&](int i, u64 it, double v) {
+        if constexpr (INLINE_VAL) h16[i] = HItem{v, it};
+        else h8[i] = it;
+    };
+    auto push = [&](u64 it, double itv) {
         int child = hn++;
         while (child > 0) {
             const int parent = (child + 1) / 2 - 1;
-            HItem pv = heap[parent];
-            if (h_smaller(it, pv)) {
-                heap[child] = pv;
+            u64 pi;
+            double pv;
+            get(parent, pi, pv);
+            if (less(itv, it, pv, pi)) {
+                put(child, pi, pv);
                 child = parent;
             } else
                 break;
         }
-        heap[child] = it;
+        put(child, it, itv);
     };
     for (int i = 0; i < A; ++i)
-        if (out[i] > 0) push(HItem{val[i], (unsigned long long)(unsigned)i});
+        if (out[i] > 0) push((u64)(unsigned)i, val[i]);
     unsigned age = 0;
     while (hn) {
-        const HItem top = heap[0];
+        u64 top;
+        double topv;
+        get(0, top, topv);
         --hn;
         if (hn > 0) {
-            const HItem last = heap[hn];
+            u64 last;
+            double lastv;
+            get(hn, last, lastv);
             int i = 0;
             for (;;) {
                 const int l = 2 * i + 1, r = l + 1;
                 if (l >= hn) break;
-                HItem lv = heap[l];
+                u64 li, ri = 0;
+                double lv, rv = 0.;
+                get(l, li, lv);
+                if (r < hn) get(r, ri, rv);  // both children are fetched before either is compared
                 int s = i;
-                HItem sv = last;
-                if (h_smaller(lv, last)) {
+                u64 si = last;
+                double sv = lastv;
+                if (less(lv, li, lastv, last)) {
                     s = l;
+                    si = li;
                     sv = lv;
                 }
-                if (r < hn) {
-                    HItem rv = heap[r];
-                    if (h_smaller(rv, sv)) {
-                        s = r;
-                        sv = rv;
-                    }
+                if (r < hn && less(rv, ri, sv, si)) {
+                    s = r;
+                    si = ri;
+                    sv = rv;
                 }
                 if (s == i) break;
-                heap[i] = sv;
+                put(i, si, sv);
                 i = s;
             }
-            heap[i] = last;
-            if ((top.ai >> 32) == 0) {
-                const HItem nt = heap[0];
-                if ((nt.ai >> 32) == 0 && nt.v == top.v) tie = true;
+            put(i, last, lastv);
+            if ((top >> 32) == 0) {
+                u64 nt;
+                double ntv;
+                get(0, nt, ntv);
+                if ((nt >> 32) == 0 && ntv == topv) {
+                    if (ties == 0 && swap_first_tie) {  // equal keys: exchanging them keeps the heap valid
+                        put(0, top, topv);
+                        top = nt;
+                    }
+                    if (ties < 2) ++ties;
+                }
             }
         }
-        const int idx = (int)(top.ai & 0xffffffffu);
+        const int idx = (int)(unsigned)top;
         const int y = idx / bw, x = idx - y * bw;
         const int lab = out[idx];
-        const int nb[4] = {idx - bw, idx - 1, idx + 1, idx + bw};
+        const int nb[4] = {idx - bw, idx - 1, idx + 1, idx + bw};  // neighbour order of skimage
         const bool ok[4] = {y > 0, x > 0, x < bw - 1, y < bh - 1};
+        int oq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) oq[k] = ok[k] ? out[nb[k]] : -1;  // four independent LDS reads in flight
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) continue;
+            if (oq[k] != 0) continue;  // -1: not in the mask / this component, >0: already labelled
             const int q = nb[k];
-            if (out[q] != 0) continue;  // -1: not this component, >0: already labelled
             age += 1;
             out[q] = lab;
-            push(HItem{val[q], ((unsigned long long)age << 32) | (unsigned)q});
+            push(((u64)age << 32) | (unsigned)q, val[q]);
         }
     }
-    return tie;
+    return ties;
 }
 
-#define WS_AMAX 2048  // largest bounding-box area replayed out of LDS (28 B per pixel)
+#define WS_AMAX 7600  // largest window replayed out of LDS (8-byte heap items: 20 B per pixel -> 152 KB)
+#define WS_AMAX16 5400  // ... with the value inline in the heap item (28 B per pixel)
+#define WS_LDS_BYTES (WS_AMAX * 20)
 
 // planes that are dead by now are re-used: par2 = ymin, hraw = ymax, vraw = xmin, cnt = xmax,
 // lab = "component holds a marker", par = component list
@@ -644,91 +611,118 @@ __global__ __launch_bounds__(PP_T) void ws_list(PPBuf b)
     if (b.broot[g0 + i] != (int)i || !b.lab[g0 + i]) return;
     const int slot = atomicAdd(&b.stat[n].n_comp, 1);
     b.par[g0 + slot] = (int)i;
+    const int bh = ((const int32_t *)b.hraw)[g0 + i] - b.par2[g0 + i] + 1, bw = b.cnt[g0 + i] - ((const int32_t *)b.vraw)[g0 + i] + 1;
+    atomicMax(&b.stat[n].max_area, bh * bw);
+}
+
+// Replay one window [y0..y0+bh) x [x0..x0+bw) of tile n; root >= 0 restricts the mask to that component,
+// root < 0 takes the whole blob mask (whole-tile replay).  All 64 lanes stage / write back, lane 0 floods.
+__device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned char *lds, int *s_flag)
+{
+    typedef unsigned long long u64;
+    const long g0 = (long)n * b.P;
+    const int A = bh * bw;
+    double *val;
+    int32_t *out;
+    u64 *heap;
+    const bool in_lds = A <= WS_AMAX;
+    const bool inline_val = A <= WS_AMAX16;
+    if (in_lds) {
+        val = (double *)lds;
+        heap = (u64 *)(lds + (size_t)8 * A);
+        out = (int32_t *)(lds + (size_t)(inline_val ? 24 : 16) * A);
+    } else {
+        // oversized window: same replay out of HBM scratch (dist / overall / heap planes are dead by now)
+        if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, A);
+        __syncthreads();
+        const long off = *s_flag;
+        __syncthreads();
+        if (off + A > b.P) return true;  // scratch exhausted (overlapping boxes): leave it to the whole-tile replay
+        val = b.dist + g0 + off;
+        out = (int32_t *)(b.overall + g0) + off;
+        heap = b.heap + 2 * g0 + off;
+    }
+    auto stage = [&]() {
+        for (int t = threadIdx.x; t < A; t += 64) {
+            const int yy = t / bw, xx = t - yy * bw;
+            const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
+            const bool member = root >= 0 ? (b.broot[gi] == root) : (b.blb[gi] != 0);
+            out[t] = member ? b.mk[gi] : -1;
+            val[t] = b.blur[gi];
+        }
+        __syncthreads();
+    };
+    auto flood = [&](bool swap_first) {
+        if (threadIdx.x == 0) {
+            if (!in_lds) __threadfence();
+            *s_flag = inline_val ? ws_flood_window<true>(heap, val, out, bh, bw, swap_first)
+                                 : ws_flood_window<false>(heap, val, out, bh, bw, swap_first);
+            if (!in_lds) __threadfence();
+        }
+        __syncthreads();
+        const int r = *s_flag;
+        __syncthreads();
+        return r;
+    };
+    stage();
+    const int ties = flood(false);
+    for (int t = threadIdx.x; t < A; t += 64) {
+        const int v = out[t];
+        if (v >= 0) {
+            const int yy = t / bw, xx = t - yy * bw;
+            b.inst[g0 + (long)(y0 + yy) * b.W + (x0 + xx)] = v;
+        }
+    }
+    if (root < 0 || ties == 0) return false;  // the whole-tile window IS the global run: its ties are skimage's
+    if (ties >= 2) return true;
+    // exactly one 2-way marker tie: replay with the two items exchanged; identical labels => harmless
+    __syncthreads();
+    stage();
+    flood(true);
+    int diff = 0;
+    for (int t = threadIdx.x; t < A; t += 64) {
+        const int v = out[t];
+        if (v >= 0) {
+            const int yy = t / bw, xx = t - yy * bw;
+            diff |= b.inst[g0 + (long)(y0 + yy) * b.W + (x0 + xx)] != v;
+        }
+    }
+    const bool any = __any(diff);
+    __syncthreads();
+    return any;
 }
 
 __global__ __launch_bounds__(64) void ws_component(PPBuf b)
 {
-    __shared__ __attribute__((aligned(16))) HItem s_heap[WS_AMAX];
-    __shared__ double s_val[WS_AMAX];
-    __shared__ int32_t s_out[WS_AMAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
     __shared__ int s_flag;
     const int n = blockIdx.y;
     const long g0 = (long)n * b.P;
     const int ncomp = b.stat[n].n_comp;
+    // a tile dominated by one blob gains nothing from the per-component split: replay it whole, here,
+    // concurrently with the other tiles' components (and exactly, so no tie bookkeeping is needed)
+    if (2L * b.stat[n].max_area > b.P) {
+        if (blockIdx.x == 0 && ncomp > 0) ws_window(b, n, -1, 0, 0, b.H, b.W, ws_lds, &s_flag);
+        return;
+    }
     for (int k = blockIdx.x; k < ncomp; k += gridDim.x) {
         const int root = b.par[g0 + k];
         const int y0 = b.par2[g0 + root], y1 = ((const int32_t *)b.hraw)[g0 + root];
         const int x0 = ((const int32_t *)b.vraw)[g0 + root], x1 = b.cnt[g0 + root];
-        const int bh = y1 - y0 + 1, bw = x1 - x0 + 1, A = bh * bw;
-        __syncthreads();  // previous iteration's LDS fully consumed
-        if (A <= WS_AMAX) {
-            for (int t = threadIdx.x; t < A; t += 64) {
-                const int yy = t / bw, xx = t - yy * bw;
-                const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
-                const bool member = b.broot[gi] == root;
-                s_out[t] = member ? b.mk[gi] : -1;
-                s_val[t] = b.blur[gi];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_flag = ws_flood_window(s_heap, s_val, s_out, bh, bw) ? 1 : 0;
-            __syncthreads();
-            for (int t = threadIdx.x; t < A; t += 64) {
-                const int v = s_out[t];
-                if (v > 0) {
-                    const int yy = t / bw, xx = t - yy * bw;
-                    b.inst[g0 + (long)(y0 + yy) * b.W + (x0 + xx)] = v;
-                }
-            }
-            if (threadIdx.x == 0 && s_flag) b.stat[n].tie = 1;
-        } else {
-            // oversized component: same replay with the window, the labels and the heap in HBM scratch
-            // (dist plane = window values, overall plane = window labels, both dead by now)
-            if (threadIdx.x == 0) s_flag = atomicAdd(&b.stat[n].heap_top, A);
-            __syncthreads();
-            const long off = s_flag;  // sum of window areas may exceed P: checked below
-            if (off + A > b.P) {
-                if (threadIdx.x == 0) b.stat[n].tie = 1;  // no scratch left: let the whole-tile replay do it
-                continue;
-            }
-            double *wv = b.dist + g0 + off;
-            int32_t *wo = (int32_t *)(b.overall + g0) + off;
-            HItem *wh = (HItem *)(b.heap + 2 * (g0 + off));
-            for (int t = threadIdx.x; t < A; t += 64) {
-                const int yy = t / bw, xx = t - yy * bw;
-                const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
-                wo[t] = b.broot[gi] == root ? b.mk[gi] : -1;
-                wv[t] = b.blur[gi];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __threadfence();
-                if (ws_flood_window(wh, wv, wo, bh, bw)) b.stat[n].tie = 1;
-                __threadfence();
-            }
-            __syncthreads();
-            for (int t = threadIdx.x; t < A; t += 64) {
-                const int v = wo[t];
-                if (v > 0) {
-                    const int yy = t / bw, xx = t - yy * bw;
-                    b.inst[g0 + (long)(y0 + yy) * b.W + (x0 + xx)] = v;
-                }
-            }
-        }
+        if (ws_window(b, n, root, y0, x0, y1 - y0 + 1, x1 - x0 + 1, ws_lds, &s_flag) && threadIdx.x == 0) b.stat[n].tie = 1;
     }
 }
 
-// tiles that reported a tie: exact whole-tile replay (lane 0; heap in HBM)
+// tiles that reported a tie (or all tiles when forced): exact whole-tile replay = one window over the tile
 __global__ __launch_bounds__(64) void ws_fallback(PPBuf b, int force)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
+    __shared__ int s_flag;
     const int n = blockIdx.x;
     if (!force && !b.stat[n].tie) return;
-    const long g0 = (long)n * b.P;
-    int32_t *out = b.inst + g0;
-    for (long i = threadIdx.x; i < b.P; i += 64) out[i] = b.blb[g0 + i] ? b.mk[g0 + i] : 0;  // markers * mask
+    if (threadIdx.x == 0) b.stat[n].heap_top = 0;  // the component pass is over: its HBM scratch is free again
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    __threadfence();
-    ws_flood((HItem *)(b.heap + 2 * g0), b.blur + g0, b.blb + g0, out, b.H, b.W);
+    ws_window(b, n, -1, 0, 0, b.H, b.W, ws_lds, &s_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -778,6 +772,7 @@ __global__ void pp_stat_init(TileStat *s, int n)
     s[i].n_comp = 0;
     s[i].heap_top = 0;
     s[i].tie = 0;
+    s[i].max_area = 0;
 }
 
 static thread_local char pp_err[256] = "";
@@ -827,8 +822,15 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
     hipLaunchKernelGGL(ws_list, grid, blk, 0, s, b);
     long maxc = b.P / 10 + 1;
     if (maxc > 2048) maxc = 2048;
-    if (!ws_mode) hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), 0, s, b);
-    hipLaunchKernelGGL(ws_fallback, dim3(n), dim3(64), 0, s, b, ws_mode);
+    static bool ws_attr = false;
+    if (!ws_attr) {
+        if (hipFuncSetAttribute((const void *)ws_component, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)ws_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess)
+            return HVN_E_LAUNCH;
+        ws_attr = true;
+    }
+    if (!ws_mode) hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_LDS_BYTES, s, b);
+    hipLaunchKernelGGL(ws_fallback, dim3(n), dim3(64), WS_LDS_BYTES, s, b, ws_mode);
     const size_t NP = (size_t)n * b.P;
     if (tap_blb) hipMemcpyAsync(tap_blb, b.blb, NP * 4, hipMemcpyDeviceToDevice, s);
     if (tap_dist) hipMemcpyAsync(tap_dist, b.blur, NP * 8, hipMemcpyDeviceToDevice, s);

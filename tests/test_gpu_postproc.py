@@ -145,3 +145,13 @@ def test_oversized_component_uses_hbm_window():
     assert len(np.unique(want)) > 2          # several instances inside one connected blob
     got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+
+
+def test_large_image_many_components():
+    """1000x1000 map with ~800 nuclei: per-component parallel replay (incl. harmless-tie proofs) == oracle."""
+    from hover_net_amd.synth import synth_pred_maps
+    from oracle import postproc as O
+
+    pred = synth_pred_maps(1, 1000, 1000, None, seed=45, k_lo=2, k_hi=8)[0]
+    got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
+    np.testing.assert_array_equal(got, O.proc_batch(pred))
