@@ -144,8 +144,15 @@ def main():
         launches = L.lib().hvn_profile_conv_launches()
         L.lib().hvn_profile_enable(0)
         achieved = conv_flops / (ms * 1e-3) / 1e12
+        # HBM bytes of the same 140 launches from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        # (tools/pmc_traffic.py, gfx950 x2 correction on FETCH_SIZE); cannot be collected live
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5:
+            traffic = json.load(open(tpath))["hbm_bytes_per_step"]
         result["roofline"] = {"bound": "mfma", "kernel": "hvn_conv_igemm_f32", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                              "traffic_unit": "HBM bytes per step (all conv launches; rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                               "launches_per_step": launches, "conv_ms_per_step": ms, "conv_gflop_per_step": conv_flops / 1e9}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

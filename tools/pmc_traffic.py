@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""HBM traffic of the conv kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
+`python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline` (HVN_SPLIT=1 HVN_LANES=0).
+Sums the counters over the hvn_conv_igemm_f32 dispatches of the LAST plan execution.
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x.
+usage: python tools/pmc_traffic.py <fetch.db> <write.db> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def total(db, counter, n_last):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select dispatch_id, sum(value), min(start) from counters_collection "
+                          "where kernel_name like '%igemm%' and counter_name=? group by dispatch_id order by min(start)", (counter,)))
+    rows = rows[-n_last:]
+    return sum(r[1] for r in rows), len(rows)
+
+
+n = 140
+fetch_kb, nf = total(sys.argv[1], "FETCH_SIZE", n)
+write_kb, nw = total(sys.argv[2], "WRITE_SIZE", n)
+out = {"launches": nf, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
+       "fetch_bytes_corrected": fetch_kb * 1024 * 2, "write_bytes": write_kb * 1024,
+       "hbm_bytes_per_step": fetch_kb * 1024 * 2 + write_kb * 1024,
+       "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncalibrated"}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(out)
