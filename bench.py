@@ -138,11 +138,16 @@ def main():
     if rank == 0 and not args.no_roofline:
         eng = net.engine(args.batch)
         conv_flops = sum(o.flops() for o in eng.plan.ops if o.kind == 2) * args.batch
+        # single launch stream for this pass (HIP events bracket each conv launch on that stream)
+        saved = (eng.n_split, eng.n_lane_streams)
+        eng.n_split, eng.n_lane_streams = 1, 0
+        torch.cuda.synchronize(dev)
         L.lib().hvn_profile_enable(1)
         run_desc.infer_step_device(tiles, net)
         ms = L.lib().hvn_profile_conv_ms()
         launches = L.lib().hvn_profile_conv_launches()
         L.lib().hvn_profile_enable(0)
+        eng.n_split, eng.n_lane_streams = saved
         achieved = conv_flops / (ms * 1e-3) / 1e12
         # HBM bytes of the same 140 launches from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         # (tools/pmc_traffic.py, gfx950 x2 correction on FETCH_SIZE); cannot be collected live

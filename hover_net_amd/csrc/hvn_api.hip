@@ -175,7 +175,6 @@ int hvn_run_op(const hvn_op *op, int batch, void *stream)
 int hvn_run_plan(const hvn_op *ops, int n_ops, int batch, void *stream)
 {
     if (!ops || n_ops <= 0 || batch <= 0) return fail(HVN_E_ARG, "run_plan: bad arguments%s", "");
-    if (g_prof) g_ev_used = 0;
     for (int i = 0; i < n_ops; ++i) {
         int rc = run_one(&ops[i], batch, (hipStream_t)stream);
         if (rc == -2) return fail(HVN_E_LAUNCH, "launch failed at op %s%ld", "", i);

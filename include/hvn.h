@@ -70,8 +70,9 @@ HVN_API int         hvn_device_ok(void);  /* 1 if a gfx950 device is current */
 HVN_API int hvn_run_plan(const hvn_op *ops, int n_ops, int batch, void *stream);
 /* single launches, used by the per-kernel parity tests */
 HVN_API int hvn_run_op(const hvn_op *op, int batch, void *stream);
-/* timing of the last hvn_run_plan on `stream` measured with hipEvents around every CONV launch:
- * returns total CONV milliseconds (sync point); <0 if profiling was not enabled */
+/* per-launch timing of the CONV kernel: hvn_profile_enable(1) resets the tally and brackets every
+ * CONV launch of the following hvn_run_plan / hvn_run_op calls with hipEvents on their stream;
+ * hvn_profile_conv_ms() synchronises and returns the summed milliseconds (<0 if nothing was recorded) */
 HVN_API int    hvn_profile_enable(int on);
 HVN_API double hvn_profile_conv_ms(void);
 HVN_API int    hvn_profile_conv_launches(void);
