@@ -106,6 +106,7 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.Cout = op->cout;
         a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_t = op->pad_t; a.pad_l = op->pad_l;
         a.relu = op->relu;
+        a.groups = op->groups > 1 ? op->groups : 1;
         a.M = (long)batch * a.Ho * a.Wo;
         if (!a.x || !a.w || !a.y) return fail(HVN_E_ARG, "conv: null pointer%s", "");
         if (a.Cin % 32) return fail(HVN_E_ARG, "conv: input channels must be a multiple of 32 (got %s%ld)", "", a.Cin);

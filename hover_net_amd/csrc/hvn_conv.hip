@@ -41,7 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #define BK 32
 #define LDS_LD 36  // padded row length in floats
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     constexpr int PA = BM / 32, PB = BN / 32;  // staging passes (32 rows of 8 float4 per pass)
     constexpr int EP_LD = BN + 4;              // epilogue tile row length (floats)
     static_assert(WAVES_M * WAVES_N == 4, "256 threads");
+    static_assert(!GROUPED || (BN == 32 && WM == 32 && WN == 32), "grouped mode: 4 groups x 8 output channels per 32-wide tile");
     static_assert(BM * EP_LD <= 2 * (BM + BN) * LDS_LD, "epilogue tile must fit in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                       // [2][BM][LDS_LD]
@@ -190,8 +191,43 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // GROUPED (block-diagonal weights, 8 output channels per 32-channel slab): 16x16x4 MFMA tiles, two pixel
+    // tiles x two 16-channel column tiles per wave; a slab only touches the column tile that holds its group
+    f32x4 gacc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int taps = p.KH * p.KW;
 
     // MFMAs of the k-sub-chunks [Q0, Q1) (8 reduction indices each) of LDS buffer `cur`
+    auto compute_grouped = [&](int cur, int kt, auto q0c, auto q1c) {
+        constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;  // in units of 8 k
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int grp = kt / taps;                 // slab == group (32 input channels per group)
+        const int nt = grp >> 1;                   // column tile holding this group's 8 output channels
+        const float *a = As + cur * BM * LDS_LD + (wm * WM + l15) * LDS_LD + 4 * l4;
+        const float *b = Bs + cur * BN * LDS_LD + (nt * 16 + l15) * LDS_LD + 4 * l4;
+#pragma unroll
+        for (int c = Q0 / 2; c < (Q1 + 1) / 2; ++c) {  // chunks of 16 k (4 lane groups x 4)
+            const f32x4 fb = *(const f32x4 *)(b + c * 16);
+            const f32x4 fa0 = *(const f32x4 *)(a + c * 16);
+            const f32x4 fa1 = *(const f32x4 *)(a + 16 * LDS_LD + c * 16);
+            if (nt == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], gacc[0][0], 0, 0, 0);
+                    gacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], gacc[1][0], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], gacc[0][1], 0, 0, 0);
+                    gacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], gacc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    };
     auto compute = [&](int cur, auto q0c, auto q1c) {
         constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
         const float *a = As + cur * BM * LDS_LD + (wm * WM + l31) * LDS_LD + 4 * lh;
@@ -213,6 +249,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    auto mma = [&](int kt, auto q0c, auto q1c) {
+        if constexpr (GROUPED) compute_grouped(kt & 1, kt, q0c, q1c);
+        else compute(kt & 1, q0c, q1c);
     };
     using std::integral_constant;
     constexpr int NQ = BK / 8;
@@ -246,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
             return;
         }
         // ---- segment 1 ----
-        compute(kt & 1, integral_constant<int, 0>{}, integral_constant<int, Q1>{});
+        mma(kt, integral_constant<int, 0>{}, integral_constant<int, Q1>{});
         if constexpr (decltype(do_load)::value && ABL < 1) load_global(ld, kt + 2);
 #pragma unroll
         for (int g = 0; g < Q1 * PER_Q; ++g) {
@@ -256,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- segment 2 ----
-        compute(kt & 1, integral_constant<int, Q1>{}, integral_constant<int, Q2>{});
+        mma(kt, integral_constant<int, Q1>{}, integral_constant<int, Q2>{});
         if constexpr (ABL < 2) {
             store_lds(stg, (kt + 1) & 1);
 #pragma unroll
@@ -268,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- segment 3 ----
-        if constexpr (Q2 < NQ) compute(kt & 1, integral_constant<int, Q2>{}, integral_constant<int, NQ>{});
+        if constexpr (Q2 < NQ) mma(kt, integral_constant<int, Q2>{}, integral_constant<int, NQ>{});
         if constexpr (ABL < 2) __syncthreads();
     };
     const std::true_type LOAD{};
@@ -295,12 +335,21 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
         step(s0, s1, kt, NOLOAD);
         ++kt;
     }
-    compute((KT - 1) & 1, integral_constant<int, 0>{}, integral_constant<int, NQ>{});
+    mma(KT - 1, integral_constant<int, 0>{}, integral_constant<int, NQ>{});
     __syncthreads();
 
     // ---- epilogue ------------------------------------------------------------------
     // 1. accumulators -> LDS tile [BM][EP_LD] (32 consecutive floats per half-wave: conflict-free)
     float *ep = smem;
+    if constexpr (GROUPED) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ep[(wm * WM + i * 16 + (lane >> 4) * 4 + r) * EP_LD + j * 16 + (lane & 15)] = gacc[i][j][r];
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -367,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false>
 static int launch_conv(const ConvArgs &a, hipStream_t stream)
 {
     ConvArgs p = a;
@@ -381,7 +430,7 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     p.n_tiles = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
-    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL>;
+    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
@@ -417,7 +466,11 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
         if (abl == 3) return launch_conv<128, 128, 2, 2, true, 3>(a, stream);
         return padded ? launch_conv<128, 128, 2, 2, true>(a, stream) : launch_conv<128, 128, 2, 2, false>(a, stream);
     case 64: return padded ? launch_conv<128, 64, 4, 1, true>(a, stream) : launch_conv<128, 64, 4, 1, false>(a, stream);
-    case 32: return padded ? launch_conv<128, 32, 4, 1, true>(a, stream) : launch_conv<128, 32, 4, 1, false>(a, stream);
+    case 32:
+        if (a.groups == 4 && a.Cin == 128 && a.Cout == 32 && !getenv("HVN_NO_GROUPED"))
+            return padded ? launch_conv<128, 32, 4, 1, true, 0, true>(a, stream) : launch_conv<128, 32, 4, 1, false, 0, true>(a, stream);
+        if (a.groups != 1 && !(a.groups == 4 && a.Cin == 128 && a.Cout == 32)) return -1;
+        return padded ? launch_conv<128, 32, 4, 1, true>(a, stream) : launch_conv<128, 32, 4, 1, false>(a, stream);
     default: return -1;
     }
 }

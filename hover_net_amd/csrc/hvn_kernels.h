@@ -18,6 +18,7 @@ struct ConvArgs {
     long m_tiles;
     int n_tiles;
     int stagger;
+    int groups;
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);

@@ -92,6 +92,7 @@ class Engine:
             o = self.ops[i]
             o.kind, o.kh, o.kw, o.stride = op.kind, op.kh, op.kw, op.stride
             o.pad_t, o.pad_l, o.relu, o.cout, o.tile_n, o.x_dtype = op.pad_t, op.pad_l, op.relu, op.cout, op.tile_n, 0
+            o.groups = int(op.extra.get("groups", 1))
             if op.kind == PL.OP_PREDMAP:
                 o.x.base = self.logits["np"].data_ptr()
                 o.res.base = self.logits["hv"].data_ptr()

@@ -204,6 +204,7 @@ class Plan:
         op.pre = None if pre is None else (np.asarray(pre[0], np.float32), np.asarray(pre[1], np.float32))
         op.post = None if post is None else (np.asarray(post[0], np.float32), np.asarray(post[1], np.float32))
         op.extra["cin_real"] = x.c // groups
+        op.extra["groups"] = groups
         return self.add(op)
 
     # -- memory planning --------------------------------------------------------

@@ -47,7 +47,9 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           HoVerNet.forward's NCHW contract), w = [kh][kw][3][64] taps (1/255 and BN folded), bias, relu
  *   CONV    y = epi( conv( pro(x) ) ):  pro = relu(x*pre_scale+pre_shift) if pre_scale,
  *           w = [cout_pad][x.c/32][kh*kw][32] fp32 (cout_pad = multiple of tile_n; reduction order =
- *           32-channel slab, tap, channel),
+ *           32-channel slab, tap, channel); groups = 4 declares the block-diagonal packing of a grouped
+ *           conv with 32 input / 8 output channels per group (dense-unit conv2, net_utils.py:114-125):
+ *           the kernel then multiplies each slab only against its own group's output columns,
  *           epi = (+bias) (relu) (+res) (relu(.*post_scale+post_shift) if post_scale)
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
@@ -56,7 +58,7 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           cout = nr_types (0 if none)
  */
 typedef struct hvn_op {
-    int32_t kind, kh, kw, stride, pad_t, pad_l, relu, cout, tile_n, x_dtype;
+    int32_t kind, kh, kw, stride, pad_t, pad_l, relu, cout, tile_n, x_dtype, groups, _rsv;
     hvn_view x, res, y;
     const float *w, *bias, *pre_scale, *pre_shift, *post_scale, *post_shift; /* dev */
 } hvn_op;
