@@ -153,9 +153,10 @@ def process_images(images, model, nr_types=None, batch_size=32, return_centroids
             full = stitch(pred[k:k + n], infos[i], img.shape).contiguous()
             inst, rec, _ = post_proc.process_batch_device(full.unsqueeze(0), nr_types, return_centroids)
             info = None
+            inst_h = inst[0].cpu().numpy()
             if rec is not None:
-                info = post_proc.records_to_dict(rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1), nr_types)
-            results[i] = (inst[0].cpu().numpy(), info)
+                info = post_proc.records_to_dict(rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1), nr_types, inst_h)
+            results[i] = (inst_h, info)
         k += n
     if world > 1:
         import torch.distributed as dist

@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhvn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("hvn_conv.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip")
+SOURCES = ("hvn_conv.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fvisibility=hidden", "-Wno-unused-value")
 
@@ -32,7 +32,7 @@ class hvn_inst_rec(ctypes.Structure):
 EXPORTS = (
     "hvn_version", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_postproc_workspace_bytes", "hvn_postproc",
-    "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table",
+    "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
 )
 
 
@@ -80,6 +80,9 @@ def lib():
                                          ctypes.c_size_t, ctypes.c_void_p]
         L.hvn_instance_table_workspace_bytes.restype = ctypes.c_size_t
         L.hvn_instance_table_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.hvn_trace_contours.restype = ctypes.c_long
+        L.hvn_trace_contours.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
         _LIB = L
     return _LIB
 

@@ -10,8 +10,9 @@
 
 Instance separation (`__proc_np_hv`, post_proc.py:26-90) and the array half of the
 per-instance loop (bbox / centroid / type vote, post_proc.py:119-181) are HIP kernels in
-libhvn_hip.so.  Contour tracing (`cv2.findContours`, post_proc.py:132-135) is not built yet:
-`contour` is None in the returned dict.  No CPU fallback exists.
+libhvn_hip.so.  Contour tracing (`cv2.findContours`, post_proc.py:132-135) is an O(perimeter) host
+routine of the same library over each instance's bbox crop (csrc/hvn_contour.cpp).  No CPU fallback
+exists for the GPU stages.
 """
 import ctypes
 
@@ -100,17 +101,41 @@ def process_batch_device(pred_dev, nr_types=None, return_centroids=False):
     return inst, None, None
 
 
-def records_to_dict(rec_host, nr_types):
-    """One tile's records (numpy structured array) -> the reference's inst_info_dict."""
+def trace_contours(inst_host, rec_host):
+    """Host: outer-border contour of every present label (cv2.findContours ... [0][0] semantics, see
+    csrc/hvn_contour.cpp).  -> dict label -> int32 [K,2] array of (x, y)."""
+    inst_host = np.ascontiguousarray(inst_host, np.int32)
+    rec_host = np.ascontiguousarray(rec_host)
+    h, w = inst_host.shape
+    n = rec_host.shape[0]
+    max_pts = 4 * int((inst_host > 0).sum()) + 8 * n + 16
+    pts = np.empty((max_pts, 2), np.int32)
+    offs = np.empty(n + 1, np.int64)
+    tot = L.lib().hvn_trace_contours(inst_host.ctypes.data, h, w, rec_host.ctypes.data, n, pts.ctypes.data, max_pts, offs.ctypes.data)
+    if tot < 0:
+        raise L.HvnError("hvn_trace_contours failed (%d)" % tot)
+    return {int(rec_host["label"][i]): pts[offs[i]:offs[i + 1]].copy() for i in range(n) if rec_host["area"][i] > 0}
+
+
+def records_to_dict(rec_host, nr_types, inst_host=None):
+    """One tile's records (numpy structured array) -> the reference's inst_info_dict.  With `inst_host`
+    the contours are traced too and, like the reference (post_proc.py:140-143), instances whose contour
+    has fewer than 3 points are left out of the dict (they stay in the instance map)."""
     out = {}
+    contours = trace_contours(inst_host, rec_host) if inst_host is not None else None
     for r in rec_host[rec_host["area"] > 0]:
+        contour = None
+        if contours is not None:
+            contour = contours[int(r["label"])]
+            if contour.shape[0] < 3:
+                continue
         bbox = np.array([[r["rmin"], r["cmin"]], [r["rmax"], r["cmax"]]])
         cx = r["sum_x"] / float(r["area"]) + r["cmin"]   # m10/m00 on the crop, then + offset (post_proc.py:145-152)
         cy = r["sum_y"] / float(r["area"]) + r["rmin"]
         out[int(r["label"])] = {
             "bbox": bbox,
             "centroid": np.array([cx, cy]),
-            "contour": None,
+            "contour": contour,
             "type_prob": None if nr_types is None else float(r["type_count"] / (r["area"] + 1.0e-6)),
             "type": None if nr_types is None else int(r["type"]),
         }
@@ -124,5 +149,5 @@ def process(pred_map, nr_types=None, return_centroids=False):
     pred_inst = inst[0].cpu().numpy()
     info = None
     if rec is not None:
-        info = records_to_dict(rec[0].cpu().numpy().view(_REC_DTYPE).reshape(-1), nr_types)
+        info = records_to_dict(rec[0].cpu().numpy().view(_REC_DTYPE).reshape(-1), nr_types, pred_inst)
     return pred_inst, info

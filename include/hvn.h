@@ -109,6 +109,13 @@ HVN_API int hvn_instance_table(const int32_t *inst, const float *pred, int n, in
                                int nr_types, hvn_inst_rec *records, int32_t *counts, int max_inst,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* -- contours: cv2.findContours(crop, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] of process() (post_proc.py:132-143)
+ * HOST function (O(perimeter) per instance over its bbox crop): inst = host int32 [h][w]; recs = host records
+ * (slots with area 0 are skipped); pts = host int32 [max_pts][2] as (x, y) in map coordinates;
+ * offs = host int64 [n_rec + 1] prefix offsets into pts.  Returns the total number of points or <0. */
+HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_inst_rec *recs, int n_rec,
+                                int32_t *pts, long max_pts, int64_t *offs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,9 +78,12 @@ def test_process_contract_and_instance_table():
     want = O.proc_np_hv(pred[..., 1:])
     np.testing.assert_array_equal(inst, want)
     ids = [i for i in np.unique(want) if i > 0]
-    assert sorted(info.keys()) == ids
+    assert set(info.keys()) <= set(ids)
+    for i in set(ids) - set(info.keys()):   # post_proc.py:140-143: contours with < 3 points are skipped
+        ys, xs = np.nonzero(want == i)
+        assert min(ys.max() - ys.min(), xs.max() - xs.min()) == 0
     tmap = pred[..., 0].astype(np.int32)
-    for i in ids:
+    for i in sorted(info.keys()):
         m = want == i
         ys, xs = np.nonzero(m)
         e = info[i]
@@ -88,6 +91,10 @@ def test_process_contract_and_instance_table():
         cx = (xs - xs.min()).sum() / float(m.sum()) + xs.min()
         cy = (ys - ys.min()).sum() / float(m.sum()) + ys.min()
         assert e["centroid"].tolist() == [cx, cy]
+        c = e["contour"]
+        assert c.dtype == np.int32 and c.ndim == 2 and c.shape[1] == 2 and c.shape[0] >= 3
+        assert m[c[:, 1], c[:, 0]].all()                          # contour points lie on the instance
+        assert tuple(c[0]) == (xs[ys == ys.min()].min(), ys.min())  # findContours starts at the first raster pixel
         tl, tc = np.unique(tmap[m], return_counts=True)
         order = sorted(zip(tl, tc), key=lambda t: t[1], reverse=True)   # post_proc.py:168-177
         t = order[0][0]
