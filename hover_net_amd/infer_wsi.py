@@ -1,0 +1,261 @@
+"""Whole-slide inference -- the data path of `infer/wsi.py:InferManager.process_single_file`
+(/root/reference/infer/wsi.py:449-709) with the prediction map resident in HBM.
+
+Kept from the reference (pinned by tests/test_infer_wsi.py against the reference's own functions):
+  * geometry: `_get_patch_top_left_info` (wsi.py:64-88), `_get_tile_info` (:92-151),
+    `_get_chunk_patch_info` (:155-221), the chunk -> patch selection rule (:341-351) and the
+    mask test of `__select_valid_patches` (:300-327);
+  * the three post-processing phases over grid / boundary / cross tiles and the sequential merge
+    rules of `post_proc_normal_tile_callback` (:569-599) and `post_proc_fixing_tile_callback`
+    (:602-677), including the reference's id offsetting by the running maximum id.
+
+Different by design:
+  * `pred_map` ([H,W,3|4] float32, 25.6 GB for a 40k x 40k slide) lives in HBM (288 GB per GPU)
+    instead of a disk memmap written by a helper process (wsi.py:520-534, 235-258); patch outputs
+    are scattered into it with one indexed write per chunk;
+  * patches of a chunk are sharded over the ranks (one process per GPU, `infer_tile.run_sharded`,
+    one all_gather per chunk) instead of `nn.DataParallel`;
+  * a tile (2048 x 2048 + margins) is post-processed on the GPU (`post_proc.process_batch_device`:
+    per-component parallel watershed) instead of a 16-process CPU pool; tiles are dealt round-robin
+    to the ranks, results are exchanged, and every rank applies the merge callbacks in tile order;
+  * the slide backend is any object with `.shape` and `.read_region((x, y), (w, h))`
+    (`ArraySlide` wraps a numpy array / memmap; OpenSlide is not required).
+"""
+import numpy as np
+import torch
+
+from . import infer_tile, post_proc, run_desc
+
+
+# --------------------------------------------------------------------------------------------
+# geometry
+def get_patch_top_left_info(img_shape, input_size, output_size):
+    img_shape, input_size, output_size = (np.asarray(a) for a in (img_shape, input_size, output_size))
+    diff = input_size - output_size
+    nr_step = np.floor((img_shape - diff) / output_size) + 1
+    last = (diff // 2) + nr_step * output_size
+    ys = np.arange(diff[0] // 2, last[0], output_size[0], dtype=np.int32)
+    xs = np.arange(diff[1] // 2, last[1], output_size[1], dtype=np.int32)
+    # np.meshgrid(ys, xs) flattened: x outer, y inner
+    out_tl = np.stack([np.tile(ys, xs.shape[0]), np.repeat(xs, ys.shape[0])], axis=-1)
+    return out_tl - diff // 2, out_tl
+
+
+def get_tile_info(img_shape, tile_shape, ambiguous_size=128):
+    img_shape, tile_shape = np.asarray(img_shape), np.asarray(tile_shape)
+    tl, _ = get_patch_top_left_info(img_shape, tile_shape, tile_shape)
+    br = np.minimum(tl + tile_shape, img_shape)
+    grid = np.stack([tl, br], axis=1)
+    gx, gy = np.unique(tl[:, 1]), np.unique(tl[:, 0])
+    a = ambiguous_size
+
+    def boxes(y_lo, x_lo, y_hi, x_hi):
+        # np.meshgrid(first, second) flattened pairs: second outer, first inner
+        def mesh(f, s):
+            return np.tile(f, s.shape[0]), np.repeat(s, f.shape[0])
+
+        ly, lx = mesh(y_lo, x_lo)
+        hy, hx = mesh(y_hi, x_hi)
+        return np.stack([np.stack([ly, lx], -1), np.stack([hy, hx], -1)], axis=1)
+
+    bx = boxes(gy, gx[1:] - a, gy + tile_shape[0], gx[1:] + a)
+    # the reference builds the horizontal strips with meshgrid(y, x) as well -> y inner, x outer
+    by = boxes(gy[1:] - a, gx, gy[1:] + a, gx + tile_shape[1])
+    cross = boxes(gy[1:] - 2 * a, gx[1:] - 2 * a, gy[1:] + 2 * a, gx[1:] + 2 * a)
+    return grid, np.concatenate([bx, by], axis=0), cross
+
+
+def get_chunk_patch_info(img_shape, chunk_input_shape, patch_input_shape, patch_output_shape):
+    img_shape, chunk_input_shape, pin, pout = (np.asarray(a) for a in (img_shape, chunk_input_shape, patch_input_shape, patch_output_shape))
+    rnd = lambda x, y: np.floor(x / y) * y  # noqa: E731
+    diff = pin - pout
+    chunk_out = rnd(chunk_input_shape - diff, pout).astype(np.int64)
+    chunk_in = (chunk_out + diff).astype(np.int64)
+    p_in_tl, _ = get_patch_top_left_info(img_shape, pin, pout)
+    p_out_tl = p_in_tl + diff
+    patch_info = np.stack([np.stack([p_in_tl, p_in_tl + pin], axis=1), np.stack([p_out_tl, p_out_tl + pout], axis=1)], axis=1)
+    c_in_tl, _ = get_patch_top_left_info(img_shape, chunk_in, chunk_out)
+    c_in_br = c_in_tl + chunk_in
+    for ax in (0, 1):  # keep the chunk inside the slide, on the patch grid
+        sel = np.nonzero(c_in_br[:, ax] > img_shape[ax])[0]
+        c_in_br[sel, ax] = rnd((img_shape[ax] - diff[ax]) - c_in_tl[sel, ax], pout[ax]) + c_in_tl[sel, ax] + diff[ax]
+    chunk_info = np.stack([np.stack([c_in_tl, c_in_br], axis=1),
+                           np.stack([c_in_tl + diff // 2, c_in_br - diff // 2], axis=1)], axis=1)
+    return chunk_info, patch_info
+
+
+def select_valid(info_list, mask, proc_shape, has_output_info=True):
+    """Indices of boxes whose (output) area touches the tissue mask (wsi.py:300-327)."""
+    ratio = mask.shape[0] / proc_shape[0]
+    keep = []
+    for i in range(info_list.shape[0]):
+        box = np.squeeze(info_list[i])
+        box = np.rint((box[1] if has_output_info else box) * ratio).astype(np.int64)
+        if np.sum(mask[box[0][0]:box[1][0], box[0][1]:box[1][1]]) > 0:
+            keep.append(i)
+    return info_list[keep]
+
+
+# --------------------------------------------------------------------------------------------
+class ArraySlide:
+    """Slide backend over an in-memory / memory-mapped uint8 [H,W,3] array (misc/wsi_handler.py API subset)."""
+
+    def __init__(self, array):
+        self.array = array
+        self.shape = array.shape
+
+    def read_region(self, coords, size):
+        x, y = int(coords[0]), int(coords[1])
+        w, h = int(size[0]), int(size[1])
+        return np.asarray(self.array[y:y + h, x:x + w, :3])
+
+
+def remove_inst(inst_map, ids):
+    if len(ids):
+        inst_map[np.isin(inst_map, np.asarray(list(ids)))] = 0
+    return inst_map
+
+
+class WsiMerger:
+    """Host state of the three-phase stitch: global instance map + instance dict, updated strictly in tile
+    order (the callbacks of wsi.py:569-677 'must be in sequential ordering')."""
+
+    def __init__(self, proc_shape):
+        self.inst_map = np.zeros(tuple(proc_shape), np.int32)
+        self.inst_info = {}
+
+    def _max_id(self):
+        return max(self.inst_info.keys()) if self.inst_info else 0
+
+    def normal(self, pred_inst, info, tile_tl, tile_br):
+        if len(info) == 0:
+            return
+        top_left = np.asarray(tile_tl)[::-1]
+        off = self._max_id()
+        for i, e in info.items():
+            e["bbox"] = e["bbox"] + top_left        # (sic) the reference adds (x, y) to the (row, col) box
+            e["contour"] = e["contour"] + top_left
+            e["centroid"] = e["centroid"] + top_left
+            self.inst_info[i + off] = e
+        pred_inst = pred_inst.copy()
+        pred_inst[pred_inst > 0] += off
+        self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = pred_inst
+
+    def fixing(self, pred_inst, info, tile_tl, tile_br):
+        if len(info) == 0:
+            return
+        top_left = np.asarray(tile_tl)[::-1]
+        off = self._max_id()                                     # before any removal (wsi.py:621-624)
+        roi = self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]].copy()
+        edge = np.concatenate([roi[[0, -1], :].ravel(), roi[:, [0, -1]].ravel()])
+        on_edge = np.unique(edge)[1:]                            # "[1:]  # exclude background" (wsi.py:631, as is)
+        inner = np.unique(roi)[1:]
+        inner = np.setdiff1d(inner, on_edge, assume_unique=True)
+        roi = remove_inst(roi, inner)                            # old nuclei fully inside the strip are replaced
+        self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = roi
+        for i in inner:
+            self.inst_info.pop(i, None)
+        pred_inst = pred_inst.copy()
+        touching = np.unique(pred_inst[roi > 0])                 # new nuclei overlapping the kept (split) ones
+        new_inner = np.setdiff1d(np.unique(pred_inst)[1:], touching, assume_unique=True)
+        pred_inst = remove_inst(pred_inst, touching)
+        for i in new_inner:
+            if i not in info:                                    # contour had < 3 points (wsi.py:655-657)
+                continue
+            e = info[i]
+            e["bbox"] = e["bbox"] + top_left
+            e["contour"] = e["contour"] + top_left
+            e["centroid"] = e["centroid"] + top_left
+            self.inst_info[i + off] = e
+        pred_inst[pred_inst > 0] += off
+        self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = roi + pred_inst
+
+
+# --------------------------------------------------------------------------------------------
+class WsiInference:
+    def __init__(self, model, nr_types=None, batch_size=32, chunk_shape=10000, tile_shape=2048, ambiguous_size=128,
+                 patch_input_shape=None, patch_output_shape=None):
+        net = model.module if hasattr(model, "module") and not hasattr(model, "engine") else model
+        self.model, self.nr_types, self.batch_size = model, nr_types, batch_size
+        pin = patch_input_shape or (270 if net.mode == "original" else 256)     # run_infer.py:145-150
+        pout = patch_output_shape or (80 if net.mode == "original" else 164)
+        self.pin, self.pout = np.array([pin, pin]), np.array([pout, pout])
+        self.chunk_shape = np.array([chunk_shape, chunk_shape])
+        self.tile_shape = np.array([tile_shape, tile_shape], np.int64)
+        self.ambiguous_size = ambiguous_size
+        self.device = next(net.parameters()).device
+        self.out_ch = 3 if nr_types is None else 4
+
+    # -- stage 1: raw prediction into the HBM-resident map ----------------------------------------
+    def raw_prediction(self, slide, mask):
+        shape = np.array(slide.shape[:2])
+        pred_map = torch.zeros((int(shape[0]), int(shape[1]), self.out_ch), dtype=torch.float32, device=self.device)
+        chunk_info, patch_info = get_chunk_patch_info(shape, self.chunk_shape, self.pin, self.pout)
+        between = lambda x, a, b: (a <= x) & (x <= b)  # noqa: E731
+        h = int(self.pout[0])
+        ar = torch.arange(h, device=self.device)
+        for ci in range(chunk_info.shape[0]):
+            chunk = chunk_info[ci]
+            start, end = chunk[0, 0], chunk[0, 1] - self.pin
+            sel = between(patch_info[:, 0, 0, 0], start[0], end[0]) & between(patch_info[:, 0, 0, 1], start[1], end[1])
+            plist = select_valid(np.array(patch_info[sel]), mask, shape)
+            if plist.shape[0] == 0:
+                continue
+            region = slide.read_region(chunk[0][0][::-1], (chunk[0][1] - chunk[0][0])[::-1])
+            rel = plist[:, 0, 0] - chunk[0, 0]                    # patch input top-left inside the chunk
+            win = int(self.pin[0])
+            patches = np.stack([region[y:y + win, x:x + win] for y, x in rel])
+            out = infer_tile.run_sharded(torch.from_numpy(np.ascontiguousarray(patches)),
+                                         lambda b: run_desc.infer_step_device(b.to(self.device), self.model), self.batch_size)
+            # output top-left in the slide = input top-left + diff // 2 (the placement rule of _assemble_and_flush,
+            # wsi.py:235-258; patch_info[:, 1] is offset by the FULL diff in the reference and only feeds the mask test)
+            otl = torch.from_numpy((plist[:, 0, 0] + (self.pin - self.pout) // 2).astype(np.int64)).to(self.device)
+            rows = (otl[:, 0, None] + ar)[:, :, None].expand(-1, h, h)
+            cols = (otl[:, 1, None] + ar)[:, None, :].expand(-1, h, h)
+            pred_map[rows, cols] = out                            # one scatter per chunk
+        return pred_map
+
+    # -- stage 2: three-phase post-processing ------------------------------------------------------
+    def _tile_results(self, pred_map, tiles):
+        """(pred_inst numpy, inst_info dict) per tile; tiles dealt round-robin to the ranks."""
+        _, rank, world = infer_tile._dist()
+        mine = {}
+        for i in range(tiles.shape[0]):
+            if i % world != rank:
+                continue
+            tl, br = tiles[i][0], tiles[i][1]
+            tile = pred_map[tl[0]:br[0], tl[1]:br[1]].contiguous().unsqueeze(0)
+            inst, rec, _ = post_proc.process_batch_device(tile, self.nr_types, True)
+            inst_h = inst[0].cpu().numpy()
+            info = post_proc.records_to_dict(rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1), self.nr_types, inst_h)
+            mine[i] = (inst_h, info)
+        if world > 1:
+            import torch.distributed as dist
+
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+            mine = {k: v for p in parts for k, v in p.items()}
+        return [mine[i] for i in range(tiles.shape[0])]
+
+    def run(self, slide, mask=None):
+        """slide: object with .shape / .read_region; mask: uint8 tissue mask at any scale (None = all tissue).
+        Returns (inst_map int32 [H,W] numpy, inst_info dict) like `wsi_inst_map` / `wsi_inst_info`."""
+        shape = np.array(slide.shape[:2])
+        if mask is None:
+            mask = np.ones((max(1, int(shape[0]) // 32), max(1, int(shape[1]) // 32)), np.uint8)
+        pred_map = self.raw_prediction(slide, mask)
+        return self.stitch_instances(pred_map, mask)
+
+    def stitch_instances(self, pred_map, mask=None):
+        """Stage 2 alone: three-phase tile post-processing + merge of an HBM-resident prediction map."""
+        shape = np.array(pred_map.shape[:2])
+        if mask is None:
+            mask = np.ones((max(1, int(shape[0]) // 32), max(1, int(shape[1]) // 32)), np.uint8)
+        grid, boundary, cross = get_tile_info(shape, self.tile_shape, self.ambiguous_size)
+        merger = WsiMerger(shape)
+        for phase, tiles in enumerate((grid, boundary, cross)):
+            tiles = select_valid(tiles, mask, shape, has_output_info=False)
+            cb = merger.normal if phase == 0 else merger.fixing
+            for (inst_h, info), t in zip(self._tile_results(pred_map, tiles), tiles):
+                cb(inst_h, info, t[0], t[1])
+        return merger.inst_map, merger.inst_info
