@@ -41,7 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #define BK 32
 #define LDS_LD 36  // padded row length in floats
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 
     const int kchunks = p.Cin / BK;
     const int KT = p.KH * p.KW * kchunks;
-    const bool has_pre = p.pre_s != nullptr;
+    const bool has_pre = HAS_PRE && p.pre_s != nullptr;
     // branch-free prologue: scale 1 / shift 0 / clamp -inf when there is none
     const float pre_lo = has_pre ? 0.f : -__builtin_inff();
     const float *pre_s = has_pre ? p.pre_s : p.w;  // any valid address; value unused when !has_pre
@@ -133,8 +133,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
         const char *wbase = (const char *)(p.w + (long)kt * BK);
         const char *sbase = (const char *)(pre_s + ld_c * pre_step);
         const char *bbase = (const char *)(pre_b + ld_c * pre_step);
-        st.rps = *(const f32x4 *)(sbase + (unsigned long)(unsigned)(scol * 4));
-        st.rpb = *(const f32x4 *)(bbase + (unsigned long)(unsigned)(scol * 4));
+        if constexpr (HAS_PRE) {
+            st.rps = *(const f32x4 *)(sbase + (unsigned long)(unsigned)(scol * 4));
+            st.rpb = *(const f32x4 *)(bbase + (unsigned long)(unsigned)(scol * 4));
+        }
         if constexpr (PADDED) st.okmask = 0;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
@@ -161,6 +163,15 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     auto store_lds = [&](Stage &st, int buf) {
         float *a = As + buf * BM * LDS_LD;
         float *b = Bs + buf * BN * LDS_LD;
+        if constexpr (!PADDED && !HAS_PRE) {
+            // nothing to transform: rows past the end of the image batch hold finite garbage that only
+            // reaches accumulator rows which are never stored
+#pragma unroll
+            for (int j = 0; j < PA; ++j) *(f32x4 *)(a + (srow + 32 * j) * LDS_LD + scol) = st.ra[j];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * LDS_LD + scol) = st.rb[j];
+            return;
+        }
         f32x4 ps = st.rps, pb = st.rpb;
         if (!has_pre) {
             ps = (f32x4){1.f, 1.f, 1.f, 1.f};
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true>
 static int launch_conv(const ConvArgs &a, hipStream_t stream)
 {
     ConvArgs p = a;
@@ -430,7 +441,7 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     p.n_tiles = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
-    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED>;
+    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED, HAS_PRE>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
@@ -464,8 +475,13 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
         if (abl == 1) return launch_conv<128, 128, 2, 2, true, 1>(a, stream);
         if (abl == 2) return launch_conv<128, 128, 2, 2, true, 2>(a, stream);
         if (abl == 3) return launch_conv<128, 128, 2, 2, true, 3>(a, stream);
+        if (!a.pre_s && !getenv("HVN_NO_RAWSTORE"))
+            return padded ? launch_conv<128, 128, 2, 2, true, 0, false, false>(a, stream) : launch_conv<128, 128, 2, 2, false, 0, false, false>(a, stream);
         return padded ? launch_conv<128, 128, 2, 2, true>(a, stream) : launch_conv<128, 128, 2, 2, false>(a, stream);
-    case 64: return padded ? launch_conv<128, 64, 4, 1, true>(a, stream) : launch_conv<128, 64, 4, 1, false>(a, stream);
+    case 64:
+        if (!a.pre_s && !getenv("HVN_NO_RAWSTORE"))
+            return padded ? launch_conv<128, 64, 4, 1, true, 0, false, false>(a, stream) : launch_conv<128, 64, 4, 1, false, 0, false, false>(a, stream);
+        return padded ? launch_conv<128, 64, 4, 1, true>(a, stream) : launch_conv<128, 64, 4, 1, false>(a, stream);
     case 32:
         if (a.groups == 4 && a.Cin == 128 && a.Cout == 32 && !getenv("HVN_NO_GROUPED"))
             return padded ? launch_conv<128, 32, 4, 1, true, 0, true>(a, stream) : launch_conv<128, 32, 4, 1, false, 0, true>(a, stream);
