@@ -107,6 +107,13 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_t = op->pad_t; a.pad_l = op->pad_l;
         a.relu = op->relu;
         a.groups = op->groups > 1 ? op->groups : 1;
+        a.x2 = (const float *)op->x2.base;
+        a.x2sn = op->x2.sn; a.x2sy = op->x2.sy; a.x2sx = op->x2.sx;
+        a.Cin2 = a.x2 ? op->x2.c : 0;
+        a.stride2 = op->_rsv > 0 ? op->_rsv : 1;
+        if (a.x2 && (op->kh != 1 || op->kw != 1 || a.stride != 1 || a.Cin2 % 32 || !aligned16(a.x2) || ((a.x2sn | a.x2sy | a.x2sx) & 3) ||
+                     a.pre_s || (long)(a.Ho - 1) * a.stride2 >= op->x2.h || (long)(a.Wo - 1) * a.stride2 >= op->x2.w))
+            return fail(HVN_E_ARG, "conv: second input needs a 1x1 stride-1 op without prologue and a view that covers the output grid%s", "");
         a.M = (long)batch * a.Ho * a.Wo;
         if (!a.x || !a.w || !a.y) return fail(HVN_E_ARG, "conv: null pointer%s", "");
         if (a.Cin % 32) return fail(HVN_E_ARG, "conv: input channels must be a multiple of 32 (got %s%ld)", "", a.Cin);

@@ -41,7 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #define BK 32
 #define LDS_LD 36  // padded row length in floats
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -69,11 +69,6 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     const unsigned m0 = (unsigned)m_tile * BM;
     const int n0 = n_tile * BN;
     const unsigned M = (unsigned)p.M;
-    // De-phase the two workgroups that share a CU (dispatched 256 apart): in lockstep their
-    // barrier / staging phases coincide and leave the matrix pipe idle; half a k-step apart one
-    // wave's MFMAs cover the other's staging.  Pure timing, no effect on results.
-    if (p.stagger && ((blockIdx.x >> 8) & 1))
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks each
 
     // ---- per-thread staging coordinates --------------------------------------------
     // Addressing is split into a wave-UNIFORM 64-bit base that moves with the k-step (scalar ALU)
@@ -106,13 +101,30 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     // how out-of-image taps (zero padding) and tail rows are produced without a select.
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)xblk, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, 0x7fffffff, 0x00020000);
-    const long Ktot = (long)p.KH * p.KW * p.Cin;
+    // optional second 1x1 input (fused shortcut): its channels extend the reduction after the first input's
+    unsigned a2_voff[PA];
+    const float *x2blk = HAS_X2 ? p.x2 + (long)n_blk * p.x2sn : p.x;
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc((void *)x2blk, 0, 0x7fffffff, 0x00020000);
+    if constexpr (HAS_X2) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const unsigned m = m0 + srow + 32 * j;
+            const bool ok = m < M;
+            const unsigned mm = ok ? m : m0;
+            const unsigned n = mm / HoWo;
+            const unsigned rem = mm - n * HoWo;
+            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+            a2_voff[j] = ok ? (unsigned)(((long)(n - n_blk) * p.x2sn + (long)(oy * p.stride2) * p.x2sy + (long)(ox * p.stride2) * p.x2sx + scol) * 4) : OOB;
+        }
+    }
+    const long Ktot = (long)p.KH * p.KW * p.Cin + (HAS_X2 ? p.Cin2 : 0);
     unsigned w_voff[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) w_voff[j] = (unsigned)(((long)(n0 + srow + 32 * j) * Ktot + scol) * 4);
 
     const int kchunks = p.Cin / BK;
-    const int KT = p.KH * p.KW * kchunks;
+    const int KT1 = p.KH * p.KW * kchunks;
+    const int KT = KT1 + (HAS_X2 ? p.Cin2 / BK : 0);
     const bool has_pre = HAS_PRE && p.pre_s != nullptr;
     // branch-free prologue: scale 1 / shift 0 / clamp -inf when there is none
     const float pre_lo = has_pre ? 0.f : -__builtin_inff();
@@ -130,8 +142,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
 
     // issue the raw loads of one k-step (nothing here waits on memory)
     auto load_global = [&](Stage &st, int kt) {
-        const int a_soff = (int)(((long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BK) * 4);  // uniform (SALU)
+        int a_soff = (int)(((long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BK) * 4);  // uniform (SALU)
         const int w_soff = kt * (BK * 4);
+        const bool second = HAS_X2 && kt >= KT1;                                             // uniform
+        if constexpr (HAS_X2) a_soff = second ? (kt - KT1) * (BK * 4) : a_soff;
         if constexpr (HAS_PRE) {
             st.rps = *(const f32x4 *)(pre_s + ld_c * pre_step + scol);
             st.rpb = *(const f32x4 *)(pre_b + ld_c * pre_step + scol);
@@ -143,7 +157,11 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
                 const bool ok = (unsigned)(a_iy[j] + ld_r) < (unsigned)p.H && (unsigned)(a_ix[j] + ld_s) < (unsigned)p.W;
                 vo = ok ? vo : OOB;
             }
-            st.ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, a_soff, 0));
+            if constexpr (HAS_X2) {
+                vo = second ? a2_voff[j] : vo;
+                st.ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? rsrc_a2 : rsrc_a, vo, a_soff, 0));
+            } else
+                st.ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, a_soff, 0));
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j)
@@ -415,21 +433,15 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
 static int launch_conv(const ConvArgs &a, hipStream_t stream)
 {
     ConvArgs p = a;
-    static int stagger = -1;
-    if (stagger < 0) {
-        const char *e = getenv("HVN_CONV_STAGGER");
-        stagger = e ? atoi(e) : 0;
-    }
-    p.stagger = stagger;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
-    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED, HAS_PRE>;
+    auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED, HAS_PRE, HAS_X2>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
@@ -458,6 +470,12 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
     if (abl < 0) {
         const char *e = getenv("HVN_CONV_ABLATE");
         abl = e ? atoi(e) : 0;
+    }
+    if (a.x2) {  // fused shortcut: 1x1, no prologue, no padding (validated by the caller)
+        if (padded || a.Cin2 % BK) return -1;
+        if (tile_n == 128) return launch_conv<128, 128, 2, 2, false, 0, false, false, true>(a, stream);
+        if (tile_n == 64) return launch_conv<128, 64, 4, 1, false, 0, false, false, true>(a, stream);
+        return -1;
     }
     switch (tile_n) {
     case 128:

@@ -17,8 +17,10 @@ struct ConvArgs {
     long M;
     long m_tiles;
     int n_tiles;
-    int stagger;
     int groups;
+    const float *x2;      // optional second 1x1 input (channels appended to the reduction)
+    long x2sn, x2sy, x2sx;
+    int Cin2, stride2;
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);

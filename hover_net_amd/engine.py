@@ -93,6 +93,7 @@ class Engine:
             o.kind, o.kh, o.kw, o.stride = op.kind, op.kh, op.kw, op.stride
             o.pad_t, o.pad_l, o.relu, o.cout, o.tile_n, o.x_dtype = op.pad_t, op.pad_l, op.relu, op.cout, op.tile_n, 0
             o.groups = int(op.extra.get("groups", 1))
+            o._rsv = int(op.extra.get("stride2", 1))
             if op.kind == PL.OP_PREDMAP:
                 o.x.base = self.logits["np"].data_ptr()
                 o.res.base = self.logits["hv"].data_ptr()
@@ -101,7 +102,7 @@ class Engine:
                 o.y.base = self.pred_map.data_ptr()
                 o.y.h, o.y.w, o.y.c = P.pred_map.h, P.pred_map.w, P.pred_map.c
                 continue
-            for fld, v in (("x", op.x), ("res", op.res), ("y", op.y)):
+            for fld, v in (("x", op.x), ("res", op.res), ("y", op.y), ("x2", op.extra.get("x2"))):
                 if v is None:
                     continue
                 if v.buf.offset >= 0:
@@ -157,7 +158,7 @@ class Engine:
             ctypes.memmove(ops, self.ops, ctypes.sizeof(self.ops))
             for i, op in enumerate(self.plan.ops):
                 o = ops[i]
-                for fld in ("x", "res", "y"):
+                for fld in ("x", "res", "y", "x2"):
                     v = getattr(o, fld)
                     if v.base:
                         if op.kind == PL.OP_HEAD and fld == "y":

@@ -188,13 +188,18 @@ class Plan:
         self.ops.append(op)
         return op
 
-    def conv(self, name, x, y, wt, *, stride=1, pad=(0, 0), bn=None, relu=0, pre=None, res=None, post=None, groups=1, bias=None):
+    def conv(self, name, x, y, wt, *, stride=1, pad=(0, 0), bn=None, relu=0, pre=None, res=None, post=None, groups=1, bias=None,
+             x2=None, wt2=None, stride2=1):
+        """x2 / wt2 / stride2: a second 1x1 input whose channels are appended to the reduction (fused shortcut)."""
         s = b = None
         if bn is not None:
             s, b = bn
+        if x2 is not None:
+            assert wt.shape[2:] == (1, 1) and wt2.shape[2:] == (1, 1) and stride == 1 and groups == 1 and pre is None
+            wt = np.concatenate([wt, wt2], axis=1)
         w, tn = _pack_conv(wt, s, groups)
         cout, _cin_g, kh, kw = wt.shape
-        assert x.c == w.shape[1] * 32 and y.c == cout, (name, x.c, w.shape, y.c, cout)
+        assert x.c + (x2.c if x2 is not None else 0) == w.shape[1] * 32 and y.c == cout, (name, x.c, w.shape, y.c, cout)
         assert y.h == (x.h + pad[0] + pad[1] - kh) // stride + 1, (name, x.h, y.h)
         if bias is not None:
             b = bias if b is None else b + bias
@@ -203,8 +208,13 @@ class Plan:
         op.bias = None if b is None else np.asarray(b, np.float32)
         op.pre = None if pre is None else (np.asarray(pre[0], np.float32), np.asarray(pre[1], np.float32))
         op.post = None if post is None else (np.asarray(post[0], np.float32), np.asarray(post[1], np.float32))
-        op.extra["cin_real"] = x.c // groups
+        op.extra["cin_real"] = (x.c + (x2.c if x2 is not None else 0)) // groups
         op.extra["groups"] = groups
+        if x2 is not None:
+            assert y.h == (x2.h - 1) // stride2 + 1
+            op.extra["x2"], op.extra["stride2"] = x2, stride2
+            if x2.buf.dtype == "f32":
+                op.extra["reads"] = [x2.buf]
         return self.add(op)
 
     # -- memory planning --------------------------------------------------------
@@ -253,7 +263,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
     for bi, (name, in_ch, (c1, c2, c3), units, stride) in enumerate(arch.RES_BLOCKS):
         hi, ho = x.h, d_sz[bi]
         acc = View(P.buf(name + ".sum", ho, ho, c3))
-        P.conv(name + ".shortcut", x, acc, W(name + ".shortcut.weight"), stride=stride)
+        block_in = x
         cur = x
         for i in range(units):
             p = "%s.units.%d." % (name, i)
@@ -266,8 +276,14 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
                    bn=BN(p + "conv2/bn"), relu=1)
             last = i == units - 1
             out = View(P.buf(name + ".out", ho, ho, c3)) if last else acc
-            P.conv(p + "conv3", t2, out, W(p + "conv3.weight"), res=acc,
-                   post=BN(name + ".blk_bna.bn") if last else None)
+            if i == 0:
+                # unit 0: the strided 1x1 shortcut (net_utils.py:229-230) is a second input of the same GEMM
+                # (K = c2 + in_ch): its result is never written to / re-read from HBM as a residual
+                P.conv(p + "conv3", t2, out, W(p + "conv3.weight"), x2=block_in, wt2=W(name + ".shortcut.weight"), stride2=stride,
+                       post=BN(name + ".blk_bna.bn") if last else None)
+            else:
+                P.conv(p + "conv3", t2, out, W(p + "conv3.weight"), res=acc,
+                       post=BN(name + ".blk_bna.bn") if last else None)
             cur = acc
         x = out
         skips.append(out)

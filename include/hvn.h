@@ -49,7 +49,10 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           w = [cout_pad][x.c/32][kh*kw][32] fp32 (cout_pad = multiple of tile_n; reduction order =
  *           32-channel slab, tap, channel); groups = 4 declares the block-diagonal packing of a grouped
  *           conv with 32 input / 8 output channels per group (dense-unit conv2, net_utils.py:114-125):
- *           the kernel then multiplies each slab only against its own group's output columns,
+ *           the kernel then multiplies each slab only against its own group's output columns;
+ *           x2 (1x1 convs): a second input tensor whose channels are appended to the reduction, read at
+ *           (oy*s2, ox*s2) with s2 = `_rsv` -- y = W1.x + W2.x2 fuses a residual block's strided 1x1 shortcut
+ *           (net_utils.py:229-230) into its first conv3, the weight rows being [x.c | x2.c] wide,
  *           epi = (+bias) (relu) (+res) (relu(.*post_scale+post_shift) if post_scale)
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
@@ -60,6 +63,7 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
 typedef struct hvn_op {
     int32_t kind, kh, kw, stride, pad_t, pad_l, relu, cout, tile_n, x_dtype, groups, _rsv;
     hvn_view x, res, y;
+    hvn_view x2;         /* CONV, 1x1 only: optional second input (base NULL = none), sampled with spatial stride `_rsv` */
     const float *w, *bias, *pre_scale, *pre_shift, *post_scale, *post_shift; /* dev */
 } hvn_op;
 

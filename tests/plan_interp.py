@@ -34,10 +34,13 @@ class Arena:
         return t[:, v.y0:v.y0 + v.h, v.x0:v.x0 + v.w, v.c0:v.c0 + v.c]
 
 
-def conv_ref(op, x, res=None):
-    """x: [N,h,w,cin] NHWC view tensor -> [N,ho,wo,cout]."""
+def conv_ref(op, x, res=None, x2=None):
+    """x: [N,h,w,cin] NHWC view tensor -> [N,ho,wo,cout].  x2: optional second 1x1 input (strided)."""
     if op.pre is not None:
         x = F.relu(x * torch.from_numpy(op.pre[0]) + torch.from_numpy(op.pre[1]))
+    if x2 is not None:
+        s2 = op.extra["stride2"]
+        x = torch.cat([x, x2[:, ::s2, ::s2][:, :x.shape[1], :x.shape[2]]], -1)
     w = torch.from_numpy(PL.unpack_conv(op.w, op.cout))
     w = w.view(op.cout, w.shape[1], op.kh, op.kw)
     xin = x.permute(0, 3, 1, 2)
@@ -96,7 +99,8 @@ def run(plan, imgs_u8, taps=None):
                 A.view(op.y).copy_(conv0_ref(op, imgs_u8))
             elif op.kind == PL.OP_CONV:
                 res = A.view(op.res).clone() if op.res is not None else None
-                A.view(op.y).copy_(conv_ref(op, A.view(op.x).clone(), res))
+                x2 = A.view(op.extra["x2"]).clone() if op.extra.get("x2") is not None else None
+                A.view(op.y).copy_(conv_ref(op, A.view(op.x).clone(), res, x2))
             elif op.kind == PL.OP_UPADD:
                 A.view(op.y).copy_(upadd_ref(A.view(op.x), A.view(op.res)))
             elif op.kind == PL.OP_HEAD:

@@ -114,3 +114,33 @@ def test_descriptor_validation():
     assert b"conv" in L.lib().hvn_last_error()
     op.kind = 99
     assert L.lib().hvn_run_op(ctypes.addressof(op), 1, None) == -1
+
+
+@pytest.mark.parametrize("stride2,cin2,cout", [(1, 64, 256), (2, 256, 512)])
+def test_conv1x1_fused_shortcut_second_input(stride2, cin2, cout):
+    """Residual block unit 0: conv3(t2) + strided 1x1 shortcut(x_in) as ONE GEMM over two inputs, with the
+    block-closing BN-ReLU epilogue."""
+    import plan_interp
+    from gpu_util import MiniPlan, rand_conv_weight
+    from hover_net_amd import plan as PL
+    from hover_net_amd.engine import Engine
+
+    rng = np.random.default_rng(5)
+    n, so = 2, 13
+    si = (so - 1) * stride2 + 1 + (1 if stride2 == 2 else 0)   # even input like the real net (H = 2*Ho)
+    P = MiniPlan()
+    x = PL.View(P.buf("t2", so, so, 64))
+    x2 = PL.View(P.buf("xin", si, si, cin2))
+    y = PL.View(P.buf("y", so, so, cout))
+    op = P.conv("fused", x, y, rand_conv_weight(rng, cout, 64, 1), x2=x2, wt2=rand_conv_weight(rng, cout, cin2, 1),
+                stride2=stride2, post=(rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.3, cout)))
+    P.pack()
+    eng = Engine(P, max_batch=n, n_split=1)
+    eng.arena.copy_(torch.randn(eng.arena.shape, generator=torch.Generator().manual_seed(1)))
+    A = plan_interp.Arena(P, n)
+    A.flat.copy_(eng.arena.cpu())
+    eng.run_raw(n)
+    torch.cuda.synchronize()
+    want = plan_interp.conv_ref(op, A.view(op.x).clone(), None, A.view(x2).clone())
+    got = eng.buffer(op.y, n).cpu()
+    _check(got, want)

@@ -45,7 +45,8 @@ def test_every_conv_is_kernel_legal():
             if op.kind != PL.OP_CONV:
                 continue
             assert op.x.c % 32 == 0 and op.x.c0 % 4 == 0 and op.y.c0 % 4 == 0, op.name
-            assert op.w.shape[0] % op.tile_n == 0 and op.w.shape[1] * 32 == op.x.c and op.w.shape[3] == 32
+            x2 = op.extra.get('x2')
+            assert op.w.shape[0] % op.tile_n == 0 and op.w.shape[1] * 32 == op.x.c + (x2.c if x2 is not None else 0) and op.w.shape[3] == 32
             assert op.tile_n in (32, 64, 128)
 
 
