@@ -39,6 +39,7 @@ class Engine:
         import os
         self.n_split = int(os.environ.get("HVN_SPLIT", "2")) if n_split is None else int(n_split)
         self.n_lane_streams = int(os.environ.get("HVN_LANES", "2"))  # extra streams for the decoder branches
+        self.split_decoder = os.environ.get("HVN_SPLIT_DECODER", "0") != "0"
         self._streams = None
         self._upload_params()
         self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32, device=self.device)
@@ -175,18 +176,21 @@ class Engine:
             self._sub_ops[key] = ops
         return self._sub_ops[key]
 
-    def _launch(self, ops, n_ops, cnt, stream, lane_streams):
-        """One sub-batch: encoder on `stream`, decoder branches fanned out over `lane_streams`."""
+    def _launch(self, ops, n_ops, cnt, stream, lane_streams, start=0):
+        """One sub-batch from op `start`: encoder on `stream`, decoder branches fanned out over `lane_streams`."""
         lib = L.lib()
         base = ctypes.addressof(ops)
         osz = ctypes.sizeof(L.hvn_op)
         lanes = getattr(self.plan, "lanes", None)
         if not lanes or not lane_streams or n_ops != len(self.ops):
-            L.check(lib.hvn_run_plan(base, n_ops, cnt, ctypes.c_void_p(stream.cuda_stream)), "hvn_run_plan")
+            L.check(lib.hvn_run_plan(base + start * osz, n_ops - start, cnt, ctypes.c_void_p(stream.cuda_stream)), "hvn_run_plan")
             return
         branch_i = 0
         pending = []
         for lane, lo, hi in lanes:
+            lo = max(lo, start)
+            if lo >= hi:
+                continue
             if lane == "main":
                 for ev in pending:          # join before the shared epilogue
                     stream.wait_event(ev)
@@ -217,8 +221,33 @@ class Engine:
         if self._streams is None or len(self._streams) < need:
             self._streams = [torch.cuda.Stream(self.device) for _ in range(need)]
         lane_pool = self._streams[split - 1:]
+        lanes = getattr(self.plan, "lanes", None)
+        enc_end = lanes[0][2] if (lanes and lanes[0][0] == "main" and len(lanes) > 1) else 0
         if split == 1:
             self._launch(self.ops, n_ops, n, main, lane_pool[:n_lane])
+        elif not self.split_decoder and enc_end and upto is None:
+            # encoder (large launches, tail-quantised) on `split` sub-batch streams; the decoder's small
+            # dense-unit launches run on the whole batch, fanned out over the branch lanes
+            o0 = self.ops[0]
+            esz = 1 if o0.x_dtype == 0 else 4
+            fork = torch.cuda.Event()
+            fork.record(main)
+            bounds = [n * k // split for k in range(split + 1)]
+            for k in range(split):
+                first, cnt = bounds[k], bounds[k + 1] - bounds[k]
+                ops = self._shifted_ops(first)
+                ops[0].x = o0.x
+                ops[0].x_dtype = o0.x_dtype
+                ops[0].x.base = o0.x.base + esz * first * o0.x.sn
+                st = main if k == 0 else self._streams[k - 1]
+                if k:
+                    st.wait_event(fork)
+                L.check(L.lib().hvn_run_plan(ctypes.addressof(ops), enc_end, cnt, ctypes.c_void_p(st.cuda_stream)), "hvn_run_plan")
+                if k:
+                    join = torch.cuda.Event()
+                    join.record(st)
+                    main.wait_event(join)
+            self._launch(self.ops, n_ops, n, main, lane_pool[:n_lane], start=enc_end)
         else:
             o0 = self.ops[0]
             esz = 1 if o0.x_dtype == 0 else 4
