@@ -41,5 +41,21 @@ def train_step(batch_data, run_info):  # run_desc.py:12-109
     raise NotImplementedError("hover_net_amd: the training step (SURVEY 8a T1-T5) is not built in this round")
 
 
-def valid_step(batch_data, run_info):  # run_desc.py:113-167
-    raise NotImplementedError("hover_net_amd: the validation step (SURVEY 8a T3) is not built in this round")
+def valid_step(batch_data, run_info):
+    """Drop-in for run_desc.py:113-167: eval-mode forward of a validation batch on the HIP path; returns
+    the same `{"raw": {...}}` protocol (prob_np = softmax(np)[..., 1], pred_hv, argmax type map)."""
+    run_info, _state_info = run_info
+    model = run_info["net"]["desc"]
+    net = _unwrap(model)
+    imgs = batch_data["img"]
+    true_np = torch.squeeze(batch_data["np_map"]).type(torch.int64)
+    true_hv = torch.squeeze(batch_data["hv_map"]).type(torch.float32)
+    pred = infer_step_device(imgs, model)            # [N,h,w,3|4] = [type?, p_nuc, h, v] on the device
+    pred = pred.cpu()
+    c0 = 0 if net.nr_types is None else 1
+    result = {"raw": {"imgs": imgs.numpy(), "true_np": true_np.numpy(), "true_hv": true_hv.numpy(),
+                      "prob_np": pred[..., c0].numpy().copy(), "pred_hv": pred[..., c0 + 1:c0 + 3].numpy().copy()}}
+    if net.nr_types is not None:
+        result["raw"]["true_tp"] = torch.squeeze(batch_data["tp_map"]).type(torch.int64).numpy()
+        result["raw"]["pred_tp"] = pred[..., 0].numpy().copy()
+    return result

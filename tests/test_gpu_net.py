@@ -176,3 +176,23 @@ def test_wsi_pipeline_on_synthetic_slide():
     inst2, info2 = wsi.stitch_instances(torch.from_numpy(maps).to("cuda"))
     np.testing.assert_array_equal(inst_map, inst2)
     assert sorted(info2) == sorted(info)
+
+
+def test_valid_step_protocol():
+    """run_desc.valid_step (run_desc.py:113-167): same raw-dict protocol, values from the oracle."""
+    from hover_net_amd import run_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    from oracle import net_torch
+
+    sd = synth_state_dict("original", 5, seed=91)
+    net = _model("original", 5, sd)
+    tiles = torch.from_numpy(synth_tiles(2, 270, seed=92))
+    batch = {"img": tiles, "np_map": torch.zeros(2, 80, 80, dtype=torch.int32), "hv_map": torch.zeros(2, 80, 80, 2),
+             "tp_map": torch.zeros(2, 80, 80, dtype=torch.int32)}
+    out = run_desc.valid_step(batch, [{"net": {"desc": net}}, {}])["raw"]
+    assert sorted(out) == ["imgs", "pred_hv", "pred_tp", "prob_np", "true_hv", "true_np", "true_tp"]
+    want = net_torch.infer_epilogue(net_torch.forward(sd, tiles.permute(0, 3, 1, 2).float(), "original")).numpy()
+    assert out["prob_np"].shape == (2, 80, 80) and out["pred_hv"].shape == (2, 80, 80, 2) and out["pred_tp"].shape == (2, 80, 80)
+    assert np.abs(out["prob_np"] - want[..., 1]).max() <= TOL and np.abs(out["pred_hv"] - want[..., 2:]).max() <= TOL
+    assert (out["pred_tp"] != want[..., 0]).mean() < 2e-3
+    assert out["true_np"].dtype == np.int64 and out["true_hv"].dtype == np.float32
