@@ -123,11 +123,36 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
             return fail(HVN_E_ARG, "conv: prologue vectors must be 16-byte aligned and come in pairs%s", "");
         if (!a.post_s != !a.post_b) return fail(HVN_E_ARG, "conv: epilogue affine must come in pairs%s", "");
         if (op->y.c != op->cout) return fail(HVN_E_ARG, "conv: output view channels != cout%s", "");
+        a.nbatch = op->nbatch > 1 ? op->nbatch : 1;
+        a.xb = op->batch_stride[0]; a.wb = op->batch_stride[1]; a.yb = op->batch_stride[2];
+        if (a.nbatch > 1 && ((a.xb | a.wb | a.yb) & 3)) return fail(HVN_E_ARG, "conv: batch strides must keep 16-byte alignment%s", "");
         if (g_prof) prof_mark(s);
         int rc = hvn_launch_conv(a, op->tile_n, s);
         if (g_prof) prof_mark(s);
         if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "conv: launch failed (tile_n=%s%ld)", "", op->tile_n);
         return 0;
+    }
+    case HVN_OP_WINO_IN:
+    case HVN_OP_WINO_OUT: {
+        WinoArgs a;
+        const bool in = op->kind == HVN_OP_WINO_IN;
+        a.x = (const float *)op->x.base;
+        a.xsn = op->x.sn; a.xsy = op->x.sy; a.xsx = op->x.sx;
+        a.y = (float *)op->y.base;
+        a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
+        a.mat = op->w; a.bias = op->bias;
+        a.N = batch; a.H = op->x.h; a.W = op->x.w; a.C = in ? op->x.c : op->y.c;
+        a.ty = op->kh; a.tx = op->kw; a.pad = op->pad_t; a.relu = op->relu;
+        if (!a.x || !a.y || !a.mat || a.ty <= 0 || a.tx <= 0 || (a.C & 3)) return fail(HVN_E_ARG, "winograd transform: bad descriptor%s", "");
+        if (!aligned16(a.x) || !aligned16(a.y) || ((a.xsn | a.xsy | a.xsx | a.ysn | a.ysy | a.ysx) & 3))
+            return fail(HVN_E_ARG, "winograd transform: views not 16-byte aligned%s", "");
+        if (in && (op->y.h != 36 || op->y.w != a.ty * a.tx || op->y.c != a.C)) return fail(HVN_E_ARG, "wino_in: V must be [36][tiles][c]%s", "");
+        if (!in && (op->x.h != 36 || op->x.w != a.ty * a.tx || op->y.h != 2 * a.ty || op->y.w != 2 * a.tx || op->x.c != a.C))
+            return fail(HVN_E_ARG, "wino_out: M must be [36][tiles][cout] and y 2ty x 2tx%s", "");
+        if (g_prof) prof_mark(s);
+        int rc = in ? hvn_launch_wino_in(a, s) : hvn_launch_wino_out(a, s);
+        if (g_prof) prof_mark(s);
+        return rc;
     }
     case HVN_OP_UPADD: {
         UpAddArgs a;

@@ -42,8 +42,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #define LDS_LD 36  // padded row length in floats
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
-__global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(const ConvArgs p)
+__global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
 {
+    if (p.nbatch > 1) {  // batched launch: one of nbatch independent problems per blockIdx.y
+        p.x += (long)blockIdx.y * p.xb;
+        p.w += (long)blockIdx.y * p.wb;
+        p.y += (long)blockIdx.y * p.yb;
+    }
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM / 32, PB = BN / 32;  // staging passes (32 rows of 8 float4 per pass)
@@ -450,7 +455,7 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     const long groups = (p.m_tiles + 7) / 8;
     const long grid = groups * 8 * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, p.nbatch > 1 ? p.nbatch : 1), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

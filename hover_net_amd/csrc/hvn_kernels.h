@@ -21,6 +21,8 @@ struct ConvArgs {
     const float *x2;      // optional second 1x1 input (channels appended to the reduction)
     long x2sn, x2sy, x2sx;
     int Cin2, stride2;
+    int nbatch;           // > 1: blockIdx.y selects one of nbatch independent problems
+    long xb, wb, yb;      // element strides between them
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);
@@ -65,3 +67,16 @@ struct PredMapArgs {
     int N, H, W, nr_types;      // nr_types = 0: no type channel
 };
 int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream);
+
+struct WinoArgs {
+    const float *x;       // WINO_IN: input view; WINO_OUT: M [36][tiles][C] per sample
+    long xsn, xsy, xsx;
+    float *y;             // WINO_IN: V [36][tiles][C] per sample; WINO_OUT: output view
+    long ysn, ysy, ysx;
+    const float *mat;     // B^T (6x6) or A^T (2x6)
+    const float *bias;    // WINO_OUT only
+    int N, H, W, C;       // WINO_IN: input window extent / channels; WINO_OUT: C = cout
+    int ty, tx, pad, relu;
+};
+int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream);
+int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream);

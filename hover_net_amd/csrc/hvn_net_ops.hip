@@ -168,3 +168,145 @@ int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(hvn_predmap, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---------------------------------------------------------------------------------------
+// Winograd F(2x2,5x5) transforms around the batched GEMM of the 5x5 decoder convs
+// (net_desc.py:45,52,59 conva; 51 % of the network's FLOPs).  y = A^T [ (G g G^T) .* (B^T d B) ] A:
+// 36 multiplications per 2x2 outputs instead of 100 (hover_net_amd/winograd.py derives the matrices).
+// Both kernels are HBM-bound byte movers: one thread = one tile x 4 channels, 16-byte accesses,
+// consecutive threads on consecutive channels.
+__global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4n = p.C >> 2;
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int T1 = p.ty * p.tx;
+    const int tile = (int)(t % T1);
+    const int n = (int)(t / T1);
+    const int tyi = tile / p.tx, txi = tile - tyi * p.tx;
+    const int y0 = 2 * tyi - p.pad, x0 = 2 * txi - p.pad;
+    float bt[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) bt[k] = p.mat[k];  // wave-uniform -> scalar loads
+    const float *src = p.x + (long)n * p.xsn + c4 * 4;
+    // tmp[a][j] = sum_i BT[a][i] d[i][j], column by column
+    float4 tmp[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float4 d[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int yy = y0 + r, xx = x0 + j;
+            d[r] = ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                       ? *(const float4 *)(src + (long)yy * p.xsy + (long)xx * p.xsx)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const float m = bt[a * 6 + r];
+                s.x = fmaf(m, d[r].x, s.x);
+                s.y = fmaf(m, d[r].y, s.y);
+                s.z = fmaf(m, d[r].z, s.z);
+                s.w = fmaf(m, d[r].w, s.w);
+            }
+            tmp[a][j] = s;
+        }
+    }
+    // V[a][b] = sum_j tmp[a][j] BT[b][j]
+    float *dst = p.y + (long)n * p.ysn + (long)tile * p.ysx + c4 * 4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float m = bt[b * 6 + j];
+                s.x = fmaf(m, tmp[a][j].x, s.x);
+                s.y = fmaf(m, tmp[a][j].y, s.y);
+                s.z = fmaf(m, tmp[a][j].z, s.z);
+                s.w = fmaf(m, tmp[a][j].w, s.w);
+            }
+            *(float4 *)(dst + (long)(a * 6 + b) * p.ysy) = s;
+        }
+}
+
+int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream)
+{
+    const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
+    hipLaunchKernelGGL(hvn_wino_in, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+__global__ __launch_bounds__(256) void hvn_wino_out(const WinoArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4n = p.C >> 2;
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int T1 = p.ty * p.tx;
+    const int tile = (int)(t % T1);
+    const int n = (int)(t / T1);
+    const int tyi = tile / p.tx, txi = tile - tyi * p.tx;
+    float at[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) at[k] = p.mat[k];
+    const float *src = p.x + (long)n * p.xsn + (long)tile * p.xsx + c4 * 4;
+    // tmp[pq][b] = sum_a AT[pq][a] M[a][b]
+    float4 tmp[2][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float4 m[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m[a] = *(const float4 *)(src + (long)(a * 6 + b) * p.xsy);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const float w = at[q * 6 + a];
+                s.x = fmaf(w, m[a].x, s.x);
+                s.y = fmaf(w, m[a].y, s.y);
+                s.z = fmaf(w, m[a].z, s.z);
+                s.w = fmaf(w, m[a].w, s.w);
+            }
+            tmp[q][b] = s;
+        }
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *(const float4 *)(p.bias + c4 * 4);
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    float *dst = p.y + (long)n * p.ysn + c4 * 4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)        // output row
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {  // output column
+            float4 s = bias;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const float w = at[r * 6 + b];
+                s.x = fmaf(w, tmp[q][b].x, s.x);
+                s.y = fmaf(w, tmp[q][b].y, s.y);
+                s.z = fmaf(w, tmp[q][b].z, s.z);
+                s.w = fmaf(w, tmp[q][b].w, s.w);
+            }
+            s.x = fmaxf(s.x, lo);
+            s.y = fmaxf(s.y, lo);
+            s.z = fmaxf(s.z, lo);
+            s.w = fmaxf(s.w, lo);
+            *(float4 *)(dst + (long)(2 * tyi + q) * p.ysy + (long)(2 * txi + r) * p.ysx) = s;
+        }
+}
+
+int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream)
+{
+    const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
+    hipLaunchKernelGGL(hvn_wino_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -95,6 +95,11 @@ class Engine:
             o.pad_t, o.pad_l, o.relu, o.cout, o.tile_n, o.x_dtype = op.pad_t, op.pad_l, op.relu, op.cout, op.tile_n, 0
             o.groups = int(op.extra.get("groups", 1))
             o._rsv = int(op.extra.get("stride2", 1))
+            o.nbatch = int(op.extra.get("nbatch", 1))
+            for bi, bs in enumerate(op.extra.get("batch_strides", (0, 0, 0))):
+                o.batch_stride[bi] = int(bs)
+            if op.kind in (PL.OP_WINO_IN, PL.OP_WINO_OUT):
+                o.kh, o.kw = op.extra["tiles"]
             if op.kind == PL.OP_PREDMAP:
                 o.x.base = self.logits["np"].data_ptr()
                 o.res.base = self.logits["hv"].data_ptr()

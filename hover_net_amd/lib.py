@@ -20,7 +20,8 @@ class hvn_view(ctypes.Structure):
 class hvn_op(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("kind", "kh", "kw", "stride", "pad_t", "pad_l", "relu", "cout", "tile_n", "x_dtype", "groups", "_rsv")] + \
                [("x", hvn_view), ("res", hvn_view), ("y", hvn_view), ("x2", hvn_view)] + \
-               [(k, ctypes.c_void_p) for k in ("w", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift")]
+               [(k, ctypes.c_void_p) for k in ("w", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift")] + \
+               [("batch_stride", ctypes.c_int64 * 3), ("nbatch", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
 
 
 class hvn_inst_rec(ctypes.Structure):

@@ -14,6 +14,9 @@ channels-last (NHWC) fp32 activations that stay resident in HBM:
              strided input / output views, so dense-block concats and centre crops
              are address arithmetic, never copies
   UPADD    nearest 2x upsample + (cropped) skip add
+  WINO_IN / WINO_OUT  input / output transforms of the Winograd F(2x2,5x5) form of the 5x5 decoder convs
+           (51 % of the network's FLOPs): 36 multiplications per 2x2 outputs instead of 100; the 36
+           independent [tiles x cin] . [cin x cout] products run as ONE batched launch of the CONV kernel
   HEAD     1x1 conv to the 2..6 logits (+bias), written NCHW (the forward() contract)
   PREDMAP  infer_step's softmax / argmax / concat (run_desc.py:185-194)
 
@@ -28,7 +31,7 @@ import numpy as np
 
 from . import arch
 
-OP_CONV0, OP_CONV, OP_UPADD, OP_HEAD, OP_PREDMAP = 1, 2, 3, 4, 5
+OP_CONV0, OP_CONV, OP_UPADD, OP_HEAD, OP_PREDMAP, OP_WINO_IN, OP_WINO_OUT = 1, 2, 3, 4, 5, 6, 7
 
 
 @dataclass
@@ -97,6 +100,8 @@ class Op:
     extra: dict = field(default_factory=dict)
 
     def flops(self):
+        if "algo_flops" in self.extra:        # Winograd GEMM: credited with the direct convolution's work
+            return self.extra["algo_flops"]
         if self.kind == OP_CONV:
             return 2.0 * self.y.h * self.y.w * self.cout * self.kh * self.kw * self.extra.get("cin_real", self.x.c)
         if self.kind == OP_CONV0:
@@ -217,6 +222,46 @@ class Plan:
                 op.extra["reads"] = [x2.buf]
         return self.add(op)
 
+    def conv_winograd(self, name, x, y, wt, *, pad=(0, 0), bn=None, relu=0, share_in=False):
+        """5x5 stride-1 conv as Winograd F(2x2,5x5): WINO_IN (shared between convs that read the same view with
+        the same padding) -> batched CONV over the 36 transform positions -> WINO_OUT (+bias, ReLU)."""
+        from . import winograd as WG
+
+        cout, cin, kh, kw = wt.shape
+        assert (kh, kw) == (5, 5) and y.h % 2 == 0 and y.w % 2 == 0 and x.c == cin and y.c == cout
+        assert y.h == x.h + pad[0] + pad[1] - 4
+        s = b = None
+        if bn is not None:
+            s, b = bn
+            wt = wt * s[:, None, None, None]
+        ty, tx = y.h // 2, y.w // 2
+        t1 = ty * tx
+        key = (id(x.buf), x.y0, x.x0, x.h, x.w, x.c0, x.c, pad[0])
+        cache = self.__dict__.setdefault("_wino_in", {})
+        if key not in cache:
+            vbuf = self.buf(name + ".V", 36, t1, cin)
+            op = Op(OP_WINO_IN, name + ".wino_in", x=x, y=View(vbuf), w=np.ascontiguousarray(WG.BT, np.float32),
+                    pad_t=pad[0], pad_l=pad[0], extra={"tiles": (ty, tx), "shared": share_in})
+            self.add(op)
+            cache[key] = vbuf
+        vbuf = cache[key]
+        mbuf = self.buf(name + ".M", 36, t1, cout)
+        u = WG.transform_weights(wt)                                          # [36, cout, cin] float64
+        tn = _tile_n(cout)
+        cout_pad = (cout + tn - 1) // tn * tn
+        packed = np.zeros((36, cout_pad, cin // 32, 1, 32), np.float32)
+        packed[:, :cout] = u.reshape(36, cout, cin // 32, 1, 32)
+        g = Op(OP_CONV, name + ".wino_gemm", x=View(vbuf, 0, 0, 1, t1), y=View(mbuf, 0, 0, 1, t1), w=packed, cout=cout, tile_n=tn)
+        g.extra.update(nbatch=36, batch_strides=(t1 * cin, cout_pad * cin, t1 * cout), cin_real=cin, groups=1,
+                       algo_flops=2.0 * y.h * y.w * cout * cin * 25, exec_flops=2.0 * 36 * t1 * cout * cin)
+        self.add(g)
+        # the batched launch touches all 36 rows of V and M
+        for bb in (vbuf, mbuf):
+            bb.last = max(bb.last, len(self.ops) - 1)
+        o = Op(OP_WINO_OUT, name + ".wino_out", x=View(mbuf), y=y, w=np.ascontiguousarray(WG.AT, np.float32),
+               bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx)})
+        return self.add(o)
+
     # -- memory planning --------------------------------------------------------
     def pack(self, align=64):
         """Greedy interval packing of the per-sample activation arena (floats)."""
@@ -240,8 +285,12 @@ class Plan:
         return sum(o.flops() for o in self.ops)
 
 
-def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
-    """sd: reference-format state_dict (torch tensors or numpy arrays)."""
+def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None):
+    """sd: reference-format state_dict (torch tensors or numpy arrays).
+    winograd: run the 5x5 decoder convs as F(2x2,5x5) (default on; env HVN_WINOGRAD=0 turns it off)."""
+    import os
+    if winograd is None:
+        winograd = os.environ.get("HVN_WINOGRAD", "1") != "0"
     P = Plan(mode, nr_types)
     g = P.geo
     k = g["k"]
@@ -305,7 +354,11 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
             p = pb + uname + "."
             ctot = cmid + units * arch.DENSE_GROWTH
             cat = View(P.buf(p + "cat", cat_sz, cat_sz, ctot))
-            P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
+            if k == 5 and winograd:
+                # the u3 input is the same for every branch: its transform runs once, before the branch lanes fork
+                P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"))
+            else:
+                P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
             c = cmid
             win = cat
             for i in range(units):
@@ -322,8 +375,12 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
             P.add(Op(OP_UPADD, p + "upadd", x=uo, res=skip, y=nxt))
             cur_in = nxt
         u1 = View(P.buf(pb + "u1", g["out"], g["out"], 64))
-        P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
-               bn=BN(pb + "u0.bn"), relu=1)
+        if k == 5 and winograd:
+            P.conv_winograd(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
+                            bn=BN(pb + "u0.bn"), relu=1)
+        else:
+            P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
+                   bn=BN(pb + "u0.bn"), relu=1)
         oc = arch.branch_out_ch(br, nr_types)
         lg = Buf("logits." + br, g["out"], g["out"], oc)
         P.logits[br] = lg
@@ -339,7 +396,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True):
     # branch then fill the chip together with the others')
     lanes, cur, start = [], None, 0
     for i, op in enumerate(P.ops):
-        lane = op.name.split(".")[1] if op.name.startswith("decoder.") else "main"
+        lane = op.name.split(".")[1] if (op.name.startswith("decoder.") and not op.extra.get("shared")) else "main"
         if lane != cur:
             if cur is not None:
                 lanes.append((cur, start, i))

@@ -38,7 +38,7 @@ typedef struct hvn_view {
     int32_t sc;          /* channel stride in elements (CONV0 input only, e.g. h*w for NCHW) */
 } hvn_view;
 
-enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN_OP_PREDMAP = 5 };
+enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN_OP_PREDMAP = 5, HVN_OP_WINO_IN = 6, HVN_OP_WINO_OUT = 7 };
 
 /*
  * One fused launch of the network plan (hover_net_amd/plan.py lowers
@@ -54,6 +54,13 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           (oy*s2, ox*s2) with s2 = `_rsv` -- y = W1.x + W2.x2 fuses a residual block's strided 1x1 shortcut
  *           (net_utils.py:229-230) into its first conv3, the weight rows being [x.c | x2.c] wide,
  *           epi = (+bias) (relu) (+res) (relu(.*post_scale+post_shift) if post_scale)
+ *           nbatch > 1: `nbatch` independent problems in one launch; problem b reads x.base + b*batch_stride[0],
+ *           w + b*batch_stride[1] and writes y.base + b*batch_stride[2] (elements) -- the 36 transform-domain
+ *           products of a Winograd convolution,
+ *   WINO_IN  Winograd F(2x2,5x5) input transform of a 5x5 stride-1 conv (net_desc.py:45,52,59 conva):
+ *           x = input view (zero padding pad_t/pad_l), y = V as [36][tiles][c] per sample (y.h = 36, y.w = tiles),
+ *           kh x kw = tile grid, w = B^T (6x6),
+ *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [36][tiles][cout] per sample, w = A^T (2x6), kh x kw = tile grid,
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
  *   PREDMAP y.base = [n][h][w][3|4] = [argmax(tp)?, softmax(np)[1], hv0, hv1]
@@ -65,6 +72,8 @@ typedef struct hvn_op {
     hvn_view x, res, y;
     hvn_view x2;         /* CONV, 1x1 only: optional second input (base NULL = none), sampled with spatial stride `_rsv` */
     const float *w, *bias, *pre_scale, *pre_shift, *post_scale, *post_shift; /* dev */
+    int64_t batch_stride[3]; /* CONV with nbatch > 1: element strides of x, w, y between problems */
+    int32_t nbatch, _pad2;
 } hvn_op;
 
 /* -- library ---------------------------------------------------------------------- */

@@ -87,6 +87,38 @@ def predmap_ref(logits, branches):
     return torch.cat(ch, -1)
 
 
+def wino_in_ref(op, x):
+    """x [N,h,w,c] -> V [N,36,T,c] with T = ty*tx tiles (row-major)."""
+    ty, tx = op.extra["tiles"]
+    bt = torch.from_numpy(op.w)                       # [6,6]
+    pt = op.pad_t
+    need_h, need_w = 2 * ty + 4, 2 * tx + 4
+    xp = F.pad(x.permute(0, 3, 1, 2), (pt, need_w - x.shape[2] - pt, pt, need_h - x.shape[1] - pt))
+    tiles = xp.unfold(2, 6, 2).unfold(3, 6, 2)        # [N,c,ty,tx,6,6]
+    v = torch.einsum("ai,nctsij,bj->nabtsc", bt, tiles, bt)
+    return v.reshape(x.shape[0], 36, ty * tx, x.shape[3])
+
+
+def wino_gemm_ref(op, v):
+    """v [N,36,T,cin] -> m [N,36,T,cout]."""
+    w = torch.from_numpy(op.w[:, :op.cout]).reshape(36, op.cout, -1)   # [36,cout,cin]
+    return torch.einsum("nxtc,xoc->nxto", v, w)
+
+
+def wino_out_ref(op, m):
+    """m [N,36,T,cout] -> y [N,2ty,2tx,cout]."""
+    ty, tx = op.extra["tiles"]
+    at = torch.from_numpy(op.w)                        # [2,6]
+    n, _, _, co = m.shape
+    mm = m.reshape(n, 6, 6, ty, tx, co)
+    y = torch.einsum("pa,nabtsc,qb->ntpsqc", at, mm, at).reshape(n, 2 * ty, 2 * tx, co)
+    if op.bias is not None:
+        y = y + torch.from_numpy(op.bias)
+    if op.relu:
+        y = F.relu(y)
+    return y
+
+
 def run(plan, imgs_u8, taps=None):
     """imgs_u8: uint8 [N,H,W,3] tensor -> (logits dict NCHW, pred_map or None)."""
     n = imgs_u8.shape[0]
@@ -97,6 +129,12 @@ def run(plan, imgs_u8, taps=None):
         for op in plan.ops:
             if op.kind == PL.OP_CONV0:
                 A.view(op.y).copy_(conv0_ref(op, imgs_u8))
+            elif op.kind == PL.OP_WINO_IN:
+                A.view(op.y).copy_(wino_in_ref(op, A.view(op.x).clone()))
+            elif op.kind == PL.OP_CONV and op.extra.get("nbatch"):
+                A.tensor(op.y.buf).copy_(wino_gemm_ref(op, A.tensor(op.x.buf).clone()))
+            elif op.kind == PL.OP_WINO_OUT:
+                A.view(op.y).copy_(wino_out_ref(op, A.view(op.x).clone()))
             elif op.kind == PL.OP_CONV:
                 res = A.view(op.res).clone() if op.res is not None else None
                 x2 = A.view(op.extra["x2"]).clone() if op.extra.get("x2") is not None else None

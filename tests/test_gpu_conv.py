@@ -144,3 +144,45 @@ def test_conv1x1_fused_shortcut_second_input(stride2, cin2, cout):
     want = plan_interp.conv_ref(op, A.view(op.x).clone(), None, A.view(x2).clone())
     got = eng.buffer(op.y, n).cpu()
     _check(got, want)
+
+
+@pytest.mark.parametrize("cin,cout,s,pad,bn", [(64, 128, 14, (0, 0), False), (256, 64, 12, (2, 2), True), (1024, 256, 10, (0, 0), False)])
+def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn):
+    """WINO_IN -> batched GEMM -> WINO_OUT (F(2x2,5x5)) against a direct fp32 5x5 convolution, writing into a
+    channel window of a wider buffer like the dense-block concat."""
+    import plan_interp
+    import torch.nn.functional as F
+    from gpu_util import MiniPlan, rand_conv_weight
+    from hover_net_amd import plan as PL
+    from hover_net_amd.engine import Engine
+
+    rng = np.random.default_rng(7)
+    n = 2
+    so = s + pad[0] + pad[1] - 4
+    P = MiniPlan()
+    x = PL.View(P.buf("x", s, s, cin))
+    ybuf = P.buf("y", so, so, cout + 32)
+    y = PL.View(ybuf, 0, 0, so, so, 32, cout)
+    wt = rand_conv_weight(rng, cout, cin, 5)
+    kw = dict(bn=(rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout)), relu=1) if bn else {}
+    P.conv_winograd("w", x, y, wt, pad=pad, **kw)
+    ybuf.first = 0      # keep the output buffer live from the start so the packer cannot lend its space to V / M
+    P.pack()
+    eng = Engine(P, max_batch=n, n_split=1)
+    eng.arena.copy_(torch.randn(eng.arena.shape, generator=torch.Generator().manual_seed(3)))
+    xin = eng.buffer(x, n).cpu().clone()
+    before = eng.buffer(PL.View(ybuf), n).cpu().clone()
+    eng.run_raw(n)
+    torch.cuda.synchronize()
+    w = torch.from_numpy(wt).float()
+    want = F.conv2d(F.pad(xin.permute(0, 3, 1, 2), (pad[0], pad[1], pad[0], pad[1])), w).permute(0, 2, 3, 1)
+    if bn:
+        want = F.relu(want * torch.from_numpy(kw["bn"][0]).float() + torch.from_numpy(kw["bn"][1]).float())
+    got = eng.buffer(PL.View(ybuf), n).cpu()
+    _check(got[..., 32:], want, tol=5e-4)
+    assert torch.equal(got[..., :32], before[..., :32])      # the neighbouring channels are untouched
+    # and the interpreter's transform-domain tensors agree stage by stage
+    A = plan_interp.Arena(P, n)
+    A.view(x).copy_(xin)
+    v = plan_interp.wino_in_ref(P.ops[0], A.view(x).clone())
+    _check(eng.buffer(P.ops[0].y, n).cpu().reshape(v.shape), v, tol=1e-4)

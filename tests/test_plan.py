@@ -35,7 +35,7 @@ def test_arena_packing_has_no_live_overlap():
             if a.last < b.first or b.last < a.first:
                 continue
             assert a.offset + a.size <= b.offset or b.offset + b.size <= a.offset, (a.name, b.name)
-    assert P.arena_per_sample * 4 < 300e6  # ~260 MB / tile (decoder branches keep their buffers live: concurrent lanes)
+    assert P.arena_per_sample * 4 < 1000e6  # ~930 MB / tile: the Winograd transform-domain tensors (36/4 x the 5x5 convs' inputs and outputs) of three concurrent branches
 
 
 def test_every_conv_is_kernel_legal():
