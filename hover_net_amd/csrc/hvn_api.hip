@@ -141,14 +141,18 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.y = (float *)op->y.base;
         a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
         a.mat = op->w; a.bias = op->bias;
-        a.N = batch; a.H = op->x.h; a.W = op->x.w; a.C = in ? op->x.c : op->y.c;
+        a.N = batch; a.H = in ? op->x.h : op->y.h; a.W = in ? op->x.w : op->y.w; a.C = in ? op->x.c : op->y.c;
         a.ty = op->kh; a.tx = op->kw; a.pad = op->pad_t; a.relu = op->relu;
+        const int n2 = in ? op->y.h : op->x.h;       // transform positions: 36 -> F(2x2,5x5), 64 -> F(4x4,5x5)
+        a.m = n2 == 36 ? 2 : n2 == 64 ? 4 : 0;
+        if (!a.m) return fail(HVN_E_ARG, "winograd transform: %s%ld transform positions (36 or 64 expected)", "", (long)n2);
         if (!a.x || !a.y || !a.mat || a.ty <= 0 || a.tx <= 0 || (a.C & 3)) return fail(HVN_E_ARG, "winograd transform: bad descriptor%s", "");
         if (!aligned16(a.x) || !aligned16(a.y) || ((a.xsn | a.xsy | a.xsx | a.ysn | a.ysy | a.ysx) & 3))
             return fail(HVN_E_ARG, "winograd transform: views not 16-byte aligned%s", "");
-        if (in && (op->y.h != 36 || op->y.w != a.ty * a.tx || op->y.c != a.C)) return fail(HVN_E_ARG, "wino_in: V must be [36][tiles][c]%s", "");
-        if (!in && (op->x.h != 36 || op->x.w != a.ty * a.tx || op->y.h != 2 * a.ty || op->y.w != 2 * a.tx || op->x.c != a.C))
-            return fail(HVN_E_ARG, "wino_out: M must be [36][tiles][cout] and y 2ty x 2tx%s", "");
+        if (in && (op->y.w != a.ty * a.tx || op->y.c != a.C)) return fail(HVN_E_ARG, "wino_in: V must be [n*n][tiles][c]%s", "");
+        if (!in && (op->x.w != a.ty * a.tx || op->y.h > a.m * a.ty || op->y.h <= a.m * (a.ty - 1) || op->y.w > a.m * a.tx ||
+                    op->y.w <= a.m * (a.tx - 1) || op->x.c != a.C))
+            return fail(HVN_E_ARG, "wino_out: M must be [n*n][tiles][cout] and the tiles must cover y%s", "");
         if (g_prof) prof_mark(s);
         int rc = in ? hvn_launch_wino_in(a, s) : hvn_launch_wino_out(a, s);
         if (g_prof) prof_mark(s);

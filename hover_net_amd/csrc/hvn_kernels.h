@@ -69,14 +69,15 @@ struct PredMapArgs {
 int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream);
 
 struct WinoArgs {
-    const float *x;       // WINO_IN: input view; WINO_OUT: M [36][tiles][C] per sample
+    const float *x;       // WINO_IN: input view; WINO_OUT: M [n*n][tiles][C] per sample (n = m + 4)
     long xsn, xsy, xsx;
-    float *y;             // WINO_IN: V [36][tiles][C] per sample; WINO_OUT: output view
+    float *y;             // WINO_IN: V [n*n][tiles][C] per sample; WINO_OUT: output view
     long ysn, ysy, ysx;
-    const float *mat;     // B^T (6x6) or A^T (2x6)
+    const float *mat;     // B^T (n x n) or A^T (m x n)
     const float *bias;    // WINO_OUT only
-    int N, H, W, C;       // WINO_IN: input window extent / channels; WINO_OUT: C = cout
+    int N, H, W, C;       // WINO_IN: input window extent / channels; WINO_OUT: output extent / cout
     int ty, tx, pad, relu;
+    int m;                // output tile edge: 2 or 4
 };
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream);
 int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream);

@@ -170,143 +170,138 @@ int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream)
 }
 
 // ---------------------------------------------------------------------------------------
-// Winograd F(2x2,5x5) transforms around the batched GEMM of the 5x5 decoder convs
+// Winograd F(m x m, 5x5) transforms (m = 2 or 4, n = m + 4) around the batched GEMM of the 5x5 decoder convs
 // (net_desc.py:45,52,59 conva; 51 % of the network's FLOPs).  y = A^T [ (G g G^T) .* (B^T d B) ] A:
-// 36 multiplications per 2x2 outputs instead of 100 (hover_net_amd/winograd.py derives the matrices).
-// Both kernels are HBM-bound byte movers: one thread = one tile x 4 channels, 16-byte accesses,
-// consecutive threads on consecutive channels.
+// n^2 multiplications per m^2 outputs instead of 25 m^2 (hover_net_amd/winograd.py derives the matrices).
+// Both kernels are HBM-bound byte movers: one thread = one tile x VW channels, consecutive threads on
+// consecutive channels.  VW = 4 (16-byte accesses) where the n^2 x VW register tile fits, 2 for the 8x8 input tile.
+template <int VW> struct WVec;
+template <> struct WVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <> struct WVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+
+template <int MO, int VW>
 __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
 {
+    constexpr int NW = MO + 4;
+    typedef typename WVec<VW>::T VT;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c4n = p.C >> 2;
-    const int c4 = (int)(i % c4n);
-    long t = i / c4n;
+    const int cvn = p.C / VW;
+    const int cv = (int)(i % cvn);
+    long t = i / cvn;
     const int T1 = p.ty * p.tx;
     const int tile = (int)(t % T1);
     const int n = (int)(t / T1);
     const int tyi = tile / p.tx, txi = tile - tyi * p.tx;
-    const int y0 = 2 * tyi - p.pad, x0 = 2 * txi - p.pad;
-    float bt[36];
+    const int y0 = MO * tyi - p.pad, x0 = MO * txi - p.pad;
+    float bt[NW * NW];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) bt[k] = p.mat[k];  // wave-uniform -> scalar loads
-    const float *src = p.x + (long)n * p.xsn + c4 * 4;
+    for (int k = 0; k < NW * NW; ++k) bt[k] = p.mat[k];  // wave-uniform -> scalar loads
+    const float *src = p.x + (long)n * p.xsn + cv * VW;
     // tmp[a][j] = sum_i BT[a][i] d[i][j], column by column
-    float4 tmp[6][6];
+    VT tmp[NW][NW];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        float4 d[6];
+    for (int j = 0; j < NW; ++j) {
+        VT d[NW];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
+        for (int r = 0; r < NW; ++r) {
             const int yy = y0 + r, xx = x0 + j;
             d[r] = ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                       ? *(const float4 *)(src + (long)yy * p.xsy + (long)xx * p.xsx)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                       ? *(const VT *)(src + (long)yy * p.xsy + (long)xx * p.xsx)
+                       : (VT)(0.f);
         }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < NW; ++a) {
+            VT s = (VT)(0.f);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const float m = bt[a * 6 + r];
-                s.x = fmaf(m, d[r].x, s.x);
-                s.y = fmaf(m, d[r].y, s.y);
-                s.z = fmaf(m, d[r].z, s.z);
-                s.w = fmaf(m, d[r].w, s.w);
-            }
+            for (int r = 0; r < NW; ++r) s = __builtin_elementwise_fma((VT)(bt[a * NW + r]), d[r], s);
             tmp[a][j] = s;
         }
     }
     // V[a][b] = sum_j tmp[a][j] BT[b][j]
-    float *dst = p.y + (long)n * p.ysn + (long)tile * p.ysx + c4 * 4;
+    float *dst = p.y + (long)n * p.ysn + (long)tile * p.ysx + cv * VW;
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < NW; ++a)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < NW; ++b) {
+            VT s = (VT)(0.f);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float m = bt[b * 6 + j];
-                s.x = fmaf(m, tmp[a][j].x, s.x);
-                s.y = fmaf(m, tmp[a][j].y, s.y);
-                s.z = fmaf(m, tmp[a][j].z, s.z);
-                s.w = fmaf(m, tmp[a][j].w, s.w);
-            }
-            *(float4 *)(dst + (long)(a * 6 + b) * p.ysy) = s;
+            for (int j = 0; j < NW; ++j) s = __builtin_elementwise_fma((VT)(bt[b * NW + j]), tmp[a][j], s);
+            *(VT *)(dst + (long)(a * NW + b) * p.ysy) = s;
         }
 }
 
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream)
 {
-    const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
-    hipLaunchKernelGGL(hvn_wino_in, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    if (a.m == 2) {
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
+        hipLaunchKernelGGL((hvn_wino_in<2, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else {
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
+        hipLaunchKernelGGL((hvn_wino_in<4, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+template <int MO, int VW>
 __global__ __launch_bounds__(256) void hvn_wino_out(const WinoArgs p, long total)
 {
+    constexpr int NW = MO + 4;
+    typedef typename WVec<VW>::T VT;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c4n = p.C >> 2;
+    const int c4n = p.C / VW;
     const int c4 = (int)(i % c4n);
     long t = i / c4n;
     const int T1 = p.ty * p.tx;
     const int tile = (int)(t % T1);
     const int n = (int)(t / T1);
     const int tyi = tile / p.tx, txi = tile - tyi * p.tx;
-    float at[12];
+    float at[MO * NW];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) at[k] = p.mat[k];
-    const float *src = p.x + (long)n * p.xsn + (long)tile * p.xsx + c4 * 4;
-    // tmp[pq][b] = sum_a AT[pq][a] M[a][b]
-    float4 tmp[2][6];
+    for (int k = 0; k < MO * NW; ++k) at[k] = p.mat[k];
+    const float *src = p.x + (long)n * p.xsn + (long)tile * p.xsx + c4 * VW;
+    // tmp[q][b] = sum_a AT[q][a] M[a][b]
+    VT tmp[MO][NW];
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        float4 m[6];
+    for (int b = 0; b < NW; ++b) {
+        VT m[NW];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) m[a] = *(const float4 *)(src + (long)(a * 6 + b) * p.xsy);
+        for (int a = 0; a < NW; ++a) m[a] = *(const VT *)(src + (long)(a * NW + b) * p.xsy);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < MO; ++q) {
+            VT s = (VT)(0.f);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const float w = at[q * 6 + a];
-                s.x = fmaf(w, m[a].x, s.x);
-                s.y = fmaf(w, m[a].y, s.y);
-                s.z = fmaf(w, m[a].z, s.z);
-                s.w = fmaf(w, m[a].w, s.w);
-            }
+            for (int a = 0; a < NW; ++a) s = __builtin_elementwise_fma((VT)(at[q * NW + a]), m[a], s);
             tmp[q][b] = s;
         }
     }
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = *(const float4 *)(p.bias + c4 * 4);
+    VT bias = (VT)(0.f);
+    if (p.bias) bias = *(const VT *)(p.bias + c4 * VW);
     const float lo = p.relu ? 0.f : -__builtin_inff();
-    float *dst = p.y + (long)n * p.ysn + c4 * 4;
+    float *dst = p.y + (long)n * p.ysn + c4 * VW;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)        // output row
+    for (int q = 0; q < MO; ++q)        // output row
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {  // output column
-            float4 s = bias;
+        for (int r = 0; r < MO; ++r) {  // output column
+            VT s = bias;
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const float w = at[r * 6 + b];
-                s.x = fmaf(w, tmp[q][b].x, s.x);
-                s.y = fmaf(w, tmp[q][b].y, s.y);
-                s.z = fmaf(w, tmp[q][b].z, s.z);
-                s.w = fmaf(w, tmp[q][b].w, s.w);
-            }
-            s.x = fmaxf(s.x, lo);
-            s.y = fmaxf(s.y, lo);
-            s.z = fmaxf(s.z, lo);
-            s.w = fmaxf(s.w, lo);
-            *(float4 *)(dst + (long)(2 * tyi + q) * p.ysy + (long)(2 * txi + r) * p.ysx) = s;
+            for (int b = 0; b < NW; ++b) s = __builtin_elementwise_fma((VT)(at[r * NW + b]), tmp[q][b], s);
+            s = __builtin_elementwise_max(s, (VT)(lo));
+            const int oy = MO * tyi + q, ox = MO * txi + r;
+            if (oy < p.H && ox < p.W)   // partial last tile when the output extent is not a multiple of m
+                *(VT *)(dst + (long)oy * p.ysy + (long)ox * p.ysx) = s;
         }
 }
 
 int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream)
 {
-    const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
-    hipLaunchKernelGGL(hvn_wino_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    if (a.m == 2) {
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
+        hipLaunchKernelGGL((hvn_wino_out<2, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else {
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
+        hipLaunchKernelGGL((hvn_wino_out<4, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

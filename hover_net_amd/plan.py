@@ -222,44 +222,46 @@ class Plan:
                 op.extra["reads"] = [x2.buf]
         return self.add(op)
 
-    def conv_winograd(self, name, x, y, wt, *, pad=(0, 0), bn=None, relu=0, share_in=False):
-        """5x5 stride-1 conv as Winograd F(2x2,5x5): WINO_IN (shared between convs that read the same view with
-        the same padding) -> batched CONV over the 36 transform positions -> WINO_OUT (+bias, ReLU)."""
+    def conv_winograd(self, name, x, y, wt, *, pad=(0, 0), bn=None, relu=0, share_in=False, m=4):
+        """5x5 stride-1 conv as Winograd F(m x m, 5x5): WINO_IN (shared between convs that read the same view with
+        the same padding) -> batched CONV over the (m+4)^2 transform positions -> WINO_OUT (+bias, ReLU).
+        Output extents that are not a multiple of m get a partial last tile (its surplus outputs are not written)."""
         from . import winograd as WG
 
         cout, cin, kh, kw = wt.shape
-        assert (kh, kw) == (5, 5) and y.h % 2 == 0 and y.w % 2 == 0 and x.c == cin and y.c == cout
+        assert (kh, kw) == (5, 5) and m in (2, 4) and x.c == cin and y.c == cout
         assert y.h == x.h + pad[0] + pad[1] - 4
+        at, _g, bt = WG.MATS[m]
+        n2 = (m + 4) ** 2
         s = b = None
         if bn is not None:
             s, b = bn
             wt = wt * s[:, None, None, None]
-        ty, tx = y.h // 2, y.w // 2
+        ty, tx = -(-y.h // m), -(-y.w // m)
         t1 = ty * tx
-        key = (id(x.buf), x.y0, x.x0, x.h, x.w, x.c0, x.c, pad[0])
+        key = (id(x.buf), x.y0, x.x0, x.h, x.w, x.c0, x.c, pad[0], m)
         cache = self.__dict__.setdefault("_wino_in", {})
         if key not in cache:
-            vbuf = self.buf(name + ".V", 36, t1, cin)
-            op = Op(OP_WINO_IN, name + ".wino_in", x=x, y=View(vbuf), w=np.ascontiguousarray(WG.BT, np.float32),
-                    pad_t=pad[0], pad_l=pad[0], extra={"tiles": (ty, tx), "shared": share_in})
+            vbuf = self.buf(name + ".V", n2, t1, cin)
+            op = Op(OP_WINO_IN, name + ".wino_in", x=x, y=View(vbuf), w=np.ascontiguousarray(bt, np.float32),
+                    pad_t=pad[0], pad_l=pad[0], extra={"tiles": (ty, tx), "shared": share_in, "m": m})
             self.add(op)
             cache[key] = vbuf
         vbuf = cache[key]
-        mbuf = self.buf(name + ".M", 36, t1, cout)
-        u = WG.transform_weights(wt)                                          # [36, cout, cin] float64
+        mbuf = self.buf(name + ".M", n2, t1, cout)
+        u = WG.transform_weights(wt, m)                                       # [n2, cout, cin] float64
         tn = _tile_n(cout)
         cout_pad = (cout + tn - 1) // tn * tn
-        packed = np.zeros((36, cout_pad, cin // 32, 1, 32), np.float32)
-        packed[:, :cout] = u.reshape(36, cout, cin // 32, 1, 32)
+        packed = np.zeros((n2, cout_pad, cin // 32, 1, 32), np.float32)
+        packed[:, :cout] = u.reshape(n2, cout, cin // 32, 1, 32)
         g = Op(OP_CONV, name + ".wino_gemm", x=View(vbuf, 0, 0, 1, t1), y=View(mbuf, 0, 0, 1, t1), w=packed, cout=cout, tile_n=tn)
-        g.extra.update(nbatch=36, batch_strides=(t1 * cin, cout_pad * cin, t1 * cout), cin_real=cin, groups=1,
-                       algo_flops=2.0 * y.h * y.w * cout * cin * 25, exec_flops=2.0 * 36 * t1 * cout * cin)
+        g.extra.update(nbatch=n2, batch_strides=(t1 * cin, cout_pad * cin, t1 * cout), cin_real=cin, groups=1,
+                       algo_flops=2.0 * y.h * y.w * cout * cin * 25, exec_flops=2.0 * n2 * t1 * cout * cin)
         self.add(g)
-        # the batched launch touches all 36 rows of V and M
-        for bb in (vbuf, mbuf):
+        for bb in (vbuf, mbuf):   # the batched launch touches every row of V and M
             bb.last = max(bb.last, len(self.ops) - 1)
-        o = Op(OP_WINO_OUT, name + ".wino_out", x=View(mbuf), y=y, w=np.ascontiguousarray(WG.AT, np.float32),
-               bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx)})
+        o = Op(OP_WINO_OUT, name + ".wino_out", x=View(mbuf), y=y, w=np.ascontiguousarray(at, np.float32),
+               bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m})
         return self.add(o)
 
     # -- memory planning --------------------------------------------------------
@@ -287,10 +289,12 @@ class Plan:
 
 def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None):
     """sd: reference-format state_dict (torch tensors or numpy arrays).
-    winograd: run the 5x5 decoder convs as F(2x2,5x5) (default on; env HVN_WINOGRAD=0 turns it off)."""
+    winograd: output tile m (2 or 4) of the Winograd F(m x m, 5x5) form of the 5x5 decoder convs; 0 / False = direct
+    convolution; default 4 (env HVN_WINOGRAD)."""
     import os
     if winograd is None:
-        winograd = os.environ.get("HVN_WINOGRAD", "1") != "0"
+        winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
+    wino_m = 4 if winograd is True else int(winograd)
     P = Plan(mode, nr_types)
     g = P.geo
     k = g["k"]
@@ -356,7 +360,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
             cat = View(P.buf(p + "cat", cat_sz, cat_sz, ctot))
             if k == 5 and winograd:
                 # the u3 input is the same for every branch: its transform runs once, before the branch lanes fork
-                P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"))
+                P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"), m=wino_m)
             else:
                 P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
             c = cmid
@@ -377,7 +381,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         u1 = View(P.buf(pb + "u1", g["out"], g["out"], 64))
         if k == 5 and winograd:
             P.conv_winograd(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
-                            bn=BN(pb + "u0.bn"), relu=1)
+                            bn=BN(pb + "u0.bn"), relu=1, m=wino_m)
         else:
             P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
                    bn=BN(pb + "u0.bn"), relu=1)

@@ -1,7 +1,7 @@
-"""Winograd / Toom-Cook F(2x2, 5x5) transform matrices (exact rationals -> float64).
+"""Winograd / Toom-Cook F(m x m, 5x5) transform matrices, m in {2, 4} (exact rationals -> float64).
 
-y = A^T [ (G g G^T) .* (B^T d B) ] A computes a 2x2 block of a 5x5 *correlation* from a 6x6 input block with
-36 multiplications instead of 100.  Derived from the polynomial evaluation points (0, 1, -1, 2, -1/2, inf) by
+y = A^T [ (G g G^T) .* (B^T d B) ] A computes an m x m block of a 5x5 *correlation* from an (m+4)^2 input block:
+36 multiplications per 2x2 outputs (9 per output) or 64 per 4x4 outputs (4 per output) instead of 25.  Derived from the polynomial evaluation points (0, 1, -1, 2, -1/2, inf) by
 transposing Toom-Cook multiplication: A^T = E_2^T, G = E_5, B^T = (V^-1)^T with E_k the evaluation matrix of
 degree-(k-1) polynomials at the points and V = E_6.  The point set was picked for fp32 accuracy
 (1024-channel reduction: 4e-6 abs error vs 1.4e-5 for (0, +-1, +-2)).
@@ -10,10 +10,12 @@ from fractions import Fraction as Fr
 
 import numpy as np
 
-POINTS = (Fr(0), Fr(1), Fr(-1), Fr(2), Fr(-1, 2))
+POINTS = {2: (Fr(0), Fr(1), Fr(-1), Fr(2), Fr(-1, 2)),
+          4: (Fr(0), Fr(1), Fr(-1), Fr(2), Fr(-1, 2), Fr(1, 2), Fr(-2))}
 
 
-def toom_cook(m, r, pts=POINTS):
+def toom_cook(m, r, pts=None):
+    pts = POINTS[m] if pts is None else pts
     n = m + r - 1
     assert len(pts) == n - 1
 
@@ -40,10 +42,11 @@ def toom_cook(m, r, pts=POINTS):
     return f(at), f(ev(r)), f(bt)
 
 
-AT, G, BT = toom_cook(2, 5)     # (2,6), (6,5), (6,6)
+MATS = {m: toom_cook(m, 5) for m in (2, 4)}   # m -> (A^T (m, m+4), G (m+4, 5), B^T (m+4, m+4))
 
 
-def transform_weights(wt):
-    """[cout, cin, 5, 5] float64 -> U [36, cout, cin] float64 with U[a*6+b] = (G g G^T)[a][b]."""
-    u = np.einsum("ar,ocrs,bs->aboc", G, wt, G)
-    return u.reshape(36, wt.shape[0], wt.shape[1])
+def transform_weights(wt, m):
+    """[cout, cin, 5, 5] float64 -> U [(m+4)^2, cout, cin] float64 with U[a*n+b] = (G g G^T)[a][b]."""
+    g = MATS[m][1]
+    u = np.einsum("ar,ocrs,bs->aboc", g, wt, g)
+    return u.reshape((m + 4) ** 2, wt.shape[0], wt.shape[1])

@@ -55,12 +55,13 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           (net_utils.py:229-230) into its first conv3, the weight rows being [x.c | x2.c] wide,
  *           epi = (+bias) (relu) (+res) (relu(.*post_scale+post_shift) if post_scale)
  *           nbatch > 1: `nbatch` independent problems in one launch; problem b reads x.base + b*batch_stride[0],
- *           w + b*batch_stride[1] and writes y.base + b*batch_stride[2] (elements) -- the 36 transform-domain
+ *           w + b*batch_stride[1] and writes y.base + b*batch_stride[2] (elements) -- the n*n transform-domain
  *           products of a Winograd convolution,
- *   WINO_IN  Winograd F(2x2,5x5) input transform of a 5x5 stride-1 conv (net_desc.py:45,52,59 conva):
- *           x = input view (zero padding pad_t/pad_l), y = V as [36][tiles][c] per sample (y.h = 36, y.w = tiles),
- *           kh x kw = tile grid, w = B^T (6x6),
- *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [36][tiles][cout] per sample, w = A^T (2x6), kh x kw = tile grid,
+ *   WINO_IN  Winograd F(m x m, 5x5) input transform of a 5x5 stride-1 conv (net_desc.py:45,52,59 conva), m = 2 or 4,
+ *           n = m + 4: x = input view (zero padding pad_t/pad_l), y = V as [n*n][tiles][c] per sample (y.h = n*n = 36
+ *           or 64 selects m, y.w = tiles), kh x kw = tile grid, w = B^T (n x n),
+ *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [n*n][tiles][cout] per sample, w = A^T (m x n), kh x kw = tile grid
+ *           covering y (a partial last tile's surplus outputs are dropped),
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
  *   PREDMAP y.base = [n][h][w][3|4] = [argmax(tp)?, softmax(np)[1], hv0, hv1]

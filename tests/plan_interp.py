@@ -88,30 +88,34 @@ def predmap_ref(logits, branches):
 
 
 def wino_in_ref(op, x):
-    """x [N,h,w,c] -> V [N,36,T,c] with T = ty*tx tiles (row-major)."""
+    """x [N,h,w,c] -> V [N,n*n,T,c] with T = ty*tx tiles (row-major), n = m + 4."""
     ty, tx = op.extra["tiles"]
-    bt = torch.from_numpy(op.w)                       # [6,6]
+    m = op.extra["m"]
+    n_ = m + 4
+    bt = torch.from_numpy(op.w)                       # [n,n]
     pt = op.pad_t
-    need_h, need_w = 2 * ty + 4, 2 * tx + 4
+    need_h, need_w = m * ty + 4, m * tx + 4
     xp = F.pad(x.permute(0, 3, 1, 2), (pt, need_w - x.shape[2] - pt, pt, need_h - x.shape[1] - pt))
-    tiles = xp.unfold(2, 6, 2).unfold(3, 6, 2)        # [N,c,ty,tx,6,6]
+    tiles = xp.unfold(2, n_, m).unfold(3, n_, m)      # [N,c,ty,tx,n,n]
     v = torch.einsum("ai,nctsij,bj->nabtsc", bt, tiles, bt)
-    return v.reshape(x.shape[0], 36, ty * tx, x.shape[3])
+    return v.reshape(x.shape[0], n_ * n_, ty * tx, x.shape[3])
 
 
 def wino_gemm_ref(op, v):
-    """v [N,36,T,cin] -> m [N,36,T,cout]."""
-    w = torch.from_numpy(op.w[:, :op.cout]).reshape(36, op.cout, -1)   # [36,cout,cin]
+    """v [N,n2,T,cin] -> m [N,n2,T,cout]."""
+    w = torch.from_numpy(op.w[:, :op.cout]).reshape(op.w.shape[0], op.cout, -1)   # [n2,cout,cin]
     return torch.einsum("nxtc,xoc->nxto", v, w)
 
 
-def wino_out_ref(op, m):
-    """m [N,36,T,cout] -> y [N,2ty,2tx,cout]."""
+def wino_out_ref(op, mm):
+    """mm [N,n2,T,cout] -> y [N,ho,wo,cout] (partial last tiles cropped)."""
     ty, tx = op.extra["tiles"]
-    at = torch.from_numpy(op.w)                        # [2,6]
-    n, _, _, co = m.shape
-    mm = m.reshape(n, 6, 6, ty, tx, co)
-    y = torch.einsum("pa,nabtsc,qb->ntpsqc", at, mm, at).reshape(n, 2 * ty, 2 * tx, co)
+    m = op.extra["m"]
+    n_ = m + 4
+    at = torch.from_numpy(op.w)                        # [m,n]
+    nb, _, _, co = mm.shape
+    mm = mm.reshape(nb, n_, n_, ty, tx, co)
+    y = torch.einsum("pa,nabtsc,qb->ntpsqc", at, mm, at).reshape(nb, m * ty, m * tx, co)[:, :op.y.h, :op.y.w]
     if op.bias is not None:
         y = y + torch.from_numpy(op.bias)
     if op.relu:
