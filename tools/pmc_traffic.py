@@ -5,8 +5,13 @@ Sums the counters over the hvn_conv_igemm_f32 dispatches of the LAST plan execut
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x.
 usage: python tools/pmc_traffic.py <fetch.db> <write.db> <out.json>"""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hover_net_amd.plan import build_plan  # noqa: E402
+from hover_net_amd.synth import synth_state_dict  # noqa: E402
 
 
 def total(db, counter, n_last):
@@ -17,7 +22,7 @@ def total(db, counter, n_last):
     return sum(r[1] for r in rows), len(rows)
 
 
-n = 140
+n = sum(1 for o in build_plan(synth_state_dict("original", 5, seed=0), "original", 5).ops if o.kind == 2)   # conv launches / step
 fetch_kb, nf = total(sys.argv[1], "FETCH_SIZE", n)
 write_kb, nw = total(sys.argv[2], "WRITE_SIZE", n)
 out = {"launches": nf, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
