@@ -120,3 +120,18 @@ def synth_state_dict(mode="original", nr_types=None, seed=0, as_torch=True):
 
         sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
     return sd
+
+
+def synth_train_batch(n, mode="original", nr_types=None, seed=0):
+    """Synthetic training batch in the reference's loader format (dataloader/train_loader.py:109-137 feeds
+    run_desc.train_step): img uint8 [n,S,S,3], np_map int64 [n,h,w] in {0,1}, hv_map float32 [n,h,w,2] in [-1,1],
+    tp_map int64 [n,h,w] in [0,nr_types) (only with nr_types).  Nuclei are painted ellipses (synth_pred_maps)."""
+    size, out = (270, 80) if mode == "original" else (256, 164)
+    pm, inst = synth_pred_maps(n, out, out, nr_types, seed=seed + 17, noise=0.0)
+    c0 = 0 if nr_types is None else 1
+    batch = {"img": synth_tiles(n, size, seed=seed),
+             "np_map": (inst > 0).astype(np.int64),
+             "hv_map": np.ascontiguousarray(np.clip(pm[..., c0 + 1:c0 + 3], -1.0, 1.0), np.float32)}
+    if nr_types is not None:
+        batch["tp_map"] = np.clip(pm[..., 0].round().astype(np.int64), 0, nr_types - 1) * (inst > 0)
+    return batch
