@@ -109,21 +109,21 @@ def mse_loss(true, pred):
     return (d * d).mean()
 
 
-def sobel5():
-    r = torch.arange(-2, 3, dtype=torch.float32)
+def sobel5(dtype=torch.float32):
+    r = torch.arange(-2, 3, dtype=dtype)
     h, v = torch.meshgrid(r, r, indexing="ij")                                   # utils.py:135 (old default = 'ij')
     return h / (h * h + v * v + 1.0e-15), v / (h * h + v * v + 1.0e-15)
 
 
 def msge_loss(true, pred, focus):
-    kh, kv = sobel5()
+    kh, kv = sobel5(pred.dtype)
 
     def grad_hv(hv):
         dh = F.conv2d(hv[..., 0].unsqueeze(1), kh.view(1, 1, 5, 5), padding=2)
         dv = F.conv2d(hv[..., 1].unsqueeze(1), kv.view(1, 1, 5, 5), padding=2)
         return torch.cat([dh, dv], 1).permute(0, 2, 3, 1)
 
-    focus = torch.stack([focus.float(), focus.float()], -1)
+    focus = torch.stack([focus, focus], -1).type(pred.dtype)
     d = grad_hv(pred) - grad_hv(true)
     return (focus * (d * d)).sum() / (focus.sum() + 1.0e-8)
 
@@ -131,14 +131,15 @@ def msge_loss(true, pred, focus):
 LOSS_OPTS = {"np": ("bce", "dice"), "hv": ("mse", "msge"), "tp": ("bce", "dice")}       # opt.py:47-51, weights 1
 
 
-def loss_terms(logits, batch, nr_types):
+def loss_terms(logits, batch, nr_types, dtype=torch.float32):
     """logits: dict of NCHW tensors; batch: dict of tensors (np_map int64, hv_map float32, tp_map int64).
-    -> (total loss, dict of named terms) exactly as run_desc.py:40-82 composes them."""
+    -> (total loss, dict of named terms) exactly as run_desc.py:40-82 composes them.  dtype=float64 gives the
+    high-precision reference used to measure the fp32 noise floor of the gradients."""
     true_np = batch["np_map"].type(torch.int64)
-    onehot_np = F.one_hot(true_np, 2).type(torch.float32)
-    true = {"np": onehot_np, "hv": batch["hv_map"].type(torch.float32)}
+    onehot_np = F.one_hot(true_np, 2).type(dtype)
+    true = {"np": onehot_np, "hv": batch["hv_map"].type(dtype)}
     if nr_types is not None:
-        true["tp"] = F.one_hot(batch["tp_map"].type(torch.int64), nr_types).type(torch.float32)
+        true["tp"] = F.one_hot(batch["tp_map"].type(torch.int64), nr_types).type(dtype)
     pred = {k: v.permute(0, 2, 3, 1).contiguous() for k, v in logits.items()}
     pred["np"] = F.softmax(pred["np"], -1)
     if "tp" in pred:
@@ -154,15 +155,16 @@ def loss_terms(logits, batch, nr_types):
     return total, terms
 
 
-def train_step(sd, batch, mode="original", nr_types=None, freeze=False):
+def train_step(sd, batch, mode="original", nr_types=None, freeze=False, dtype=torch.float32):
     """sd: reference-format state_dict (float32 CPU tensors); batch: numpy/tensor dict (synth_train_batch).
     -> dict(loss, terms{name: float}, grads{key: tensor | None}, new_stats{key: tensor}, logits{...})."""
+    sd = {k: v.type(dtype) if v.is_floating_point() else v for k, v in sd.items()}
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k and "unpool" not in k else v)
           for k, v in sd.items()}
     batch = {k: torch.as_tensor(v) for k, v in batch.items()}
-    imgs = batch["img"].type(torch.float32).permute(0, 3, 1, 2).contiguous()
+    imgs = batch["img"].type(dtype).permute(0, 3, 1, 2).contiguous()
     logits, ns = forward_train(sd, imgs, mode, freeze)
-    total, terms = loss_terms(logits, batch, nr_types)
+    total, terms = loss_terms(logits, batch, nr_types, dtype)
     total.backward()
     grads = {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.requires_grad}
     return {"loss": float(total.detach()), "terms": {k: float(v.detach()) for k, v in terms.items()}, "grads": grads, "new_stats": ns,
