@@ -84,7 +84,7 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.w = op->w; a.bias = op->bias;
         a.y = (float *)op->y.base;
         a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
-        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.pad = op->pad_t;
+        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.pad = op->pad_t; a.relu = op->relu;
         if (op->kh != 7 || op->kw != 7 || op->x.c != 3 || op->y.c != 64 || !op->w || !op->bias)
             return fail(HVN_E_ARG, "conv0: expects 7x7x3->64 with bias%s", "");
         if (!aligned16(a.y) || (a.ysx & 3) || (a.ysy & 3) || (a.ysn & 3)) return fail(HVN_E_ARG, "conv0: output view not 16-byte aligned%s", "");
@@ -200,6 +200,10 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         return fail(HVN_E_ARG, "unknown op kind %s%ld", "", op->kind);
     }
 }
+
+}  // extern "C"
+int hvn_internal_run_one(const hvn_op *op, int batch, hipStream_t s) { return run_one(op, batch, s); }
+extern "C" {
 
 int hvn_run_op(const hvn_op *op, int batch, void *stream)
 {

@@ -37,6 +37,7 @@ struct Conv0Args {
     float *y;
     long ysn, ysy, ysx;
     int N, Ho, Wo, pad;
+    int relu;             // 1: ReLU after the bias (inference, BN folded); 0: raw conv output (training)
 };
 int hvn_launch_conv0(const Conv0Args &a, hipStream_t stream);
 
@@ -81,3 +82,99 @@ struct WinoArgs {
 };
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream);
 int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream);
+
+// ---- training step (hvn_train.hip) -------------------------------------------------------------
+struct PackArgs {
+    const float *src;     // parameter layout [cout][kh*kw][cin_g]
+    float *dst;
+    int cout, cin_g, groups, taps;
+    int mode;             // 0 forward [lead_pad][cin/32][taps][32]; 1 dgrad [lead_pad][cout/32][taps][32] (transposed, taps flipped); 2 conv0
+    int lead_pad;         // padded leading dimension (multiple of the conv kernel's column tile)
+};
+int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream);
+
+struct WgradArgs {
+    const float *x;       // conv input view
+    long xsn, xsy, xsx;
+    int H, W, Cin;
+    const float *dy;      // output-gradient view
+    long dsn, dsy, dsx;
+    int Ho, Wo, Cout;
+    float *dw;            // [Cout][KH*KW][Cin_g], accumulated with atomics
+    int N, KH, KW, stride, pad_t, pad_l, groups, Cin_g;
+    int tiles_m, tiles_n;
+    unsigned rows_per_split;
+};
+int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream);
+
+struct BnArgs {
+    const float *z;       // conv output (pre-normalisation)
+    long zsn, zsy, zsx;
+    const float *a;       // backward: the forward output relu(bn(z))
+    float *a_out;         // forward: where it is written
+    long asn, asy, asx;
+    const float *da;      // backward: gradient of a
+    long gsn, gsy, gsx;
+    float *dz;            // backward: gradient of z (accumulated), may be null
+    long dsn, dsy, dsx;
+    double *ws;           // [2*C] zeroed reduction workspace (handed back zeroed)
+    float *save;          // [4*C] scale, shift, mean, rstd
+    float *coef;          // [3*C] backward coefficients
+    const float *gamma, *beta;
+    float *dgamma, *dbeta, *running_mean, *running_var;
+    int N, H, W, C, lq;
+    float eps, momentum;
+};
+int hvn_launch_bn_forward(BnArgs a, hipStream_t stream);
+int hvn_launch_bn_backward(BnArgs a, hipStream_t stream);
+
+struct UpAddBwdArgs {
+    const float *dy;
+    long ysn, ysy, ysx;
+    float *dlo;           // may be null
+    long lsn, lsy, lsx;
+    float *dskip;         // may be null
+    long ssn, ssy, ssx;
+    int N, H, W, C;       // extent of dy
+};
+int hvn_launch_upadd_bwd(const UpAddBwdArgs &a, hipStream_t stream);
+
+struct HeadBwdArgs {
+    const float *x;       // head input a [N][H][W][64] view
+    long xsn, xsy, xsx;
+    float *dx;            // its gradient (accumulated)
+    long dsn, dsy, dsx;
+    const float *dl;      // logit gradient NCHW [N][Cout][H][W]
+    const float *w;       // [Cout][64]
+    float *dw, *db;
+    int N, H, W, Cout;
+};
+int hvn_launch_head_bwd(const HeadBwdArgs &a, hipStream_t stream);
+
+struct Conv0WgradArgs {
+    const uint8_t *img;
+    long isn, isy, isx;
+    int H, W;
+    const float *dy;
+    long ysn, ysy, ysx;
+    float *dw;            // [64][7][7][3]
+    int N, Ho, Wo, pad;
+};
+int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream);
+
+struct LossArgs {
+    const float *l_np, *l_hv, *l_tp;   // NCHW logits
+    const int32_t *t_np, *t_tp;        // [N][H][W]
+    const float *t_hv;                 // [N][H][W][2]
+    float *d_np, *d_hv, *d_tp;         // logit gradients (stage 1)
+    double *sums;                      // [64]
+    float *gws;                        // [N][H][W][2] focus-weighted Sobel differences
+    int N, H, W, T;
+    double m_total;
+};
+int hvn_launch_loss(const LossArgs &a, int stage, hipStream_t stream);
+int hvn_launch_adam(float *w, const float *g, float *m, float *v, long n, float b1, float b2, float eps, float step_size,
+                    float inv_bc2_sqrt, hipStream_t stream);
+
+struct hvn_op;
+int hvn_internal_run_one(const hvn_op *op, int batch, hipStream_t s);

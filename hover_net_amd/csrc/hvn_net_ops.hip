@@ -46,11 +46,12 @@ __global__ __launch_bounds__(256) void hvn_conv0(const Conv0Args p)
         }
     }
     const int oy = oy0 + ty, ox = ox0 + tx;
+    const float lo = p.relu ? 0.f : -__builtin_inff();
     if (oy < p.Ho && ox < p.Wo) {
         float *y = p.y + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx;
 #pragma unroll
         for (int c = 0; c < 64; c += 4)
-            *(float4 *)(y + c) = make_float4(fmaxf(acc[c], 0.f), fmaxf(acc[c + 1], 0.f), fmaxf(acc[c + 2], 0.f), fmaxf(acc[c + 3], 0.f));
+            *(float4 *)(y + c) = make_float4(fmaxf(acc[c], lo), fmaxf(acc[c + 1], lo), fmaxf(acc[c + 2], lo), fmaxf(acc[c + 3], lo));
     }
 }
 

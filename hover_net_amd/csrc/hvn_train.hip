@@ -1,0 +1,884 @@
+// hvn_train.hip -- kernels of the training step (SURVEY 8a T1/T2:
+// /root/reference/models/hovernet/run_desc.py:12-109 train_step, utils.py:54-172 losses,
+// torch BatchNorm2d in train() mode, torch.optim.Adam as configured by opt.py:38-44).
+//
+// The forward convolutions and the data gradients (dgrad = stride-1 convolution of the -- possibly dilated --
+// output gradient with flipped, transposed weights) run on hvn_conv_igemm_f32 (hvn_conv.hip); this file adds
+//   * hvn_conv_wgrad_f32   weight gradient as an fp32-MFMA GEMM over the pixel dimension (split-K, atomics)
+//   * weight (re)packing from the parameter layout [cout][kh*kw][cin_g] to the conv kernel's slab-major layout
+//     (forward) and to its transposed / tap-flipped form (dgrad), every step, on the GPU
+//   * BatchNorm(train)+ReLU forward (batch statistics in double, running-stat update) and backward
+//   * nearest-2x-upsample + skip-add backward, 1x1 logit head backward, conv0 weight gradient
+//   * the four loss terms, forward partial sums and logit gradients (two stages around an optional all-reduce)
+//   * Adam over one flat parameter slab
+// All activations are NHWC fp32 strided views; every gradient destination is ACCUMULATED into (the engine zeroes
+// the gradient arena once per step), see hover_net_amd/train_plan.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvn_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static inline int launch_ok() { return hipGetLastError() == hipSuccess ? 0 : -2; }
+
+// =========================================================================================
+// weight packing
+// =========================================================================================
+__global__ __launch_bounds__(256) void hvn_pack_w(const PackArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int taps = p.taps;
+    if (p.mode == 2) {  // conv0: [64][7][7][3] -> [7][7][3][64] * (1/255)
+        const int co = (int)(i % 64);
+        const int t = (int)(i / 64);  // tap*3 + ch
+        p.dst[i] = p.src[(long)co * (taps * 3) + t] * (1.0f / 255.0f);
+        return;
+    }
+    const int l = (int)(i & 31);
+    long r = i >> 5;
+    const int tap = (int)(r % taps);
+    r /= taps;
+    const int cin = p.cin_g * p.groups;
+    const int og = p.cout / p.groups;
+    float v = 0.f;
+    if (p.mode == 0) {  // forward: dst[co][slab][tap][l], ci = slab*32 + l
+        const int slabs = cin / 32;
+        const int slab = (int)(r % slabs);
+        const int co = (int)(r / slabs);
+        const int ci = slab * 32 + l;
+        if (co < p.cout) {
+            const int g = co / og;
+            const int cg = ci - g * p.cin_g;
+            if (cg >= 0 && cg < p.cin_g) v = p.src[((long)co * taps + tap) * p.cin_g + cg];
+        }
+    } else {  // dgrad: dst[ci][slab][tap'][l], co = slab*32 + l, source tap = taps-1-tap'
+        const int slabs = p.cout / 32;
+        const int slab = (int)(r % slabs);
+        const int ci = (int)(r / slabs);
+        const int co = slab * 32 + l;
+        if (ci < cin) {
+            const int g = co / og;
+            const int cg = ci - g * p.cin_g;
+            if (cg >= 0 && cg < p.cin_g) v = p.src[((long)co * taps + (taps - 1 - tap)) * p.cin_g + cg];
+        }
+    }
+    p.dst[i] = v;
+}
+
+int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream)
+{
+    long total;
+    if (a.mode == 2)
+        total = 64L * a.taps * 3;
+    else if (a.mode == 0)
+        total = (long)a.lead_pad * (a.cin_g * a.groups) * a.taps;
+    else
+        total = (long)a.lead_pad * a.cout * a.taps;
+    hipLaunchKernelGGL(hvn_pack_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return launch_ok();
+}
+
+// =========================================================================================
+// weight gradient: dW[co][tap][ci] = sum_{n,oy,ox} dY[n,oy,ox,co] * X[n, oy*s+r-pt, ox*s+q-pl, ci]
+// GEMM with M = cout (A = dY), N = cin (B = X shifted by the tap), K = pixels.  Both operands are K-major in
+// memory (NHWC: a pixel's channels are contiguous), so a k-step of 32 pixels is staged [pixel][channel] with
+// 16-byte loads/stores and the MFMA fragments are read straight out of that layout: lane l of
+// v_mfma_f32_32x32x2_f32 needs A[m = l&31][k = l>>5]; reading LDS[k0 + (l>>5)][col0 + (l&31)*MB + i] for the
+// wave's i-th 32-wide block means block i owns the columns congruent to i (mod MB) -- an arbitrary but fixed
+// relabelling of the M index that the epilogue undoes.  One ds_read_b64 (MB = 2) feeds two MFMA blocks.
+// Grid: x = (tap, cin tile, cout tile), y = K split; partial products are combined with fp32 atomics.
+// =========================================================================================
+template <int B, int MB>
+struct WgPitch {
+    static constexpr int value = (MB == 2) ? (B + 8) : ((B + 63) / 64 * 64 + 32);
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
+{
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MBA = WM / 32, MBB = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && (MBA == 1 || MBA == 2) && (MBB == 1 || MBB == 2), "tile shape");
+    constexpr int PITCH_A = WgPitch<BM, MBA>::value, PITCH_B = WgPitch<BN, MBB>::value;
+    constexpr int RPA = 1024 / BM, RPB = 1024 / BN;  // rows staged per pass (256 threads x float4)
+    constexpr int PA = 32 / RPA, PB = 32 / RPB;      // passes per 32-row k-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                     // [2][32][PITCH_A]
+    float *Bs = smem + 2 * 32 * PITCH_A;  // [2][32][PITCH_B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int bid = blockIdx.x;
+    const int tm = bid % p.tiles_m;
+    bid /= p.tiles_m;
+    const int tn = bid % p.tiles_n;
+    const int tap = bid / p.tiles_n;
+    const int tr = tap / p.KW, tq = tap - tr * p.KW;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const unsigned R = (unsigned)p.N * p.Ho * p.Wo;
+    const unsigned r_begin = blockIdx.y * p.rows_per_split;
+    const unsigned r_end = min(R, r_begin + p.rows_per_split);
+    if (r_begin >= r_end) return;
+    const int steps = (int)((r_end - r_begin + 31) / 32);
+
+    // per-thread staging coordinates: row (n, oy, ox) advanced incrementally by 32 per k-step
+    const int a_c4 = tid % (BM / 4), a_r = tid / (BM / 4);
+    const int b_c4 = tid % (BN / 4), b_r = tid / (BN / 4);
+    int an[PA], ay[PA], ax[PA], bn_[PB], by[PB], bx[PB];
+    unsigned arow[PA], brow[PB];
+    const unsigned HoWo = (unsigned)p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const unsigned r = r_begin + a_r + RPA * j;
+        arow[j] = r;
+        an[j] = r / HoWo;
+        const unsigned rem = r - an[j] * HoWo;
+        ay[j] = rem / p.Wo;
+        ax[j] = rem - ay[j] * p.Wo;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const unsigned r = r_begin + b_r + RPB * j;
+        brow[j] = r;
+        bn_[j] = r / HoWo;
+        const unsigned rem = r - bn_[j] * HoWo;
+        by[j] = rem / p.Wo;
+        bx[j] = rem - by[j] * p.Wo;
+    }
+    auto advance = [&](int &n, int &y, int &x) {
+        x += 32;
+        if (x >= p.Wo) { x -= p.Wo; ++y; }
+        if (x >= p.Wo) { x -= p.Wo; ++y; }
+        if (x >= p.Wo) { x -= p.Wo; ++y; }
+        if (y >= p.Ho) { y -= p.Ho; ++n; }
+        if (y >= p.Ho) { y -= p.Ho; ++n; }
+    };
+
+    f32x4 ra[PA], rb[PB];
+    auto load_global = [&]() {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (arow[j] < r_end) v = *(const f32x4 *)(p.dy + (long)an[j] * p.dsn + (long)ay[j] * p.dsy + (long)ax[j] * p.dsx + m0 + a_c4 * 4);
+            ra[j] = v;
+            arow[j] += 32;
+            advance(an[j], ay[j], ax[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int iy = by[j] * p.stride + tr - p.pad_t, ix = bx[j] * p.stride + tq - p.pad_l;
+            if (brow[j] < r_end && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *(const f32x4 *)(p.x + (long)bn_[j] * p.xsn + (long)iy * p.xsy + (long)ix * p.xsx + n0 + b_c4 * 4);
+            rb[j] = v;
+            brow[j] += 32;
+            advance(bn_[j], by[j], bx[j]);
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float *a = As + buf * 32 * PITCH_A, *b = Bs + buf * 32 * PITCH_B;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) *(f32x4 *)(a + (a_r + RPA * j) * PITCH_A + a_c4 * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (b_r + RPB * j) * PITCH_B + b_c4 * 4) = rb[j];
+    };
+
+    f32x16 acc[MBA][MBB];
+#pragma unroll
+    for (int i = 0; i < MBA; ++i)
+#pragma unroll
+        for (int j = 0; j < MBB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float *a = As + buf * 32 * PITCH_A + lh * PITCH_A + wm * WM + l31 * MBA;
+        const float *b = Bs + buf * 32 * PITCH_B + lh * PITCH_B + wn * WN + l31 * MBB;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float fa[MBA], fb[MBB];
+            if constexpr (MBA == 2) {
+                const f32x2 v = *(const f32x2 *)(a + 2 * t * PITCH_A);
+                fa[0] = v.x;
+                fa[1] = v.y;
+            } else
+                fa[0] = a[2 * t * PITCH_A];
+            if constexpr (MBB == 2) {
+                const f32x2 v = *(const f32x2 *)(b + 2 * t * PITCH_B);
+                fb[0] = v.x;
+                fb[1] = v.y;
+            } else
+                fb[0] = b[2 * t * PITCH_B];
+#pragma unroll
+            for (int i = 0; i < MBA; ++i)
+#pragma unroll
+                for (int j = 0; j < MBB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_global();
+    store_lds(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const bool more = s + 1 < steps;
+        if (more) load_global();
+        compute(s & 1);
+        if (more) store_lds((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[m][n] of block (i, j): m = 8*(r/4) + 4*lh + (r%4) -> cout column m*MBA + i, n = l31 -> cin column n*MBB + j
+    const int taps = p.KH * p.KW;
+    const int og = p.Cout / p.groups;
+#pragma unroll
+    for (int i = 0; i < MBA; ++i)
+#pragma unroll
+        for (int j = 0; j < MBB; ++j) {
+            const int ci = n0 + wn * WN + l31 * MBB + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 8 * (r >> 2) + 4 * lh + (r & 3);
+                const int co = m0 + wm * WM + m * MBA + i;
+                if (co >= p.Cout) continue;
+                int cg = ci;
+                if (p.groups > 1) {  // block-diagonal: only the co-group's own input channels exist in the parameter
+                    cg = ci - (co / og) * p.Cin_g;
+                    if (cg < 0 || cg >= p.Cin_g) continue;
+                }
+                unsafeAtomicAdd(p.dw + ((long)co * taps + tap) * p.Cin_g + cg, acc[i][j][r]);
+            }
+        }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_wgrad(WgradArgs a, hipStream_t stream)
+{
+    constexpr int MBA = BM / WAVES_M / 32, MBB = BN / WAVES_N / 32;
+    constexpr size_t lds = (size_t)2 * 32 * (WgPitch<BM, MBA>::value + WgPitch<BN, MBB>::value) * sizeof(float);
+    a.tiles_m = (a.Cout + BM - 1) / BM;
+    a.tiles_n = a.Cin / BN;
+    const long tiles = (long)a.tiles_m * a.tiles_n * a.KH * a.KW;
+    const long R = (long)a.N * a.Ho * a.Wo;
+    long ksplit = (1536 + tiles - 1) / tiles;            // ~3 workgroups per slot of the 512 the chip holds
+    const long max_split = (R + 255) / 256;              // at least 8 k-steps per workgroup
+    if (ksplit > max_split) ksplit = max_split;
+    if (ksplit < 1) ksplit = 1;
+    long rps = (R + ksplit - 1) / ksplit;
+    rps = (rps + 31) / 32 * 32;
+    ksplit = (R + rps - 1) / rps;
+    a.rows_per_split = (unsigned)rps;
+    auto k = hvn_conv_wgrad_f32<BM, BN, WAVES_M, WAVES_N>;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), lds, stream, a);
+    return launch_ok();
+}
+
+int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream)
+{
+    if (a.Cin % 32 || a.Cout % 32 || a.groups < 1 || a.Cin_g * a.groups != a.Cin) return -1;
+    const int bm = a.Cout >= 128 ? 128 : a.Cout >= 64 ? 64 : 32;
+    const int bn = a.Cin % 128 == 0 ? 128 : a.Cin % 64 == 0 ? 64 : 32;
+    if (bm == 128 && bn == 128) return launch_wgrad<128, 128, 2, 2>(a, stream);
+    if (bm == 128 && bn == 64) return launch_wgrad<128, 64, 4, 1>(a, stream);
+    if (bm == 128 && bn == 32) return launch_wgrad<128, 32, 4, 1>(a, stream);
+    if (bm == 64 && bn == 128) return launch_wgrad<64, 128, 1, 4>(a, stream);
+    if (bm == 64 && bn == 64) return launch_wgrad<64, 64, 2, 2>(a, stream);
+    if (bm == 32 && bn == 128) return launch_wgrad<32, 128, 1, 4>(a, stream);
+    return -1;   // (64|32) x (64|32)-only channel counts do not occur in this network
+}
+
+// =========================================================================================
+// BatchNorm (train) + ReLU
+// =========================================================================================
+// Per-channel reductions over (n, y, x) of an NHWC view.  MODE 0: sum z, sum z^2.  MODE 1: sum g, sum g*xhat with
+// g = da * (a > 0), xhat = (z - mean) * rstd.  A thread owns one channel quad (LQ lanes per row, 256/LQ rows per
+// block pass), accumulates in double, the block combines through LDS and adds to ws[2*c + {0,1}] with f64 atomics.
+template <int MODE>
+__global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
+{
+    __shared__ double red[256][8];
+    const int LQ = p.lq;
+    const int q = blockIdx.x * LQ + (threadIdx.x % LQ);
+    const int rsub = threadIdx.x / LQ, rper = 256 / LQ;
+    const int CQ = p.C >> 2;
+    const bool act = q < CQ;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 mean = (f32x4){0.f, 0.f, 0.f, 0.f}, rstd = mean;
+    if (MODE == 1 && act) {
+        mean = *(const f32x4 *)(p.save + 2 * p.C + q * 4);
+        rstd = *(const f32x4 *)(p.save + 3 * p.C + q * 4);
+    }
+    const long rows = (long)p.N * p.H * p.W;
+    for (long r = (long)blockIdx.y * rper + rsub; r < rows && act; r += (long)gridDim.y * rper) {
+        const int x = (int)(r % p.W);
+        const long t = r / p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const f32x4 z = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)z[e];
+                s[4 + e] += (double)z[e] * (double)z[e];
+            }
+        } else {
+            const f32x4 a = *(const f32x4 *)(p.a + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4);
+            const f32x4 da = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = a[e] > 0.f ? da[e] : 0.f;
+                const float xh = (z[e] - mean[e]) * rstd[e];
+                s[e] += (double)g;
+                s[4 + e] += (double)(g * xh);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (rsub == 0 && act) {
+        for (int k = 1; k < rper; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += red[threadIdx.x + k * LQ][e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsafeAtomicAdd(p.ws + 2 * (q * 4 + e), s[e]);
+            unsafeAtomicAdd(p.ws + 2 * (q * 4 + e) + 1, s[4 + e]);
+        }
+    }
+}
+
+// forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
+__global__ void hvn_bn_final(const BnArgs p)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    const double n = (double)p.N * p.H * p.W;
+    const double mean = p.ws[2 * c] / n;
+    double var = p.ws[2 * c + 1] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    p.ws[2 * c] = 0.0;      // the workspace is handed back zeroed
+    p.ws[2 * c + 1] = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+    const double sc = (double)p.gamma[c] * rstd;
+    p.save[c] = (float)sc;
+    p.save[p.C + c] = (float)((double)p.beta[c] - mean * sc);
+    p.save[2 * p.C + c] = (float)mean;
+    p.save[3 * p.C + c] = (float)rstd;
+    const float mom = p.momentum;
+    p.running_mean[c] = (1.f - mom) * p.running_mean[c] + mom * (float)mean;
+    p.running_var[c] = (1.f - mom) * p.running_var[c] + mom * (float)(var * n / (n - 1.0));
+}
+
+// backward finalize: dgamma += sum g*xhat, dbeta += sum g; coefficients of the dz formula
+__global__ void hvn_bn_bwd_final(const BnArgs p)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    const double n = (double)p.N * p.H * p.W;
+    const double s1 = p.ws[2 * c], s2 = p.ws[2 * c + 1];
+    p.ws[2 * c] = 0.0;
+    p.ws[2 * c + 1] = 0.0;
+    p.dgamma[c] += (float)s2;
+    p.dbeta[c] += (float)s1;
+    p.coef[c] = p.gamma[c] * p.save[3 * p.C + c];
+    p.coef[p.C + c] = (float)(s1 / n);
+    p.coef[2 * p.C + c] = (float)(s2 / n);
+}
+
+// MODE 0: a = relu(z*scale + shift).  MODE 1: dz += c1 * (g - c2 - xhat*c3).
+template <int MODE>
+__global__ __launch_bounds__(256) void hvn_bn_apply(const BnArgs p, long total)
+{
+    const int CQ = p.C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % CQ);
+        long t = i / CQ;
+        const int x = (int)(t % p.W);
+        t /= p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const f32x4 z = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
+        if (MODE == 0) {
+            const f32x4 sc = *(const f32x4 *)(p.save + q * 4), sh = *(const f32x4 *)(p.save + p.C + q * 4);
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaxf(z[e] * sc[e] + sh[e], 0.f);
+            *(f32x4 *)(p.a_out + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4) = a;
+        } else {
+            const f32x4 a = *(const f32x4 *)(p.a + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4);
+            const f32x4 da = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
+            const f32x4 mean = *(const f32x4 *)(p.save + 2 * p.C + q * 4), rstd = *(const f32x4 *)(p.save + 3 * p.C + q * 4);
+            const f32x4 c1 = *(const f32x4 *)(p.coef + q * 4), c2 = *(const f32x4 *)(p.coef + p.C + q * 4),
+                        c3 = *(const f32x4 *)(p.coef + 2 * p.C + q * 4);
+            float *dzp = p.dz + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx + q * 4;
+            f32x4 dz = *(const f32x4 *)dzp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = a[e] > 0.f ? da[e] : 0.f;
+                const float xh = (z[e] - mean[e]) * rstd[e];
+                dz[e] += c1[e] * (g - c2[e] - xh * c3[e]);
+            }
+            *(f32x4 *)dzp = dz;
+        }
+    }
+}
+
+static void bn_grid(const BnArgs &a, dim3 &grid, int &lq)
+{
+    const int cq = a.C / 4;
+    lq = 64;
+    while (lq > cq) lq >>= 1;      // largest power of two <= min(64, cq)
+    if (lq < 1) lq = 1;
+    const long rows = (long)a.N * a.H * a.W;
+    const int rper = 256 / lq;
+    long gy = (rows + rper * 16 - 1) / (rper * 16);   // >= 16 rows per thread
+    if (gy > 1024) gy = 1024;
+    if (gy < 1) gy = 1;
+    grid = dim3((unsigned)((cq + lq - 1) / lq), (unsigned)gy);
+}
+
+int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
+{
+    if (a.C % 4) return -1;
+    dim3 grid;
+    bn_grid(a, grid, a.lq);
+    hipLaunchKernelGGL(hvn_bn_reduce<0>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 255) / 256), dim3(256), 0, stream, a);
+    const long total = (long)a.N * a.H * a.W * (a.C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(hvn_bn_apply<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
+    return launch_ok();
+}
+
+int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
+{
+    if (a.C % 4) return -1;
+    dim3 grid;
+    bn_grid(a, grid, a.lq);
+    hipLaunchKernelGGL(hvn_bn_reduce<1>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 255) / 256), dim3(256), 0, stream, a);
+    if (a.dz) {
+        const long total = (long)a.N * a.H * a.W * (a.C / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(hvn_bn_apply<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
+    }
+    return launch_ok();
+}
+
+// =========================================================================================
+// y = nearest2x(lo) + skip, backward: dlo += 2x2 sum of dy, dskip += dy
+// =========================================================================================
+__global__ __launch_bounds__(256) void hvn_upadd_bwd(const UpAddBwdArgs p, long total)
+{
+    const int CQ = p.C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % CQ);
+        long t = i / CQ;
+        const int x = (int)(t % (p.W / 2));
+        t /= (p.W / 2);
+        const int y = (int)(t % (p.H / 2));
+        const int n = (int)(t / (p.H / 2));
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const f32x4 g = *(const f32x4 *)(p.dy + (long)n * p.ysn + (long)(2 * y + dy) * p.ysy + (long)(2 * x + dx) * p.ysx + q * 4);
+                s += g;
+                if (p.dskip) {
+                    float *d = p.dskip + (long)n * p.ssn + (long)(2 * y + dy) * p.ssy + (long)(2 * x + dx) * p.ssx + q * 4;
+                    *(f32x4 *)d = *(const f32x4 *)d + g;
+                }
+            }
+        if (p.dlo) {
+            float *d = p.dlo + (long)n * p.lsn + (long)y * p.lsy + (long)x * p.lsx + q * 4;
+            *(f32x4 *)d = *(const f32x4 *)d + s;
+        }
+    }
+}
+
+int hvn_launch_upadd_bwd(const UpAddBwdArgs &a, hipStream_t stream)
+{
+    if (a.C % 4 || a.H % 2 || a.W % 2) return -1;
+    const long total = (long)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(hvn_upadd_bwd, dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
+    return launch_ok();
+}
+
+// =========================================================================================
+// 1x1 logit head (64 -> C, bias) backward: da += W^T dl, dW += sum dl (x) a, db += sum dl
+// =========================================================================================
+__global__ __launch_bounds__(256) void hvn_head_bwd(const HeadBwdArgs p, long total)
+{
+    __shared__ float sw[16 * 64 + 16];  // dW tile then db
+    const int C = p.Cout;
+    for (int i = threadIdx.x; i < C * 64 + C; i += 256) sw[i] = 0.f;
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const int x = (int)(i % p.W);
+        long t = i / p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
+        float *dst = p.dx + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx;
+        const long plane = (long)p.H * p.W;
+        const float *dl = p.dl + (long)n * C * plane + (long)y * p.W + x;
+        float a[64], da[64];
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            const f32x4 v = *(const f32x4 *)(src + c);
+            const f32x4 d = *(const f32x4 *)(dst + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[c + e] = v[e];
+                da[c + e] = d[e];
+            }
+        }
+        for (int co = 0; co < C; ++co) {
+            const float g = dl[co * plane];
+            const float *__restrict__ w = p.w + co * 64;
+            atomicAdd(&sw[C * 64 + co], g);
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                da[c] = fmaf(g, w[c], da[c]);
+                atomicAdd(&sw[co * 64 + c], g * a[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) *(f32x4 *)(dst + c) = (f32x4){da[c], da[c + 1], da[c + 2], da[c + 3]};
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * 64; k += 256) unsafeAtomicAdd(p.dw + k, sw[k]);
+    for (int k = threadIdx.x; k < C; k += 256) unsafeAtomicAdd(p.db + k, sw[C * 64 + k]);
+}
+
+int hvn_launch_head_bwd(const HeadBwdArgs &a, hipStream_t stream)
+{
+    if (a.Cout < 1 || a.Cout > 16) return -1;
+    const long total = (long)a.N * a.H * a.W;
+    hipLaunchKernelGGL(hvn_head_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return launch_ok();
+}
+
+// =========================================================================================
+// conv0 weight gradient: dW[co][r][s][ch] += sum dz[n,oy,ox,co] * img[n, oy+r-pad, ox+s-pad, ch] / 255
+// One workgroup walks several 16x16 output tiles: image patch (22x22x3) and the dz tile (256 px x 64 co) in LDS;
+// thread = (co, tap phase): 37 of the 147 (r, s*3+ch) taps each, register accumulators across the tiles.
+// =========================================================================================
+#define W0_T 16
+#define W0_P (W0_T + 6)
+__global__ __launch_bounds__(256) void hvn_conv0_wgrad(const Conv0WgradArgs p, int tiles_x, int tiles_y, long tiles_total)
+{
+    __shared__ float patch[W0_P][W0_P * 3 + 2];
+    __shared__ float dz[W0_T * W0_T / 2][64];
+    const int tid = threadIdx.x;
+    const int co = tid & 63;
+    const int ph = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform tap phase
+    float acc[37];
+#pragma unroll
+    for (int k = 0; k < 37; ++k) acc[k] = 0.f;
+    for (long tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x);
+        const long t2 = tile / tiles_x;
+        const int ty = (int)(t2 % tiles_y);
+        const int n = (int)(t2 / tiles_y);
+        const int oy0 = ty * W0_T, ox0 = tx * W0_T;
+        __syncthreads();
+        const uint8_t *img = p.img + (long)n * p.isn;
+        for (int i = tid; i < W0_P * W0_P * 3; i += 256) {
+            const int py = i / (W0_P * 3), pr = i - py * (W0_P * 3);
+            const int px = pr / 3, ch = pr - px * 3;
+            const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = (float)img[(long)iy * p.isy + (long)ix * p.isx + ch];
+            patch[py][pr] = v * (1.0f / 255.0f);
+        }
+        for (int half = 0; half < 2; ++half) {      // the dz tile goes through LDS in two halves of 8 rows
+            if (half) __syncthreads();
+            for (int i = tid; i < (W0_T * W0_T / 2) * 16; i += 256) {
+                const int pix = i >> 4, c4 = i & 15;
+                const int oy = oy0 + half * 8 + (pix >> 4), ox = ox0 + (pix & 15);
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (oy < p.Ho && ox < p.Wo) v = *(const f32x4 *)(p.dy + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + c4 * 4);
+                *(f32x4 *)&dz[pix][c4 * 4] = v;
+            }
+            __syncthreads();
+            for (int pix = 0; pix < W0_T * W0_T / 2; ++pix) {
+                const float g = dz[pix][co];
+                const float *prow = &patch[half * 8 + (pix >> 4)][(pix & 15) * 3];
+#pragma unroll
+                for (int k = 0; k < 37; ++k) {
+                    const int tap = ph + 4 * k;  // 0..146 (the last phases have one tap less)
+                    if (tap < 147) {
+                        const int r = tap / 21, s3 = tap - r * 21;
+                        acc[k] = fmaf(g, prow[r * (W0_P * 3 + 2) + s3], acc[k]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 37; ++k) {
+        const int tap = ph + 4 * k;
+        if (tap < 147) unsafeAtomicAdd(p.dw + (long)co * 147 + tap, acc[k]);
+    }
+}
+
+int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream)
+{
+    const int tx = (a.Wo + W0_T - 1) / W0_T, ty = (a.Ho + W0_T - 1) / W0_T;
+    const long total = (long)tx * ty * a.N;
+    long blocks = total < 1024 ? total : 1024;
+    hipLaunchKernelGGL(hvn_conv0_wgrad, dim3((unsigned)blocks), dim3(256), 0, stream, a, tx, ty, total);
+    return launch_ok();
+}
+
+// =========================================================================================
+// losses (utils.py:54-172 as composed by run_desc.py:40-82; all weights 1)
+//   sums[0] bce_np  [1] bce_tp  [2] mse  [3] msge numerator  [4] focus sum (both channels)
+//   sums[8 + c]  dice np: inse[c], [10 + c] l[c], [12 + c] r[c]   (c < 2)
+//   sums[16 + c] dice tp: inse[c], [32 + c] l[c], [48 + c] r[c]   (c < T <= 16)
+// Stage 1 accumulates the sums of this rank's pixels and stores the focus-weighted Sobel differences; the host
+// may all-reduce `sums` over the ranks; stage 2 turns the (global) sums into the logit gradients of this rank's
+// pixels, so that SUM-reducing the parameter gradients over ranks gives the full-batch gradient of the reference's
+// single-process DataParallel step.
+// =========================================================================================
+__device__ inline float sobel5_h(int r, int s)  // kernel_h[r][s] = h / (h^2 + v^2 + 1e-15), h = r-2, v = s-2 (utils.py:135-137)
+{
+    const float h = (float)(r - 2), v = (float)(s - 2);
+    return h / (h * h + v * v + 1.0e-15f);
+}
+
+__global__ __launch_bounds__(256) void hvn_loss_partial(const LossArgs p, long total)
+{
+    __shared__ double red[64];
+    if (threadIdx.x < 64) red[threadIdx.x] = 0.0;
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const int x = (int)(i % p.W);
+        long t = i / p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const long plane = (long)p.H * p.W;
+        const long pix = (long)y * p.W + x;
+        const float eps = 10e-8f;
+        // np branch
+        {
+            const float *l = p.l_np + (long)n * 2 * plane + pix;
+            const float l0 = l[0], l1 = l[plane];
+            const float mx = fmaxf(l0, l1);
+            const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+            const float inv = 1.f / (e0 + e1);
+            const float pr[2] = {e0 * inv, e1 * inv};
+            const int tc = p.t_np[i] != 0;
+            const float q = fminf(fmaxf(pr[tc] / (pr[0] + pr[1]), eps), 1.f - eps);
+            atomicAdd(&red[0], (double)(-logf(q)));
+            for (int c = 0; c < 2; ++c) {
+                if (c == tc) atomicAdd(&red[8 + c], (double)pr[c]);
+                atomicAdd(&red[10 + c], (double)pr[c]);
+            }
+            atomicAdd(&red[12 + tc], 1.0);
+        }
+        // tp branch
+        if (p.T > 0) {
+            const float *l = p.l_tp + (long)n * p.T * plane + pix;
+            float mx = l[0];
+            for (int c = 1; c < p.T; ++c) mx = fmaxf(mx, l[c * plane]);
+            float pr[16], sum = 0.f;
+            for (int c = 0; c < p.T; ++c) {
+                pr[c] = expf(l[c * plane] - mx);
+                sum += pr[c];
+            }
+            const float inv = 1.f / sum;
+            float ps = 0.f;
+            for (int c = 0; c < p.T; ++c) {
+                pr[c] *= inv;
+                ps += pr[c];
+            }
+            const int tc = p.t_tp[i];
+            const float q = fminf(fmaxf(pr[tc] / ps, eps), 1.f - eps);
+            atomicAdd(&red[1], (double)(-logf(q)));
+            for (int c = 0; c < p.T; ++c) {
+                if (c == tc) atomicAdd(&red[16 + c], (double)pr[c]);
+                atomicAdd(&red[32 + c], (double)pr[c]);
+            }
+            atomicAdd(&red[48 + tc], 1.0);
+        }
+        // hv branch: mse + msge (Sobel of the difference, zero padding 2)
+        {
+            const float *l = p.l_hv + (long)n * 2 * plane;
+            const float *tv = p.t_hv + (long)n * plane * 2;
+            const float d0 = l[pix] - tv[pix * 2], d1 = l[plane + pix] - tv[pix * 2 + 1];
+            atomicAdd(&red[2], (double)(d0 * d0 + d1 * d1));
+            float g0 = 0.f, g1 = 0.f;
+            for (int r = 0; r < 5; ++r)
+                for (int s = 0; s < 5; ++s) {
+                    const int yy = y + r - 2, xx = x + s - 2;
+                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                        const long q2 = (long)yy * p.W + xx;
+                        g0 = fmaf(sobel5_h(r, s), l[q2] - tv[q2 * 2], g0);
+                        g1 = fmaf(sobel5_h(s, r), l[plane + q2] - tv[q2 * 2 + 1], g1);
+                    }
+                }
+            const float f = p.t_np[i] != 0 ? 1.f : 0.f;
+            atomicAdd(&red[3], (double)(f * (g0 * g0 + g1 * g1)));
+            atomicAdd(&red[4], (double)(2.f * f));
+            p.gws[i * 2] = f * g0;
+            p.gws[i * 2 + 1] = f * g1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && red[threadIdx.x] != 0.0) unsafeAtomicAdd(p.sums + threadIdx.x, red[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % p.W);
+    long t = i / p.W;
+    const int y = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    const long plane = (long)p.H * p.W;
+    const long pix = (long)y * p.W + x;
+    const float eps = 10e-8f, smooth = 1e-3f;
+    const double M = p.m_total;  // pixels of the full (all-rank) batch
+    {
+        const float *l = p.l_np + (long)n * 2 * plane + pix;
+        const float l0 = l[0], l1 = l[plane];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float inv = 1.f / (e0 + e1);
+        const float pr[2] = {e0 * inv, e1 * inv};
+        const int tc = p.t_np[i] != 0;
+        const float q = pr[tc] / (pr[0] + pr[1]);
+        const float gate = (q > eps && q < 1.f - eps) ? 1.f : 0.f;
+        float D[2], dot = 0.f;
+        for (int c = 0; c < 2; ++c) {
+            const double I = p.sums[8 + c], den = p.sums[10 + c] + p.sums[12 + c] + smooth;
+            const double tcf = c == tc ? 1.0 : 0.0;
+            D[c] = (float)(-(2.0 * tcf * den - (2.0 * I + smooth)) / (den * den));
+            dot += D[c] * pr[c];
+        }
+        float *d = p.d_np + (long)n * 2 * plane + pix;
+        for (int c = 0; c < 2; ++c) d[c * plane] = gate * (pr[c] - (c == tc ? 1.f : 0.f)) / (float)M + pr[c] * (D[c] - dot);
+    }
+    if (p.T > 0) {
+        const float *l = p.l_tp + (long)n * p.T * plane + pix;
+        float mx = l[0];
+        for (int c = 1; c < p.T; ++c) mx = fmaxf(mx, l[c * plane]);
+        float pr[16], sum = 0.f;
+        for (int c = 0; c < p.T; ++c) {
+            pr[c] = expf(l[c * plane] - mx);
+            sum += pr[c];
+        }
+        const float inv = 1.f / sum;
+        float ps = 0.f;
+        for (int c = 0; c < p.T; ++c) {
+            pr[c] *= inv;
+            ps += pr[c];
+        }
+        const int tc = p.t_tp[i];
+        const float q = pr[tc] / ps;
+        const float gate = (q > eps && q < 1.f - eps) ? 1.f : 0.f;
+        float D[16], dot = 0.f;
+        for (int c = 0; c < p.T; ++c) {
+            const double I = p.sums[16 + c], den = p.sums[32 + c] + p.sums[48 + c] + smooth;
+            const double tcf = c == tc ? 1.0 : 0.0;
+            D[c] = (float)(-(2.0 * tcf * den - (2.0 * I + smooth)) / (den * den));
+            dot += D[c] * pr[c];
+        }
+        float *d = p.d_tp + (long)n * p.T * plane + pix;
+        for (int c = 0; c < p.T; ++c) d[c * plane] = gate * (pr[c] - (c == tc ? 1.f : 0.f)) / (float)M + pr[c] * (D[c] - dot);
+    }
+    {
+        const float *l = p.l_hv + (long)n * 2 * plane;
+        const float *tv = p.t_hv + (long)n * plane * 2;
+        const float d0 = l[pix] - tv[pix * 2], d1 = l[plane + pix] - tv[pix * 2 + 1];
+        // msge: dL/de[y,x] = sum_{r,s} K[r][s] * 2 f G[y-r+2, x-s+2] / (F + 1e-8)
+        float a0 = 0.f, a1 = 0.f;
+        const float *gw = p.gws + (long)n * plane * 2;
+        for (int r = 0; r < 5; ++r)
+            for (int s = 0; s < 5; ++s) {
+                const int yy = y - r + 2, xx = x - s + 2;
+                if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                    const long q2 = ((long)yy * p.W + xx) * 2;
+                    a0 = fmaf(sobel5_h(r, s), gw[q2], a0);
+                    a1 = fmaf(sobel5_h(s, r), gw[q2 + 1], a1);
+                }
+            }
+        const float kf = (float)(2.0 / (p.sums[4] + 1.0e-8));
+        float *d = p.d_hv + (long)n * 2 * plane + pix;
+        d[0] = d0 / (float)M + kf * a0;        // mse: mean over M*2 elements of e^2 -> e / M
+        d[plane] = d1 / (float)M + kf * a1;
+    }
+}
+
+int hvn_launch_loss(const LossArgs &a, int stage, hipStream_t stream)
+{
+    if (a.T < 0 || a.T > 16) return -1;
+    const long total = (long)a.N * a.H * a.W;
+    if (stage == 0)
+        hipLaunchKernelGGL(hvn_loss_partial, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    else
+        hipLaunchKernelGGL(hvn_loss_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return launch_ok();
+}
+
+// =========================================================================================
+// Adam (torch.optim.Adam, no weight decay / amsgrad) over one flat slab
+// =========================================================================================
+__global__ __launch_bounds__(256) void hvn_adam(float *w, const float *g, float *m, float *v, long n, float b1, float b2, float eps,
+                                                float step_size, float inv_bc2_sqrt)
+{
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const f32x4 gg = *(const f32x4 *)(g + i);
+            f32x4 mm = *(const f32x4 *)(m + i), vv = *(const f32x4 *)(v + i), ww = *(const f32x4 *)(w + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mm[e] = b1 * mm[e] + (1.f - b1) * gg[e];
+                vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+                ww[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps);
+            }
+            *(f32x4 *)(m + i) = mm;
+            *(f32x4 *)(v + i) = vv;
+            *(f32x4 *)(w + i) = ww;
+        } else {
+            for (long k = i; k < n; ++k) {
+                const float gk = g[k];
+                m[k] = b1 * m[k] + (1.f - b1) * gk;
+                v[k] = b2 * v[k] + (1.f - b2) * gk * gk;
+                w[k] -= step_size * m[k] / (sqrtf(v[k]) * inv_bc2_sqrt + eps);
+            }
+        }
+    }
+}
+
+int hvn_launch_adam(float *w, const float *g, float *m, float *v, long n, float b1, float b2, float eps, float step_size,
+                    float inv_bc2_sqrt, hipStream_t stream)
+{
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hvn_adam, dim3((unsigned)blocks), dim3(256), 0, stream, w, g, m, v, n, b1, b2, eps, step_size, inv_bc2_sqrt);
+    return launch_ok();
+}

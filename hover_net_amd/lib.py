@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhvn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("hvn_conv.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_contour.cpp")
+SOURCES = ("hvn_conv.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_train_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fvisibility=hidden", "-Wno-unused-value")
 
@@ -24,6 +24,19 @@ class hvn_op(ctypes.Structure):
                [("batch_stride", ctypes.c_int64 * 3), ("nbatch", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
 
 
+class hvn_top(ctypes.Structure):
+    """One launch of the training step (include/hvn.h, training section)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ("kind", "kh", "kw", "stride", "pad_t", "pad_l", "groups", "cout", "cin_g", "mode", "lead_pad", "_pad")] + \
+               [("x", hvn_view), ("y", hvn_view), ("dx", hvn_view), ("dy", hvn_view), ("p", ctypes.c_void_p * 6),
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("net", ctypes.POINTER(hvn_op))]
+
+
+class hvn_loss(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("logits_np", "logits_hv", "logits_tp", "true_np", "true_tp", "true_hv",
+                                               "grad_np", "grad_hv", "grad_tp", "sums", "sobel_ws")] + \
+               [(k, ctypes.c_int32) for k in ("n", "h", "w", "nr_types")] + [("total_pixels", ctypes.c_double)]
+
+
 class hvn_inst_rec(ctypes.Structure):
     _fields_ = [("label", ctypes.c_int32), ("area", ctypes.c_int32), ("rmin", ctypes.c_int32), ("rmax", ctypes.c_int32),
                 ("cmin", ctypes.c_int32), ("cmax", ctypes.c_int32), ("sum_x", ctypes.c_double), ("sum_y", ctypes.c_double),
@@ -34,6 +47,7 @@ EXPORTS = (
     "hvn_version", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_postproc_workspace_bytes", "hvn_postproc",
     "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
+    "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
 )
 
 
@@ -84,6 +98,12 @@ def lib():
         L.hvn_trace_contours.restype = ctypes.c_long
         L.hvn_trace_contours.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+        L.hvn_train_last_error.restype = ctypes.c_char_p
+        L.hvn_run_train_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.hvn_loss_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.hvn_loss_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.hvn_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
         _LIB = L
     return _LIB
 

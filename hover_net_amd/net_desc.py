@@ -9,7 +9,9 @@ key-shaped tree, and `forward` lowers them once to the fused HIP launch plan
 (`hover_net_amd.plan`) executed by libhvn_hip.so.  There is no torch fallback: without
 the library or off a gfx950 device `forward` raises.
 
-Training-mode forward/backward (run_desc.train_step) is not built yet.
+In train() mode `forward` runs the training engine's forward (batch-statistics BatchNorm, running stats updated,
+activations kept for `run_desc.train_step`'s backward pass); gradients are produced by the HIP backward plan,
+not by torch autograd, so the returned logits carry no grad_fn.
 """
 from collections import OrderedDict
 
@@ -78,7 +80,9 @@ class HoVerNet(nn.Module):
 
     # -- plan lifetime ---------------------------------------------------------------------
     def _weights_version(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        # the HIP training kernels update weights / running stats behind torch's version counters: the training
+        # engine bumps _train_version on every step
+        return (getattr(self, "_train_version", 0),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def engine(self, batch):
         """(Re)lower the checkpoint when the weights changed or a larger batch arrives."""
@@ -99,8 +103,11 @@ class HoVerNet(nn.Module):
 
     def forward(self, imgs):
         if self.training:
-            raise NotImplementedError(
-                "training-mode forward (batch-statistics BN + autograd) is not built in this round; call .eval()")
+            from . import train_engine
+
+            teng = train_engine.engine_for(self, imgs.shape[0])
+            teng.img.copy_(imgs.detach().permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8))   # the loader's uint8 pixels
+            return OrderedDict((k, v.clone()) for k, v in teng.forward().items())
         eng = self.engine(imgs.shape[0])
         logits, _ = eng.run(imgs)
         # fresh tensors: the engine's buffers are overwritten by the next call

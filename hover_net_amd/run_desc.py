@@ -7,6 +7,9 @@ a uint8 `[N,H,W,3]` tensor, returning a float32 numpy array `[N,h,w,3|4]` =
 NCHW copy), the whole forward + softmax/argmax/concat epilogue is one launch plan, and
 the only host sync is the final D2H of the 102 KB/tile map.
 
+`train_step` / `valid_step` (run_desc.py:12-167) run the training-mode forward, the losses, the backward pass
+and the optimizer step on the HIP path (hover_net_amd.train_engine).
+
 `infer_step_device` is the same step without the D2H: it returns the device tensor so
 `post_proc.process_batch_device` can run the instance separation on-GPU with no CPU
 round trip per tile (the north-star path; bench.py times this one).
@@ -37,8 +40,59 @@ def infer_step(batch_data, model):
     return pred.cpu().numpy()
 
 
-def train_step(batch_data, run_info):  # run_desc.py:12-109
-    raise NotImplementedError("hover_net_amd: the training step (SURVEY 8a T1-T5) is not built in this round")
+def _dist():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def train_step(batch_data, run_info):
+    """Drop-in for run_desc.py:12-109.  Same protocol: `run_info = [{"net": {"desc", "optimizer", "extra_info"}},
+    state]`, `batch_data` = the loader's dict (img uint8 NHWC, np_map, hv_map, tp_map?), returns
+    `{"EMA": {loss_<branch>_<term>, overall_loss}, "raw": {img, np: (true, pred), hv: (true, pred)}}`.
+
+    What runs: forward in train() mode (batch-statistics BatchNorm, running stats updated), the reference's loss
+    set (opt.py:47-51: np bce+dice, hv mse+msge, tp bce+dice, weights 1 -- other weightings are rejected), backward
+    and `optimizer.step()`, all on the HIP path (hover_net_amd.train_engine).  Multi-GPU is one process per GPU:
+    when torch.distributed is initialised the loss partial sums and the flat gradient slab are SUM-all-reduced
+    (RCCL), which reproduces the reference's single-process DataParallel step over the concatenated batch
+    (full-batch dice / msge denominators, per-replica BatchNorm statistics)."""
+    from . import train_engine
+
+    run_info, _state_info = run_info
+    model = run_info["net"]["desc"]
+    optimizer = run_info["net"]["optimizer"]
+    net = _unwrap(model)
+    loss_opts = run_info["net"].get("extra_info", {}).get("loss")
+    want = {"np": {"bce": 1, "dice": 1}, "hv": {"mse": 1, "msge": 1}}
+    if net.nr_types is not None:
+        want["tp"] = {"bce": 1, "dice": 1}
+    if loss_opts is not None and {k: dict(v) for k, v in loss_opts.items() if k in want} != want:
+        raise NotImplementedError("hover_net_amd: the fused loss kernel implements the reference configuration "
+                                  "(opt.py:47-51, all weights 1); got %r" % (loss_opts,))
+    imgs = batch_data["img"]
+    eng = train_engine.engine_for(net, imgs.shape[0])
+    net.train()
+    eng.load_batch(batch_data)
+    eng.forward()
+    dist = _dist()
+    if dist is None:
+        eng.loss_and_backward()
+    else:
+        eng.loss_and_backward(world=dist.get_world_size(), all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    optimizer.step()
+    result = {"EMA": dict(eng.loss_terms())}
+    # two random samples for the visualisation protocol (run_desc.py:90-107)
+    idx = torch.randint(0, imgs.shape[0], (2,))
+    didx = idx.to(eng.device)
+    prob_np = torch.softmax(eng.logits["np"][didx], 1)[:, 1].cpu().numpy()
+    pred_hv = eng.logits["hv"][didx].permute(0, 2, 3, 1).cpu().numpy()
+    true_np = torch.as_tensor(batch_data["np_map"])[idx].type(torch.int64).numpy()
+    true_hv = torch.as_tensor(batch_data["hv_map"])[idx].type(torch.float32).numpy()
+    result["raw"] = {"img": torch.as_tensor(imgs)[idx].byte().numpy(), "np": (true_np, prob_np), "hv": (true_hv, pred_hv)}
+    return result
 
 
 def valid_step(batch_data, run_info):

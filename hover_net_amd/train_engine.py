@@ -1,0 +1,354 @@
+"""Binds a training plan (hover_net_amd.train_plan) to HBM and runs the training step through libhvn_hip.so
+(/root/reference/models/hovernet/run_desc.py:12-109).
+
+Memory (sized for 288 GB, nothing is recomputed):
+* one parameter slab and one gradient slab with the SAME layout -- every trainable tensor of the module is
+  re-pointed at its slice (conv weights in channels_last order [cout][kh][kw][cin_g], which is what the weight-
+  gradient kernel writes and the packers read), so `optimizer.step()` (torch's Adam or optim.FusedAdam, one launch
+  over the slab) updates the weights the kernels use, and a data-parallel run all-reduces ONE flat tensor;
+* one activation arena (tensor-major: each tensor holds the whole batch) and one gradient arena, contiguous with
+  the gradient slab so that a single memset clears every accumulation target of a step;
+* per-step packed copies of the weights for the conv kernel (forward and data-gradient forms).
+
+torch is used for allocation, streams and `torch.distributed` (RCCL) only.  There is no CPU fallback.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import arch
+from . import lib as L
+from . import train_plan as TP
+from .plan import OP_CONV, OP_CONV0, OP_HEAD, OP_UPADD, _tile_n
+
+T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD_BWD = 1, 2, 3, 4, 5, 6, 7, 8
+MOMENTUM = 0.1
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class TrainEngine:
+    def __init__(self, net, batch, device=None):
+        L.require_gpu()
+        self.net = net
+        self.n = int(batch)
+        self.device = torch.device(device) if device is not None else next(net.parameters()).device
+        self.plan = P = TP.TrainPlan(net.mode, net.nr_types, net.freeze)
+        self._keep = []                       # ctypes objects referenced by pointer from the op arrays
+        self._params = dict(net.named_parameters())
+        self._buffers = dict(net.named_buffers())
+        self._build_slabs()
+        data_elems, garena_elems = P.layout(self.n)
+        dev = self.device
+        self.arena = torch.empty(max(data_elems, 64), dtype=torch.float32, device=dev)
+        # gradient slab + gradient arena in one allocation (one memset per step)
+        self._gtotal = self._slab_elems + garena_elems
+        self.gmem = torch.zeros(self._gtotal, dtype=torch.float32, device=dev)
+        self.gslab = self.gmem[:self._slab_elems]
+        self.garena = self.gmem[self._slab_elems:]
+        self._point_grads()
+        g = P.geo
+        self.img = torch.empty((self.n, g["inp"], g["inp"], 3), dtype=torch.uint8, device=dev)
+        ho = g["out"]
+        self.logits = {b: torch.empty((self.n, c, h, w), dtype=torch.float32, device=dev) for b, (c, h, w) in P.logits.items()}
+        self.dlogits = {b: torch.zeros_like(v) for b, v in self.logits.items()}
+        self.true_np = torch.zeros((self.n, ho, ho), dtype=torch.int32, device=dev)
+        self.true_tp = torch.zeros((self.n, ho, ho), dtype=torch.int32, device=dev)
+        self.true_hv = torch.zeros((self.n, ho, ho, 2), dtype=torch.float32, device=dev)
+        self.sums = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sobel_ws = torch.empty((self.n, ho, ho, 2), dtype=torch.float32, device=dev)
+        cmax = max(P.bns.values())
+        self.bn_ws = torch.zeros(2 * cmax, dtype=torch.float64, device=dev)
+        self.bn_coef = torch.empty(3 * cmax, dtype=torch.float32, device=dev)
+        self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
+        self._bn_save_off, off = {}, 0
+        for k, c in P.bns.items():
+            self._bn_save_off[k] = off
+            off += 4 * c
+        self.zero_bias = torch.zeros(64, dtype=torch.float32, device=dev)
+        self._alloc_packs()
+        self._nbt = [self._buffers[k + ".num_batches_tracked"] for k in P.bns]
+        self.fwd_ops = self._lower([self._pack_ops()] + [self._lower_fwd(op) for op in P.fwd])
+        self.bwd_ops = self._lower([self._lower_bwd(op) for op in P.bwd])
+        self._loss = self._loss_desc()
+        self.last_terms = None
+
+    # -- parameter / gradient slabs ------------------------------------------------------------------
+    def _build_slabs(self):
+        """Flat fp32 slab holding every float parameter in state_dict order; conv weights channels_last."""
+        P = self.plan
+        offs, total = {}, 0
+        for key, (kind, shape) in P.table.items():
+            if kind in ("conv", "bias", "bn_w", "bn_b"):
+                numel = 1
+                for s in shape:
+                    numel *= s
+                offs[key] = total
+                total += _align(numel)
+        self._slab_elems = total
+        self._poff = offs
+        self.wslab = torch.zeros(total, dtype=torch.float32, device=self.device)
+        for key, off in offs.items():
+            p = self._params[key]
+            view = self._param_view(self.wslab, key, off)
+            view.copy_(p.data.to(self.device))
+            p.data = view
+
+    def _param_view(self, slab, key, off):
+        kind, shape = self.plan.table[key]
+        if kind == "conv":
+            cout, cin_g, kh, kw = shape
+            return torch.as_strided(slab, shape, (kh * kw * cin_g, 1, kw * cin_g, cin_g), off)
+        numel = 1
+        for s in shape:
+            numel *= s
+        return slab[off:off + numel].view(shape)
+
+    def _point_grads(self):
+        for key, off in self._poff.items():
+            p = self._params[key]
+            p.grad = self._param_view(self.gslab, key, off) if key in self.plan.trainable else None
+
+    def wptr(self, key):
+        return self.wslab.data_ptr() + 4 * self._poff[key]
+
+    def gptr(self, key):
+        return self.gslab.data_ptr() + 4 * self._poff[key]
+
+    # -- packed weights --------------------------------------------------------------------------------
+    def _alloc_packs(self):
+        P = self.plan
+        self._pack_off, total = {}, 0
+        for key, c in P.convs.items():
+            cin = c["cin_g"] * c["groups"]
+            taps = c["kh"] * c["kw"]
+            lead = _align(c["cout"], _tile_n(c["cout"]))
+            self._pack_off[(key, 0)] = (total, lead)
+            total += _align(lead * cin * taps)
+            if c["dgrad"]:
+                lead = _align(cin, _tile_n(cin))
+                self._pack_off[(key, 1)] = (total, lead)
+                total += _align(lead * c["cout"] * taps)
+        self._pack_off[("conv0./.weight", 2)] = (total, 64)
+        total += _align(7 * 7 * 3 * 64)
+        self.packs = torch.zeros(total, dtype=torch.float32, device=self.device)
+
+    def pack_ptr(self, key, mode):
+        return self.packs.data_ptr() + 4 * self._pack_off[(key, mode)][0]
+
+    def _pack_ops(self):
+        ops = []
+        for (key, mode), (off, lead) in self._pack_off.items():
+            t = L.hvn_top()
+            t.kind, t.mode, t.lead_pad = T_PACK_W, mode, lead
+            if mode == 2:
+                t.cout, t.cin_g, t.groups, t.kh, t.kw = 64, 3, 1, 7, 7
+            else:
+                c = self.plan.convs[key]
+                t.cout, t.cin_g, t.groups, t.kh, t.kw = c["cout"], c["cin_g"], c["groups"], c["kh"], c["kw"]
+            t.p[0] = self.wptr(key)
+            t.p[1] = self.packs.data_ptr() + 4 * off
+            ops.append(t)
+        return ops
+
+    # -- views -------------------------------------------------------------------------------------------
+    def _view(self, v):
+        if v is None:
+            return L.hvn_view()
+        b = v.buf
+        base = (self.garena if isinstance(b, TP.GBuf) else self.arena).data_ptr()
+        s = L.hvn_view()
+        s.base = base + 4 * (b.off + (v.y0 * b.w + v.x0) * b.c + v.c0)
+        s.sn, s.sy, s.sx = b.h * b.w * b.c, v.step * b.w * b.c, v.step * b.c
+        s.h, s.w, s.c, s.sc = v.h, v.w, v.c, 1
+        return s
+
+    def _net(self, **kw):
+        o = L.hvn_op()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        self._keep.append(o)
+        t = L.hvn_top()
+        t.kind = T_NET
+        t.net = ctypes.pointer(o)
+        return t
+
+    # -- lowering -----------------------------------------------------------------------------------------
+    def _lower_fwd(self, op):
+        if op.kind == "conv0":
+            x = L.hvn_view()
+            g = self.plan.geo["inp"]
+            x.base, x.sn, x.sy, x.sx, x.h, x.w, x.c, x.sc = self.img.data_ptr(), g * g * 3, g * 3, 3, g, g, 3, 1
+            return [self._net(kind=OP_CONV0, kh=7, kw=7, stride=1, pad_t=op.pad, pad_l=op.pad, relu=0, cout=64, x_dtype=0, x=x,
+                              y=self._view(op.y), w=self.pack_ptr(op.wkey, 2),
+                              bias=self.zero_bias.data_ptr())]
+        if op.kind == "conv":
+            kw = dict(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=op.stride, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.y.c,
+                      tile_n=_tile_n(op.y.c), groups=op.groups, x=self._view(op.x), y=self._view(op.y),
+                      w=self.pack_ptr(op.wkey, 0), nbatch=1)
+            if op.res is not None:
+                kw["res"] = self._view(op.res)
+            return [self._net(**kw)]
+        if op.kind == "bnrelu":
+            t = L.hvn_top()
+            t.kind = T_BN_FWD
+            t.x, t.y = self._view(op.z), self._view(op.a)
+            k = op.bnkey
+            t.p[0] = self.bn_ws.data_ptr()
+            t.p[1] = self.bn_save.data_ptr() + 4 * self._bn_save_off[k]
+            t.p[2], t.p[3] = self.wptr(k + ".weight"), self.wptr(k + ".bias")
+            t.p[4], t.p[5] = self._buffers[k + ".running_mean"].data_ptr(), self._buffers[k + ".running_var"].data_ptr()
+            t.eps, t.momentum = arch.BN_EPS, MOMENTUM
+            return [t]
+        if op.kind == "upadd":
+            return [self._net(kind=OP_UPADD, x=self._view(op.lo), res=self._view(op.skip), y=self._view(op.y))]
+        if op.kind == "head":
+            y = L.hvn_view()
+            y.base = self.logits[op.branch].data_ptr()
+            y.h, y.w, y.c = op.x.h, op.x.w, op.cout
+            return [self._net(kind=OP_HEAD, cout=op.cout, x=self._view(op.x), y=y,
+                              w=self.wptr(op.wkey),
+                              bias=self.wptr(op.bkey))]
+        raise KeyError(op.kind)
+
+    def _lower_bwd(self, op):
+        t = L.hvn_top()
+        if op.kind == "head_bwd":
+            t.kind, t.cout = T_HEAD_BWD, op.cout
+            t.x, t.dx = self._view(op.x), self._view(op.dx)
+            t.p[0], t.p[1] = self.dlogits[op.branch].data_ptr(), self.wptr(op.wkey)
+            t.p[2], t.p[3] = self.gptr(op.wkey), self.gptr(op.bkey)
+            return [t]
+        if op.kind == "bnrelu_bwd":
+            k = op.bnkey
+            t.kind = T_BN_BWD
+            t.x, t.y, t.dy, t.dx = self._view(op.z), self._view(op.a), self._view(op.da), self._view(op.dz)
+            t.p[0] = self.bn_ws.data_ptr()
+            t.p[1] = self.bn_save.data_ptr() + 4 * self._bn_save_off[k]
+            t.p[2] = self.wptr(k + ".weight")
+            t.p[3], t.p[4] = self.gptr(k + ".weight"), self.gptr(k + ".bias")
+            t.p[5] = self.bn_coef.data_ptr()
+            return [t]
+        if op.kind == "wgrad":
+            t.kind = T_WGRAD
+            t.kh, t.kw, t.stride, t.pad_t, t.pad_l, t.groups = op.kh, op.kw, op.stride, op.pad[0], op.pad[0], op.groups
+            t.x, t.dy = self._view(op.x), self._view(op.dy)
+            t.p[0] = self.gptr(op.wkey)
+            return [t]
+        if op.kind == "dgrad":
+            dx = self._view(op.dx)
+            return [self._net(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=1, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.dx.c,
+                              tile_n=_tile_n(op.dx.c), groups=1, x=self._view(op.dy), y=dx, res=dx,
+                              w=self.pack_ptr(op.wkey, 1), nbatch=1)]
+        if op.kind == "upadd_bwd":
+            t.kind = T_UPADD_BWD
+            t.dy, t.dx, t.y = self._view(op.dy), self._view(op.dlo), self._view(op.dskip)
+            return [t]
+        if op.kind == "conv0_wgrad":
+            t.kind, t.pad_t = T_CONV0_WGRAD, op.pad
+            g = self.plan.geo["inp"]
+            t.x.base, t.x.sn, t.x.sy, t.x.sx, t.x.h, t.x.w, t.x.c, t.x.sc = self.img.data_ptr(), g * g * 3, g * 3, 3, g, g, 3, 1
+            t.dy = self._view(op.dy)
+            t.p[0] = self.gptr(op.wkey)
+            return [t]
+        raise KeyError(op.kind)
+
+    def _lower(self, groups):
+        flat = [t for g in groups for t in g]
+        arr = (L.hvn_top * len(flat))()
+        for i, t in enumerate(flat):
+            ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(t), ctypes.sizeof(L.hvn_top))
+        return arr
+
+    def _loss_desc(self):
+        d = L.hvn_loss()
+        d.logits_np, d.logits_hv = self.logits["np"].data_ptr(), self.logits["hv"].data_ptr()
+        d.grad_np, d.grad_hv = self.dlogits["np"].data_ptr(), self.dlogits["hv"].data_ptr()
+        if "tp" in self.logits:
+            d.logits_tp, d.grad_tp = self.logits["tp"].data_ptr(), self.dlogits["tp"].data_ptr()
+            d.true_tp = self.true_tp.data_ptr()
+        d.true_np, d.true_hv = self.true_np.data_ptr(), self.true_hv.data_ptr()
+        d.sums, d.sobel_ws = self.sums.data_ptr(), self.sobel_ws.data_ptr()
+        d.n, d.h, d.w = self.n, self.true_np.shape[1], self.true_np.shape[2]
+        d.nr_types = self.net.nr_types or 0
+        return d
+
+    # -- one step ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_batch(self, batch):
+        """batch: the reference loader's dict (img uint8 NHWC, np_map, hv_map, tp_map?) of tensors / arrays."""
+        def put(dst, src, dtype):
+            src = torch.as_tensor(src)
+            if src.shape[0] != self.n:
+                raise ValueError("the training engine was built for batch %d, got %d" % (self.n, src.shape[0]))
+            dst.copy_(src.to(dtype).reshape(dst.shape), non_blocking=True)
+        put(self.img, batch["img"], torch.uint8)
+        put(self.true_np, batch["np_map"], torch.int32)
+        put(self.true_hv, batch["hv_map"], torch.float32)
+        if self.net.nr_types is not None:
+            put(self.true_tp, torch.squeeze(torch.as_tensor(batch["tp_map"])).reshape(self.true_tp.shape), torch.int32)
+
+    def forward(self):
+        lib = L.lib()
+        rc = lib.hvn_run_train_plan(self.fwd_ops, len(self.fwd_ops), self.n, self._stream())
+        if rc:
+            raise L.HvnError("hvn_run_train_plan(forward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        torch._foreach_add_(self._nbt, 1)
+        self.net._train_version = getattr(self.net, "_train_version", 0) + 1    # invalidates the cached inference plan
+        return self.logits
+
+    def loss_and_backward(self, world=1, all_reduce=None):
+        """Loss stage 1 -> (all-reduce of the partial sums) -> logit gradients -> backward plan.
+        Returns the loss terms as a float64 CPU tensor of raw sums (see loss_terms())."""
+        lib = L.lib()
+        s = self._stream()
+        self.gmem.zero_()
+        self.sums.zero_()
+        rc = lib.hvn_loss_forward(ctypes.byref(self._loss), s)
+        if rc:
+            raise L.HvnError("hvn_loss_forward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        if all_reduce is not None:
+            all_reduce(self.sums)
+        self._loss.total_pixels = float(world * self.n * self._loss.h * self._loss.w)
+        rc = lib.hvn_loss_backward(ctypes.byref(self._loss), s)
+        if rc:
+            raise L.HvnError("hvn_loss_backward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        rc = lib.hvn_run_train_plan(self.bwd_ops, len(self.bwd_ops), self.n, s)
+        if rc:
+            raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        if all_reduce is not None:
+            all_reduce(self.gslab)
+        return self.sums
+
+    def loss_terms(self, sums=None):
+        """Raw sums -> the reference's named loss terms (run_desc.py:66-82) as python floats (one D2H sync)."""
+        s = (self.sums if sums is None else sums).cpu().numpy()
+        m = self._loss.total_pixels
+        smooth = 1e-3
+        t = {}
+
+        def dice(i0, l0, r0, c):
+            return float(sum(1.0 - (2.0 * s[i0 + k] + smooth) / (s[l0 + k] + s[r0 + k] + smooth) for k in range(c)))
+        if self.net.nr_types is not None:
+            t["loss_tp_bce"] = float(s[1] / m)
+            t["loss_tp_dice"] = dice(16, 32, 48, self.net.nr_types)
+        t["loss_np_bce"] = float(s[0] / m)
+        t["loss_np_dice"] = dice(8, 10, 12, 2)
+        t["loss_hv_mse"] = float(s[2] / (2.0 * m))
+        t["loss_hv_msge"] = float(s[3] / (s[4] + 1.0e-8))
+        t["overall_loss"] = float(sum(t.values()))
+        return t
+
+
+def engine_for(net, batch):
+    """The module's training engine for this batch size (built on first use, rebuilt when the batch size changes)."""
+    eng = getattr(net, "_train_engine", None)
+    if eng is None or eng.n != int(batch) or eng.plan.freeze != net.freeze:
+        eng = TrainEngine(net, batch)
+        net._train_engine = eng
+    return eng

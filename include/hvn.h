@@ -130,6 +130,65 @@ HVN_API int hvn_instance_table(const int32_t *inst, const float *pred, int n, in
 HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_inst_rec *recs, int n_rec,
                                 int32_t *pts, long max_pts, int64_t *offs);
 
+
+/* -- training step: run_desc.py:12-109 train_step (forward in train() mode, losses utils.py:54-172, backward, Adam) --
+ * A training step is two hvn_top lists (forward, backward; hover_net_amd/train_plan.py lowers the network to them)
+ * around the two loss stages.  Weights live in the parameter layout [cout][kh*kw][cin_g] (torch channels_last);
+ * gradients are ACCUMULATED into their destinations (the caller zeroes the gradient arena once per step).
+ *   NET          net = one forward-plan op (CONV0 / CONV / UPADD / HEAD); convolutions of the forward pass and the
+ *                data gradients (stride-1 conv of the -- possibly dilated -- output gradient, res = y to accumulate)
+ *   PACK_W       p[0] = weights, p[1] = packed copy for the conv kernel; mode 0 forward ([lead_pad][cin/32][taps][32],
+ *                groups expanded block-diagonally), 1 data-gradient (transposed, taps flipped:
+ *                [lead_pad][cout/32][taps][32]), 2 conv0 ([7][7][3][64] x 1/255); cout, cin_g, groups, kh, kw
+ *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[2c] (zero on entry and exit),
+ *                p[1] = save[4c] (scale, shift, mean, rstd), p[2] = gamma, p[3] = beta, p[4] = running_mean,
+ *                p[5] = running_var (updated: momentum, unbiased variance); eps, momentum
+ *   BN_BWD       x = z, y = a, dy = grad a, dx = grad z (+=, base NULL: none); p[0] = ws, p[1] = save, p[2] = gamma,
+ *                p[3] = grad gamma (+=), p[4] = grad beta (+=), p[5] = coef[3c] scratch
+ *   WGRAD        p[0][cout][kh*kw][cin_g] += sum_pixels dy (x) x: x = conv input view, dy = output-gradient view;
+ *                kh, kw, stride, pad_t, pad_l, groups
+ *   CONV0_WGRAD  x = uint8 image view, dy = grad of the conv0 output, p[0] = grad [64][7][7][3] (+=); pad_t
+ *   UPADD_BWD    dy = grad of nearest2x(lo) + skip; dx = grad lo (+= 2x2 sums, nullable), y = grad skip (+=, nullable)
+ *   HEAD_BWD     x = head input [h][w][64], dx = its grad (+=), p[0] = logit grad NCHW, p[1] = W [cout][64],
+ *                p[2] = grad W (+=), p[3] = grad bias (+=); cout
+ */
+enum { HVN_T_NET = 1, HVN_T_PACK_W = 2, HVN_T_BN_FWD = 3, HVN_T_BN_BWD = 4, HVN_T_WGRAD = 5, HVN_T_CONV0_WGRAD = 6,
+       HVN_T_UPADD_BWD = 7, HVN_T_HEAD_BWD = 8 };
+typedef struct hvn_top {
+    int32_t kind, kh, kw, stride, pad_t, pad_l, groups, cout, cin_g, mode, lead_pad, _pad;
+    hvn_view x, y, dx, dy;
+    void *p[6];          /* dev */
+    float eps, momentum;
+    const hvn_op *net;   /* host */
+} hvn_top;
+HVN_API int hvn_run_train_plan(const hvn_top *ops, int n_ops, int batch, void *stream);
+HVN_API const char *hvn_train_last_error(void);
+
+/* Losses of run_desc.py:40-82 with opt.py:47-51 weights (np: bce + dice, hv: mse + msge, tp: bce + dice).
+ * logits_* / grad_*: dev float32 NCHW [n][c][h][w] (c = 2, 2, nr_types); true_np / true_tp: dev int32 [n][h][w];
+ * true_hv: dev float32 [n][h][w][2]; sums: dev double[64], zero before hvn_loss_forward, which adds this rank's
+ * partial sums ([0] bce_np [1] bce_tp [2] mse [3] msge numerator [4] focus sum; [8+c] [10+c] [12+c] dice np
+ * inse/l/r; [16+c] [32+c] [48+c] dice tp); the caller may SUM-all-reduce it over ranks, sets total_pixels to the
+ * pixel count of the whole batch (all ranks), and hvn_loss_backward writes the logit gradients of this rank's
+ * pixels.  sobel_ws: dev float32 [n][h][w][2] scratch carried from forward to backward. */
+typedef struct hvn_loss {
+    const float *logits_np, *logits_hv, *logits_tp;
+    const int32_t *true_np, *true_tp;
+    const float *true_hv;
+    float *grad_np, *grad_hv, *grad_tp;
+    double *sums;
+    float *sobel_ws;
+    int32_t n, h, w, nr_types;   /* nr_types = 0: no tp branch */
+    double total_pixels;
+} hvn_loss;
+HVN_API int hvn_loss_forward(const hvn_loss *l, void *stream);
+HVN_API int hvn_loss_backward(const hvn_loss *l, void *stream);
+
+/* torch.optim.Adam (opt.py:38-44: lr 1e-4, betas (0.9, 0.999), eps 1e-8, no weight decay) over flat dev slabs;
+ * step = 1 for the first update. */
+HVN_API int hvn_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

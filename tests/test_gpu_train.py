@@ -1,0 +1,432 @@
+"""-m gpu: the HIP training kernels (through the C ABI: hvn_run_train_plan / hvn_loss_* / hvn_adam_step) against
+the torch references of tests/train_interp.py, and the whole training step against the training oracle.
+
+Floating-point bar: per-kernel 1e-4..1e-3 relative on the tensor's scale (fp32 sums in a different order); the
+whole step is held to the fp32 noise floor measured against a float64 run of the oracle (the synthetic problem
+amplifies rounding through ReLU flips and batch statistics: torch's own fp32 run is a few per cent off the float64
+gradient on the worst tensors)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _L():
+    from hover_net_amd import lib as L
+    L.require_gpu()
+    return L
+
+
+def view_of(t, y0=0, x0=0, h=None, w=None, c0=0, c=None, step=1):
+    """hvn_view over a contiguous [N,H,W,C] cuda tensor."""
+    from hover_net_amd import lib as L
+    n, H, W, C = t.shape
+    v = L.hvn_view()
+    h = (H - y0 + step - 1) // step if h is None else h
+    w = (W - x0 + step - 1) // step if w is None else w
+    c = C - c0 if c is None else c
+    v.base = t.data_ptr() + t.element_size() * ((y0 * W + x0) * C + c0)
+    v.sn, v.sy, v.sx = H * W * C, step * W * C, step * C
+    v.h, v.w, v.c, v.sc = h, w, c, 1
+    return v
+
+
+def run_tops(tops, batch):
+    L = _L()
+    arr = (L.hvn_top * len(tops))()
+    for i, t in enumerate(tops):
+        ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(t), ctypes.sizeof(L.hvn_top))
+    rc = L.lib().hvn_run_train_plan(arr, len(tops), batch, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.lib().hvn_train_last_error().decode()
+    torch.cuda.synchronize()
+
+
+def close(got, want, rtol, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got - want).abs().max())
+    assert err <= rtol * scale, "%s: max err %.3e on scale %.3e" % (what, err, scale)
+
+
+def chlast(w):
+    """[cout,cin_g,kh,kw] -> the parameter-slab layout [cout][kh][kw][cin_g] as a flat cuda tensor."""
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cout,cin_g,k,groups", [(128, 64, 3, 1), (32, 32, 5, 4), (256, 1024, 1, 1), (64, 256, 5, 1), (2048, 512, 1, 1)])
+def test_pack_weights_forward_and_dgrad(cout, cin_g, k, groups):
+    import train_interp
+    from hover_net_amd import lib as L
+    from hover_net_amd.plan import _pack_conv, _tile_n
+    w = torch.randn(cout, cin_g, k, k)
+    src = chlast(w)
+    cin = cin_g * groups
+    for mode in (0, 1):
+        if mode == 0:
+            want, _ = _pack_conv(w.numpy().astype(np.float64), groups=groups)
+        else:
+            want, _ = _pack_conv(train_interp.dgrad_weights(w, groups).numpy().astype(np.float64))
+        lead = want.shape[0]
+        dst = torch.full((want.size,), 7.0, device="cuda")
+        t = L.hvn_top()
+        t.kind, t.mode, t.lead_pad, t.cout, t.cin_g, t.groups, t.kh, t.kw = 2, mode, lead, cout, cin_g, groups, k, k
+        t.p[0], t.p[1] = src.data_ptr(), dst.data_ptr()
+        run_tops([t], 1)
+        assert torch.equal(dst.cpu(), torch.from_numpy(want).reshape(-1)), (mode, lead, _tile_n(cin))
+
+
+WG_CASES = [  # n, H, W, cin, cout, k, stride, pad(lo,hi), groups, dy step
+    (2, 20, 20, 64, 64, 3, 1, (1, 1), 1, 1),
+    (2, 24, 24, 128, 256, 1, 1, (0, 0), 1, 1),
+    (3, 18, 18, 128, 32, 5, 1, (0, 0), 4, 1),
+    (2, 24, 24, 128, 128, 3, 2, (0, 1), 1, 2),
+    (1, 30, 30, 288, 128, 1, 1, (0, 0), 1, 1),
+    (2, 16, 16, 256, 64, 5, 1, (2, 2), 1, 1),
+    (2, 22, 22, 64, 256, 1, 2, (0, 0), 1, 2),
+    (1, 40, 40, 1024, 256, 5, 1, (0, 0), 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,k,stride,pad,groups,step", WG_CASES)
+def test_wgrad_matches_torch(n, H, W, cin, cout, k, stride, pad, groups, step):
+    import train_interp
+    from hover_net_amd import lib as L
+    from hover_net_amd.train_plan import TOp
+    g = torch.Generator().manual_seed(1)
+    # the conv input is a channel / spatial window of a bigger buffer, dy a (possibly dilated) view
+    xb = torch.randn(n, H + 3, W + 2, cin + 32, generator=g).cuda()
+    ho = (H + pad[0] + pad[1] - k) // stride + 1
+    dyb = torch.randn(n, ho * step, ho * step, cout, generator=g).cuda()
+    xv = view_of(xb, 2, 1, H, W, 32, cin)
+    dyv = view_of(dyb, 0, 0, ho, ho, 0, cout, step=step)
+    cin_g = cin // groups
+    dw = torch.zeros(cout * k * k * cin_g, device="cuda")
+    t = L.hvn_top()
+    t.kind, t.kh, t.kw, t.stride, t.pad_t, t.pad_l, t.groups = 5, k, k, stride, pad[0], pad[0], groups
+    t.x, t.dy = xv, dyv
+    t.p[0] = dw.data_ptr()
+    run_tops([t], n)
+    op = TOp("wgrad", "t", stride=stride, pad=pad, groups=groups)
+    x = xb.cpu()[:, 2:2 + H, 1:1 + W, 32:]
+    dy = dyb.cpu()[:, ::step, ::step]
+    want = train_interp.wgrad_ref(op, x, dy, (cout, cin_g, k, k))
+    got = dw.cpu().view(cout, k, k, cin_g).permute(0, 3, 1, 2)
+    close(got, want, 2e-4, "wgrad")
+    run_tops([t], n)          # accumulates
+    close(dw.cpu().view(cout, k, k, cin_g).permute(0, 3, 1, 2), 2 * want, 2e-4, "wgrad accumulate")
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,k,stride,pad,groups", [c[:9] for c in WG_CASES])
+def test_dgrad_as_forward_conv_of_packed_transposed_weights(n, H, W, cin, cout, k, stride, pad, groups):
+    """Data gradient = pack(mode 1) + the forward conv kernel over the (dilated) output gradient, accumulating."""
+    from hover_net_amd import lib as L
+    from hover_net_amd.plan import _tile_n
+    g = torch.Generator().manual_seed(2)
+    cin_g = cin // groups
+    w = torch.randn(cout, cin_g, k, k, generator=g) * 0.1
+    ho = (H + pad[0] + pad[1] - k) // stride + 1
+    dy = torch.randn(n, ho, ho, cout, generator=g)
+    dyb = torch.zeros(n, ho * stride, ho * stride, cout)
+    dyb[:, ::stride, ::stride] = dy
+    dyb = dyb.cuda()
+    dxb = torch.randn(n, H, W, cin, generator=g).cuda()
+    before = dxb.cpu().clone()
+    lead = (cin + _tile_n(cin) - 1) // _tile_n(cin) * _tile_n(cin)
+    packed = torch.zeros(lead * cout * k * k, device="cuda")
+    src = chlast(w)
+    tp = L.hvn_top()
+    tp.kind, tp.mode, tp.lead_pad, tp.cout, tp.cin_g, tp.groups, tp.kh, tp.kw = 2, 1, lead, cout, cin_g, groups, k, k
+    tp.p[0], tp.p[1] = src.data_ptr(), packed.data_ptr()
+    o = L.hvn_op()
+    o.kind, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.cout, o.tile_n, o.groups, o.nbatch = 2, k, k, 1, k - 1 - pad[0], k - 1 - pad[0], cin, _tile_n(cin), 1, 1
+    o.x = view_of(dyb, 0, 0, (ho - 1) * stride + 1, (ho - 1) * stride + 1, 0, cout)
+    o.y = view_of(dxb)
+    o.res = view_of(dxb)
+    o.w = packed.data_ptr()
+    tn = L.hvn_top()
+    tn.kind = 1
+    tn.net = ctypes.pointer(o)
+    run_tops([tp, tn], n)
+    x = torch.zeros(n, H, W, cin, requires_grad=True)
+    y = F.conv2d(F.pad(x.permute(0, 3, 1, 2), (pad[0], pad[1], pad[0], pad[1])), w, stride=stride, groups=groups)
+    y.backward(dy.permute(0, 3, 1, 2))
+    close(dxb.cpu() - before, x.grad, 2e-4, "dgrad")
+
+
+@pytest.mark.parametrize("n,H,W,C,crop,step", [(2, 20, 20, 64, 0, 1), (3, 17, 19, 288, 2, 1), (2, 12, 12, 2048, 0, 1), (2, 16, 16, 128, 0, 2), (1, 33, 33, 72, 1, 1)])
+def test_bn_relu_forward_backward(n, H, W, C, crop, step):
+    import train_interp
+    from hover_net_amd import lib as L
+    g = torch.Generator().manual_seed(3)
+    zb = torch.randn(n, H * step, W * step, C + 32, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    h, w = H - 2 * crop, W - 2 * crop
+    zc = zb.cuda()
+    ab = torch.zeros(n, h, w, C, device="cuda")
+    dab = torch.randn(n, h, w, C, generator=g).cuda()
+    dzb = torch.randn(n, H * step, W * step, C + 32, generator=g).cuda()
+    dz0 = dzb.cpu().clone()
+    ws = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    save, coef = torch.zeros(4 * C, device="cuda"), torch.zeros(3 * C, device="cuda")
+    gm, bt, rmc, rvc = gamma.cuda(), beta.cuda(), rm.clone().cuda(), rv.clone().cuda()
+    dgam, dbet = torch.ones(C, device="cuda"), torch.ones(C, device="cuda")
+    zv = view_of(zc, crop * step, crop * step, h, w, 32, C, step=step)
+    tf = L.hvn_top()
+    tf.kind, tf.x, tf.y = 3, zv, view_of(ab)
+    tf.p[0], tf.p[1], tf.p[2], tf.p[3], tf.p[4], tf.p[5] = ws.data_ptr(), save.data_ptr(), gm.data_ptr(), bt.data_ptr(), rmc.data_ptr(), rvc.data_ptr()
+    tf.eps, tf.momentum = 1e-5, 0.1
+    run_tops([tf], n)
+    z = zb[:, crop * step:crop * step + (h - 1) * step + 1:step, crop * step:crop * step + (w - 1) * step + 1:step, 32:]
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    a_ref, mean, rstd = train_interp.bn_fwd_ref(z, gamma, beta, rm_ref, rv_ref)
+    close(ab, a_ref, 1e-5, "bn a")
+    close(rmc, rm_ref, 1e-5, "running mean")
+    close(rvc, rv_ref, 1e-5, "running var")
+    assert float(ws.abs().max()) == 0.0
+    tb = L.hvn_top()
+    tb.kind, tb.x, tb.y, tb.dy = 4, zv, view_of(ab), view_of(dab)
+    tb.dx = view_of(dzb, crop * step, crop * step, h, w, 32, C, step=step)
+    tb.p[0], tb.p[1], tb.p[2], tb.p[3], tb.p[4], tb.p[5] = ws.data_ptr(), save.data_ptr(), gm.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr()
+    run_tops([tb], n)
+    dz_ref, dg_ref, db_ref = train_interp.bn_bwd_ref(z, a_ref, dab.cpu(), gamma, mean, rstd)
+    got = (dzb.cpu() - dz0)[:, crop * step:crop * step + (h - 1) * step + 1:step, crop * step:crop * step + (w - 1) * step + 1:step, 32:]
+    close(got, dz_ref, 1e-4, "bn dz")
+    close(dgam - 1, dg_ref, 1e-4, "dgamma")
+    close(dbet - 1, db_ref, 1e-4, "dbeta")
+    untouched = (dzb.cpu() - dz0)
+    untouched[:, crop * step:crop * step + (h - 1) * step + 1:step, crop * step:crop * step + (w - 1) * step + 1:step, 32:] = 0
+    assert float(untouched.abs().max()) == 0.0
+
+
+def test_upadd_head_conv0_backward():
+    import train_interp
+    from hover_net_amd import lib as L
+    g = torch.Generator().manual_seed(4)
+    n = 2
+    # upadd backward
+    dy = torch.randn(n, 12, 12, 64, generator=g).cuda()
+    dlo = torch.randn(n, 6, 6, 64, generator=g).cuda()
+    dsk = torch.randn(n, 20, 20, 64, generator=g).cuda()
+    lo0, sk0 = dlo.cpu().clone(), dsk.cpu().clone()
+    t = L.hvn_top()
+    t.kind, t.dy, t.dx, t.y = 7, view_of(dy), view_of(dlo), view_of(dsk, 4, 4, 12, 12)
+    run_tops([t], n)
+    close(dlo.cpu() - lo0, train_interp.upadd_bwd_ref(dy.cpu()), 1e-5, "dlo")
+    d = dsk.cpu() - sk0
+    close(d[:, 4:16, 4:16], dy.cpu(), 1e-6, "dskip")
+    d[:, 4:16, 4:16] = 0
+    assert float(d.abs().max()) == 0.0
+    # head backward
+    C = 5
+    a = torch.randn(n, 10, 10, 64, generator=g).cuda()
+    da = torch.randn(n, 10, 10, 64, generator=g).cuda()
+    da0 = da.cpu().clone()
+    dl = torch.randn(n, C, 10, 10, generator=g).cuda()
+    W_ = torch.randn(C, 64, generator=g).cuda()
+    dW, db = torch.zeros(C, 64, device="cuda"), torch.zeros(C, device="cuda")
+    t = L.hvn_top()
+    t.kind, t.cout, t.x, t.dx = 8, C, view_of(a), view_of(da)
+    t.p[0], t.p[1], t.p[2], t.p[3] = dl.data_ptr(), W_.data_ptr(), dW.data_ptr(), db.data_ptr()
+    run_tops([t], n)
+    close(dW, torch.einsum("nchw,nhwk->ck", dl.cpu(), a.cpu()), 1e-4, "head dW")
+    close(db, dl.cpu().sum((0, 2, 3)), 1e-4, "head db")
+    close(da.cpu() - da0, torch.einsum("nchw,ck->nhwk", dl.cpu(), W_.cpu()), 1e-4, "head da")
+    # conv0 weight gradient (+ the packer's conv0 mode and the relu-less conv0 forward)
+    for pad, S in ((0, 38), (3, 32)):
+        img = torch.randint(0, 256, (n, S, S, 3), generator=g, dtype=torch.uint8).cuda()
+        so = S + 2 * pad - 6
+        dz = torch.randn(n, so, so, 64, generator=g).cuda()
+        dw = torch.zeros(64 * 147, device="cuda")
+        t = L.hvn_top()
+        t.kind, t.pad_t = 6, pad
+        t.x.base, t.x.sn, t.x.sy, t.x.sx, t.x.h, t.x.w, t.x.c, t.x.sc = img.data_ptr(), S * S * 3, S * 3, 3, S, S, 3, 1
+        t.dy = view_of(dz)
+        t.p[0] = dw.data_ptr()
+        run_tops([t], n)
+        xp = F.pad(img.cpu().float().permute(0, 3, 1, 2) / 255.0, (pad, pad, pad, pad))
+        want = torch.nn.grad.conv2d_weight(xp, (64, 3, 7, 7), dz.cpu().permute(0, 3, 1, 2).contiguous())
+        close(dw.cpu().view(64, 7, 7, 3).permute(0, 3, 1, 2), want, 2e-4, "conv0 wgrad")
+        w0 = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+        packed = torch.zeros(147 * 64, device="cuda")
+        src = chlast(w0)
+        tp = L.hvn_top()
+        tp.kind, tp.mode, tp.lead_pad, tp.cout, tp.cin_g, tp.groups, tp.kh, tp.kw = 2, 2, 64, 64, 3, 1, 7, 7
+        tp.p[0], tp.p[1] = src.data_ptr(), packed.data_ptr()
+        zb = torch.zeros(n, so, so, 64, device="cuda")
+        zero = torch.zeros(64, device="cuda")
+        o = L.hvn_op()
+        o.kind, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.relu, o.cout, o.x_dtype = 1, 7, 7, 1, pad, pad, 0, 64, 0
+        o.x.base, o.x.sn, o.x.sy, o.x.sx, o.x.h, o.x.w, o.x.c, o.x.sc = img.data_ptr(), S * S * 3, S * 3, 3, S, S, 3, 1
+        o.y = view_of(zb)
+        o.w, o.bias = packed.data_ptr(), zero.data_ptr()
+        tn = L.hvn_top()
+        tn.kind, tn.net = 1, ctypes.pointer(o)
+        run_tops([tp, tn], n)
+        close(zb, F.conv2d(xp, w0).permute(0, 2, 3, 1), 1e-4, "conv0 forward (no relu)")
+
+
+@pytest.mark.parametrize("nt", [None, 5])
+def test_losses_and_logit_gradients(nt):
+    from hover_net_amd import lib as L
+    from hover_net_amd.synth import synth_train_batch
+    from oracle import train_torch
+    n, h = 3, 80
+    batch = synth_train_batch(n, "original", nt, seed=21)
+    g = torch.Generator().manual_seed(5)
+    logits = {"np": torch.randn(n, 2, h, h, generator=g) * 2, "hv": torch.randn(n, 2, h, h, generator=g)}
+    if nt:
+        logits = {"tp": torch.randn(n, nt, h, h, generator=g) * 2, **logits}
+    logits["np"][0, :, :4, :4] = torch.tensor([40.0, -40.0]).view(2, 1, 1)    # saturated pixels: the clamp gates the bce gradient
+    lg = {k: v.clone().requires_grad_(True) for k, v in logits.items()}
+    total, terms = train_torch.loss_terms(lg, {k: torch.as_tensor(v) for k, v in batch.items()}, nt)
+    total.backward()
+    dev = {k: v.cuda() for k, v in logits.items()}
+    grads = {k: torch.zeros_like(v) for k, v in dev.items()}
+    t_np = torch.as_tensor(batch["np_map"]).to(torch.int32).cuda()
+    t_hv = torch.as_tensor(batch["hv_map"]).cuda()
+    t_tp = torch.as_tensor(batch["tp_map"]).to(torch.int32).cuda() if nt else None
+    sums = torch.zeros(64, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(n, h, h, 2, device="cuda")
+    d = L.hvn_loss()
+    d.logits_np, d.logits_hv, d.grad_np, d.grad_hv = dev["np"].data_ptr(), dev["hv"].data_ptr(), grads["np"].data_ptr(), grads["hv"].data_ptr()
+    if nt:
+        d.logits_tp, d.grad_tp, d.true_tp = dev["tp"].data_ptr(), grads["tp"].data_ptr(), t_tp.data_ptr()
+    d.true_np, d.true_hv, d.sums, d.sobel_ws = t_np.data_ptr(), t_hv.data_ptr(), sums.data_ptr(), ws.data_ptr()
+    d.n, d.h, d.w, d.nr_types = n, h, h, nt or 0
+    d.total_pixels = float(n * h * h)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.lib().hvn_loss_forward(ctypes.byref(d), s) == 0, L.lib().hvn_train_last_error()
+    assert L.lib().hvn_loss_backward(ctypes.byref(d), s) == 0, L.lib().hvn_train_last_error()
+    torch.cuda.synchronize()
+    sm = sums.cpu().numpy()
+    m = n * h * h
+    got = {"loss_np_bce": sm[0] / m, "loss_hv_mse": sm[2] / (2 * m), "loss_hv_msge": sm[3] / (sm[4] + 1e-8),
+           "loss_np_dice": sum(1 - (2 * sm[8 + c] + 1e-3) / (sm[10 + c] + sm[12 + c] + 1e-3) for c in range(2))}
+    if nt:
+        got["loss_tp_bce"] = sm[1] / m
+        got["loss_tp_dice"] = sum(1 - (2 * sm[16 + c] + 1e-3) / (sm[32 + c] + sm[48 + c] + 1e-3) for c in range(nt))
+    for k, v in got.items():
+        assert abs(v - float(terms[k])) <= 2e-5 * max(1.0, abs(float(terms[k]))), (k, v, float(terms[k]))
+    for k in logits:
+        close(grads[k], lg[k].grad, 2e-4, "dlogits " + k)
+
+
+def test_adam_matches_torch():
+    from hover_net_amd import lib as L
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    w0 = torch.randn(n + 1, generator=g)[:n]
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adam([p], lr=1e-4, betas=(0.9, 0.999))
+    w = torch.zeros(n + 61, device="cuda")
+    w[:n] = w0.cuda()
+    m, v, gr = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in range(1, 4):
+        gstep = torch.randn(n, generator=g)
+        p.grad = gstep.clone()
+        opt.step()
+        gr[:n] = gstep.cuda()
+        assert L.lib().hvn_adam_step(w.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, step, s) == 0
+        torch.cuda.synchronize()
+        assert float((w[:n].cpu() - p.data).abs().max()) < 2e-7
+    assert float(w[n:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm()) / (float(b.double().norm()) + 1e-30)
+
+
+@pytest.mark.parametrize("case", ["orig5_freeze", "orig5_full", "fastseg_full"])
+def test_training_step_matches_oracle(case):
+    """forward (train-mode BN) -> losses -> backward on the HIP path vs the training oracle: loss terms, logits,
+    running stats, and every parameter gradient within a small multiple of torch-fp32's own distance to a
+    float64 run of the same oracle."""
+    from test_oracle_train import load_case
+    from hover_net_amd import net_desc
+    from hover_net_amd.synth import synth_state_dict, synth_train_batch
+    from hover_net_amd.train_engine import TrainEngine
+    from oracle import train_torch
+    gold, mode, nt, freeze = load_case(case)
+    n = int(gold["n"])
+    sd = synth_state_dict(mode, nt, seed=int(gold["wseed"]))
+    batch = synth_train_batch(n, mode, nt, seed=int(gold["bseed"]))
+    torch.set_num_threads(max(8, (os.cpu_count() or 8) // 2))
+    r32 = train_torch.train_step(sd, batch, mode, nt, freeze)
+    r64 = train_torch.train_step(sd, batch, mode, nt, freeze, dtype=torch.float64)
+    net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda")
+    eng = TrainEngine(net, n)
+    eng.load_batch(batch)
+    logits = eng.forward()
+    eng.loss_and_backward()
+    torch.cuda.synchronize()
+    terms = eng.loss_terms()
+    gterms = dict(zip([str(k) for k in gold["term_names"]], gold["term_values"]))
+    for k, v in gterms.items():
+        assert abs(terms[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, terms[k], v)
+    assert abs(terms["overall_loss"] - float(gold["loss"])) <= 1e-3 * float(gold["loss"])
+    for k, v in logits.items():
+        assert float((v.cpu() - r64["logits"][k].float()).abs().max()) < 1e-3, k
+    params = dict(net.named_parameters())
+    bufs = dict(net.named_buffers())
+    for k, v in r64["new_stats"].items():
+        assert float((bufs[k].cpu() - v.float()).abs().max()) <= 1e-4 * (float(v.abs().max()) + 1e-6), k
+    have = {k for k, p in params.items() if p.grad is not None}
+    assert have == {k for k, g in r64["grads"].items() if g is not None}
+    worst = (0.0, None)
+    for k in sorted(have):
+        g64 = r64["grads"][k]
+        e_hip = _rel_l2(params[k].grad.cpu(), g64)
+        e_t32 = _rel_l2(r32["grads"][k], g64)
+        assert e_hip <= 4.0 * e_t32 + 2e-4, (k, e_hip, e_t32)
+        if e_hip > worst[0]:
+            worst = (e_hip, k)
+    print("worst relative L2 gradient error vs float64:", worst)
+    # goldens from the reference itself: gradient norms (fp32 noise level)
+    for k, has, norm in zip(gold["grad_keys"], gold["grad_has"], gold["grad_norms"]):
+        if has:
+            got = float(params[str(k)].grad.double().norm())
+            assert abs(got - norm) <= 5e-2 * norm + 1e-7, (str(k), got, norm)
+
+
+def test_optimizer_step_updates_the_slab_the_kernels_read():
+    from hover_net_amd import net_desc
+    from hover_net_amd.optim import FusedAdam
+    from hover_net_amd.synth import synth_state_dict, synth_train_batch
+    from hover_net_amd.train_engine import TrainEngine
+    mode, nt = "original", None
+    sd = synth_state_dict(mode, nt, seed=9)
+    nets, engs = [], []
+    batch = synth_train_batch(2, mode, nt, seed=31)
+    for _ in range(2):
+        net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=True)
+        net.load_state_dict(sd, strict=True)
+        net = net.to("cuda")
+        eng = TrainEngine(net, 2)
+        eng.load_batch(batch)
+        eng.forward()
+        eng.loss_and_backward()
+        nets.append(net)
+        engs.append(eng)
+    ref_opt = torch.optim.Adam(nets[0].parameters(), lr=1e-4, betas=(0.9, 0.999))
+    fused = FusedAdam(nets[1].parameters(), lr=1e-4, betas=(0.9, 0.999))
+    for _ in range(2):
+        ref_opt.step()
+        fused.step()
+    torch.cuda.synchronize()
+    assert fused.fused_launches == 2 and fused.fallback_launches == 0
+    d = float((engs[0].wslab - engs[1].wslab).abs().max())
+    assert d < 1e-6, d
+    p1 = dict(nets[1].named_parameters())["decoder.np.u0.conv.weight"]
+    assert float((p1.detach().cpu() - sd["decoder.np.u0.conv.weight"]).abs().max()) > 1e-5     # the step moved the weights
+    assert p1.data_ptr() >= engs[1].wslab.data_ptr() and p1.data_ptr() < engs[1].wslab.data_ptr() + 4 * engs[1].wslab.numel()
