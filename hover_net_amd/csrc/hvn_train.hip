@@ -771,15 +771,16 @@ __global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long tota
         const int tc = p.t_np[i] != 0;
         const float q = pr[tc] / (pr[0] + pr[1]);
         const float gate = (q > eps && q < 1.f - eps) ? 1.f : 0.f;
-        float D[2], dot = 0.f;
+        double D[2], dot = 0.0;     // the dice term cancels heavily (D[c] - sum_j D[j] p[j]): combine in double
         for (int c = 0; c < 2; ++c) {
             const double I = p.sums[8 + c], den = p.sums[10 + c] + p.sums[12 + c] + smooth;
             const double tcf = c == tc ? 1.0 : 0.0;
-            D[c] = (float)(-(2.0 * tcf * den - (2.0 * I + smooth)) / (den * den));
-            dot += D[c] * pr[c];
+            D[c] = -(2.0 * tcf * den - (2.0 * I + smooth)) / (den * den);
+            dot += D[c] * (double)pr[c];
         }
         float *d = p.d_np + (long)n * 2 * plane + pix;
-        for (int c = 0; c < 2; ++c) d[c * plane] = gate * (pr[c] - (c == tc ? 1.f : 0.f)) / (float)M + pr[c] * (D[c] - dot);
+        for (int c = 0; c < 2; ++c)
+            d[c * plane] = (float)((double)gate * ((double)pr[c] - (c == tc ? 1.0 : 0.0)) / M + (double)pr[c] * (D[c] - dot));
     }
     if (p.T > 0) {
         const float *l = p.l_tp + (long)n * p.T * plane + pix;
@@ -799,15 +800,16 @@ __global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long tota
         const int tc = p.t_tp[i];
         const float q = pr[tc] / ps;
         const float gate = (q > eps && q < 1.f - eps) ? 1.f : 0.f;
-        float D[16], dot = 0.f;
+        double D[16], dot = 0.0;
         for (int c = 0; c < p.T; ++c) {
             const double I = p.sums[16 + c], den = p.sums[32 + c] + p.sums[48 + c] + smooth;
             const double tcf = c == tc ? 1.0 : 0.0;
-            D[c] = (float)(-(2.0 * tcf * den - (2.0 * I + smooth)) / (den * den));
-            dot += D[c] * pr[c];
+            D[c] = -(2.0 * tcf * den - (2.0 * I + smooth)) / (den * den);
+            dot += D[c] * (double)pr[c];
         }
         float *d = p.d_tp + (long)n * p.T * plane + pix;
-        for (int c = 0; c < p.T; ++c) d[c * plane] = gate * (pr[c] - (c == tc ? 1.f : 0.f)) / (float)M + pr[c] * (D[c] - dot);
+        for (int c = 0; c < p.T; ++c)
+            d[c * plane] = (float)((double)gate * ((double)pr[c] - (c == tc ? 1.0 : 0.0)) / M + (double)pr[c] * (D[c] - dot));
     }
     {
         const float *l = p.l_hv + (long)n * 2 * plane;

@@ -302,18 +302,20 @@ class TrainEngine:
         self.net._train_version = getattr(self.net, "_train_version", 0) + 1    # invalidates the cached inference plan
         return self.logits
 
-    def loss_and_backward(self, world=1, all_reduce=None):
-        """Loss stage 1 -> (all-reduce of the partial sums) -> logit gradients -> backward plan.
-        Returns the loss terms as a float64 CPU tensor of raw sums (see loss_terms())."""
+    def loss_forward(self):
+        """Zero the gradient memory, run loss stage 1 -> this rank's partial sums (device float64 [64])."""
         lib = L.lib()
-        s = self._stream()
         self.gmem.zero_()
         self.sums.zero_()
-        rc = lib.hvn_loss_forward(ctypes.byref(self._loss), s)
+        rc = lib.hvn_loss_forward(ctypes.byref(self._loss), self._stream())
         if rc:
             raise L.HvnError("hvn_loss_forward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
-        if all_reduce is not None:
-            all_reduce(self.sums)
+        return self.sums
+
+    def backward(self, world=1):
+        """Loss stage 2 (logit gradients from the -- possibly all-reduced -- sums) and the backward plan."""
+        lib = L.lib()
+        s = self._stream()
         self._loss.total_pixels = float(world * self.n * self._loss.h * self._loss.w)
         rc = lib.hvn_loss_backward(ctypes.byref(self._loss), s)
         if rc:
@@ -321,6 +323,15 @@ class TrainEngine:
         rc = lib.hvn_run_train_plan(self.bwd_ops, len(self.bwd_ops), self.n, s)
         if rc:
             raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        return self.gslab
+
+    def loss_and_backward(self, world=1, all_reduce=None):
+        """loss stage 1 -> (SUM all-reduce of the partial sums) -> backward -> (SUM all-reduce of the gradient slab).
+        With `all_reduce` = torch.distributed's (RCCL) this is the reference's DataParallel step, one process per GPU."""
+        self.loss_forward()
+        if all_reduce is not None:
+            all_reduce(self.sums)
+        self.backward(world)
         if all_reduce is not None:
             all_reduce(self.gslab)
         return self.sums
