@@ -54,7 +54,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ws, gs, lo, hi = slab
                 lo = lo // 4 * 4
                 n = hi - lo
-                if "m" not in st or st["m"].numel() != n:
+                if "m" not in st or st["m"].numel() != n + 4:
                     st["m"] = torch.zeros(n + 4, dtype=torch.float32, device=dev)
                     st["v"] = torch.zeros(n + 4, dtype=torch.float32, device=dev)
                 rc = lib.hvn_adam_step(ws + 4 * lo, gs + 4 * lo, st["m"].data_ptr(), st["v"].data_ptr(), n, group["lr"], b1, b2,

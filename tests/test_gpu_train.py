@@ -331,6 +331,7 @@ def test_adam_matches_torch():
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for step in range(1, 4):
         gstep = torch.randn(n, generator=g)
+        gstep[: n // 2] *= 10.0 ** torch.randint(-14, -5, (n // 2,), generator=g).float()     # gradients around and below eps
         p.grad = gstep.clone()
         opt.step()
         gr[:n] = gstep.cuda()
@@ -429,7 +430,13 @@ def test_optimizer_step_updates_the_slab_the_kernels_read():
         fused.step()
     torch.cuda.synchronize()
     assert fused.fused_launches == 2 and fused.fallback_launches == 0
-    d = float((engs[0].wslab - engs[1].wslab).abs().max())
+    diff = (engs[0].wslab - engs[1].wslab).abs()
+    d = float(diff.max())
+    if d >= 1e-6:
+        i = int(diff.argmax())
+        key = max((k for k, o in engs[0]._poff.items() if o <= i), key=lambda k: engs[0]._poff[k])
+        print("worst element", i, key, "w_torch", float(engs[0].wslab[i]), "w_fused", float(engs[1].wslab[i]), "g0", float(engs[0].gslab[i]),
+              "g1", float(engs[1].gslab[i]), "trainable", key in engs[0].plan.trainable)
     assert d < 1e-6, d
     p1 = dict(nets[1].named_parameters())["decoder.np.u0.conv.weight"]
     assert float((p1.detach().cpu() - sd["decoder.np.u0.conv.weight"]).abs().max()) > 1e-5     # the step moved the weights
