@@ -143,6 +143,8 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.mat = op->w; a.bias = op->bias;
         a.N = batch; a.H = in ? op->x.h : op->y.h; a.W = in ? op->x.w : op->y.w; a.C = in ? op->x.c : op->y.c;
         a.ty = op->kh; a.tx = op->kw; a.pad = op->pad_t; a.relu = op->relu;
+        a.accum = (!in && op->res.base != nullptr) ? 1 : 0;
+        if (a.accum && op->res.base != op->y.base) return fail(HVN_E_ARG, "wino_out: res must alias y (accumulate in place)%s", "");
         const int n2 = in ? op->y.h : op->x.h;       // transform positions: 36 -> F(2x2,5x5), 64 -> F(4x4,5x5)
         a.m = n2 == 36 ? 2 : n2 == 64 ? 4 : 0;
         if (!a.m) return fail(HVN_E_ARG, "winograd transform: %s%ld transform positions (36 or 64 expected)", "", (long)n2);

@@ -79,6 +79,7 @@ struct WinoArgs {
     int N, H, W, C;       // WINO_IN: input window extent / channels; WINO_OUT: output extent / cout
     int ty, tx, pad, relu;
     int m;                // output tile edge: 2 or 4
+    int accum;            // WINO_OUT: y += result (data gradients accumulate)
 };
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream);
 int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream);
@@ -90,6 +91,7 @@ struct PackArgs {
     int cout, cin_g, groups, taps;
     int mode;             // 0 forward [lead_pad][cin/32][taps][32]; 1 dgrad [lead_pad][cout/32][taps][32] (transposed, taps flipped); 2 conv0
     int lead_pad;         // padded leading dimension (multiple of the conv kernel's column tile)
+    const float *gmat;    // modes 3 / 4 (Winograd F(4x4,5x5) transforms U = G g G^T, forward / data-gradient): G [8][5]
 };
 int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream);
 

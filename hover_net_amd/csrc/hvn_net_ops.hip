@@ -290,8 +290,10 @@ __global__ __launch_bounds__(256) void hvn_wino_out(const WinoArgs p, long total
             for (int b = 0; b < NW; ++b) s = __builtin_elementwise_fma((VT)(at[r * NW + b]), tmp[q][b], s);
             s = __builtin_elementwise_max(s, (VT)(lo));
             const int oy = MO * tyi + q, ox = MO * txi + r;
-            if (oy < p.H && ox < p.W)   // partial last tile when the output extent is not a multiple of m
-                *(VT *)(dst + (long)oy * p.ysy + (long)ox * p.ysx) = s;
+            if (oy < p.H && ox < p.W) {  // partial last tile when the output extent is not a multiple of m
+                VT *d = (VT *)(dst + (long)oy * p.ysy + (long)ox * p.ysx);
+                *d = p.accum ? *d + s : s;
+            }
         }
 }
 

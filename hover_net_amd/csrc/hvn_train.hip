@@ -69,9 +69,45 @@ __global__ __launch_bounds__(256) void hvn_pack_w(const PackArgs p, long total)
     p.dst[i] = v;
 }
 
+// Winograd F(4x4,5x5) weight transform U[a*8+b] = sum_{r,s} G[a][r] g[r][s] G[b][s] (double accumulate), written in the
+// batched-GEMM layout [64][lead_pad][k/32][32].  mode 3: forward (rows = cout, k = cin); mode 4: data gradient
+// (rows = cin, k = cout, taps flipped: g'[r][s] = g[4-r][4-s]).
+__global__ __launch_bounds__(256) void hvn_pack_wino(const PackArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int K = p.mode == 3 ? p.cin_g : p.cout;
+    const int rows = p.mode == 3 ? p.cout : p.cin_g;
+    const int k = (int)(i % K);
+    long t = i / K;
+    const int row = (int)(t % p.lead_pad);
+    const int pos = (int)(t / p.lead_pad);
+    const int a = pos >> 3, b = pos & 7;
+    double acc = 0.0;
+    if (row < rows) {
+        const int co = p.mode == 3 ? row : k, ci = p.mode == 3 ? k : row;
+        const float *g = p.src + (long)co * 25 * p.cin_g + ci;
+        for (int r = 0; r < 5; ++r) {
+            double inner = 0.0;
+            for (int s2 = 0; s2 < 5; ++s2) {
+                const int tap = p.mode == 3 ? r * 5 + s2 : (4 - r) * 5 + (4 - s2);
+                inner += (double)g[(long)tap * p.cin_g] * (double)p.gmat[b * 5 + s2];
+            }
+            acc += (double)p.gmat[a * 5 + r] * inner;
+        }
+    }
+    p.dst[i] = (float)acc;
+}
+
 int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream)
 {
     long total;
+    if (a.mode == 3 || a.mode == 4) {
+        if (a.groups != 1 || a.taps != 25 || !a.gmat) return -1;
+        total = 64L * a.lead_pad * (a.mode == 3 ? a.cin_g : a.cout);
+        hipLaunchKernelGGL(hvn_pack_wino, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+        return launch_ok();
+    }
     if (a.mode == 2)
         total = 64L * a.taps * 3;
     else if (a.mode == 0)
@@ -319,12 +355,12 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
         mean = *(const f32x4 *)(p.save + 2 * p.C + q * 4);
         rstd = *(const f32x4 *)(p.save + 3 * p.C + q * 4);
     }
-    const long rows = (long)p.N * p.H * p.W;
-    for (long r = (long)blockIdx.y * rper + rsub; r < rows && act; r += (long)gridDim.y * rper) {
-        const int x = (int)(r % p.W);
-        const long t = r / p.W;
-        const int y = (int)(t % p.H);
-        const int n = (int)(t / p.H);
+    const unsigned rows = (unsigned)p.N * p.H * p.W, W = p.W, H = p.H;   // < 2^31 (validated on the host)
+    for (unsigned r = blockIdx.y * rper + rsub; r < rows && act; r += gridDim.y * rper) {
+        const unsigned t = r / W;
+        const unsigned x = r - t * W;
+        const unsigned n = t / H;
+        const unsigned y = t - n * H;
         const f32x4 z = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
         if (MODE == 0) {
 #pragma unroll
@@ -401,14 +437,14 @@ __global__ void hvn_bn_bwd_final(const BnArgs p)
 template <int MODE>
 __global__ __launch_bounds__(256) void hvn_bn_apply(const BnArgs p, long total)
 {
-    const int CQ = p.C >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % CQ);
-        long t = i / CQ;
-        const int x = (int)(t % p.W);
-        t /= p.W;
-        const int y = (int)(t % p.H);
-        const int n = (int)(t / p.H);
+    const unsigned CQ = p.C >> 2, W = p.W, H = p.H;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {   // total < 2^31 (host)
+        unsigned t = i / CQ;
+        const unsigned q = i - t * CQ;
+        const unsigned t2 = t / W;
+        const unsigned x = t - t2 * W;
+        const unsigned n = t2 / H;
+        const unsigned y = t2 - n * H;
         const f32x4 z = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
         if (MODE == 0) {
             const f32x4 sc = *(const f32x4 *)(p.save + q * 4), sh = *(const f32x4 *)(p.save + p.C + q * 4);
@@ -451,7 +487,7 @@ static void bn_grid(const BnArgs &a, dim3 &grid, int &lq)
 
 int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
 {
-    if (a.C % 4) return -1;
+    if (a.C % 4 || (long)a.N * a.H * a.W * (a.C / 4) >= (1L << 31)) return -1;
     dim3 grid;
     bn_grid(a, grid, a.lq);
     hipLaunchKernelGGL(hvn_bn_reduce<0>, grid, dim3(256), 0, stream, a);
@@ -465,7 +501,7 @@ int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
 
 int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
 {
-    if (a.C % 4) return -1;
+    if (a.C % 4 || (long)a.N * a.H * a.W * (a.C / 4) >= (1L << 31)) return -1;
     dim3 grid;
     bn_grid(a, grid, a.lq);
     hipLaunchKernelGGL(hvn_bn_reduce<1>, grid, dim3(256), 0, stream, a);
@@ -484,14 +520,14 @@ int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
 // =========================================================================================
 __global__ __launch_bounds__(256) void hvn_upadd_bwd(const UpAddBwdArgs p, long total)
 {
-    const int CQ = p.C >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % CQ);
-        long t = i / CQ;
-        const int x = (int)(t % (p.W / 2));
-        t /= (p.W / 2);
-        const int y = (int)(t % (p.H / 2));
-        const int n = (int)(t / (p.H / 2));
+    const unsigned CQ = p.C >> 2, W2 = p.W / 2, H2 = p.H / 2;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256) {
+        const unsigned t = i / CQ;
+        const unsigned q = i - t * CQ;
+        const unsigned t2 = t / W2;
+        const unsigned x = t - t2 * W2;
+        const unsigned n = t2 / H2;
+        const unsigned y = t2 - n * H2;
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -515,6 +551,7 @@ int hvn_launch_upadd_bwd(const UpAddBwdArgs &a, hipStream_t stream)
 {
     if (a.C % 4 || a.H % 2 || a.W % 2) return -1;
     const long total = (long)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
+    if (total >= (1L << 31)) return -1;
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(hvn_upadd_bwd, dim3((unsigned)blocks), dim3(256), 0, stream, a, total);

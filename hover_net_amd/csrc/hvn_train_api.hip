@@ -27,8 +27,10 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
         PackArgs a;
         a.src = (const float *)t->p[0]; a.dst = (float *)t->p[1];
         a.cout = t->cout; a.cin_g = t->cin_g; a.groups = t->groups > 1 ? t->groups : 1; a.taps = t->kh * t->kw;
-        a.mode = t->mode; a.lead_pad = t->lead_pad;
+        a.mode = t->mode; a.lead_pad = t->lead_pad; a.gmat = (const float *)t->p[2];
         if (!a.src || !a.dst) return tfail(HVN_E_ARG, "pack: null pointer", idx);
+        if ((a.mode == 3 || a.mode == 4) && (!a.gmat || a.taps != 25 || a.groups != 1 || (a.mode == 3 ? a.cin_g : a.cout) % 32))
+            return tfail(HVN_E_ARG, "pack: Winograd transform needs a 5x5 ungrouped conv, G and k % 32 == 0", idx);
         if (a.mode == 0 && ((a.cin_g * a.groups) % 32 || a.lead_pad < a.cout)) return tfail(HVN_E_ARG, "pack: forward needs cin % 32 == 0", idx);
         if (a.mode == 1 && (a.cout % 32 || a.lead_pad < a.cin_g * a.groups)) return tfail(HVN_E_ARG, "pack: dgrad needs cout % 32 == 0", idx);
         return hvn_launch_pack_w(a, s);

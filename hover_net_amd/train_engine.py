@@ -20,7 +20,8 @@ import torch
 from . import arch
 from . import lib as L
 from . import train_plan as TP
-from .plan import OP_CONV, OP_CONV0, OP_HEAD, OP_UPADD, _tile_n
+from . import winograd as WG
+from .plan import OP_CONV, OP_CONV0, OP_HEAD, OP_UPADD, OP_WINO_IN, OP_WINO_OUT, _tile_n
 
 T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD_BWD = 1, 2, 3, 4, 5, 6, 7, 8
 MOMENTUM = 0.1
@@ -69,7 +70,14 @@ class TrainEngine:
             self._bn_save_off[k] = off
             off += 4 * c
         self.zero_bias = torch.zeros(64, dtype=torch.float32, device=dev)
+        # 5x5 stride-1 convs (decoder conva, 51 % of the forward FLOPs) and their data gradients run as Winograd
+        # F(4x4,5x5) like the inference plan (plan.py:conv_winograd); HVN_TRAIN_WINOGRAD=0 keeps them direct
+        self.use_wino = os.environ.get("HVN_TRAIN_WINOGRAD", "1") != "0"
+        at, gm, bt = WG.MATS[4]
+        self.wino_mats = torch.tensor(list(bt.reshape(-1)) + list(at.reshape(-1)) + list(gm.reshape(-1)), dtype=torch.float32, device=dev)
+        self._bt_ptr, self._at_ptr, self._g_ptr = (self.wino_mats.data_ptr() + 4 * o for o in (0, 64, 96))
         self._alloc_packs()
+        self._alloc_wino_scratch()
         self._nbt = [self._buffers[k + ".num_batches_tracked"] for k in P.bns]
         self.fwd_ops = self._lower([self._pack_ops()] + [self._lower_fwd(op) for op in P.fwd])
         self.bwd_ops = self._lower([self._lower_bwd(op) for op in P.bwd])
@@ -119,18 +127,24 @@ class TrainEngine:
         return self.gslab.data_ptr() + 4 * self._poff[key]
 
     # -- packed weights --------------------------------------------------------------------------------
+    def _is_wino(self, c):
+        return self.use_wino and c["kh"] == 5 and c["kw"] == 5 and c["groups"] == 1
+
     def _alloc_packs(self):
+        """Per conv: the packed forward weights (mode 0) and, if its input needs a gradient, the transposed /
+        flipped data-gradient weights (mode 1); Winograd convs hold the transformed U instead (modes 3 / 4)."""
         P = self.plan
         self._pack_off, total = {}, 0
         for key, c in P.convs.items():
             cin = c["cin_g"] * c["groups"]
-            taps = c["kh"] * c["kw"]
+            taps = 64 if self._is_wino(c) else c["kh"] * c["kw"]
+            fm, dm = (3, 4) if self._is_wino(c) else (0, 1)
             lead = _align(c["cout"], _tile_n(c["cout"]))
-            self._pack_off[(key, 0)] = (total, lead)
+            self._pack_off[(key, fm)] = (total, lead)
             total += _align(lead * cin * taps)
             if c["dgrad"]:
                 lead = _align(cin, _tile_n(cin))
-                self._pack_off[(key, 1)] = (total, lead)
+                self._pack_off[(key, dm)] = (total, lead)
                 total += _align(lead * c["cout"] * taps)
         self._pack_off[("conv0./.weight", 2)] = (total, 64)
         total += _align(7 * 7 * 3 * 64)
@@ -151,7 +165,45 @@ class TrainEngine:
                 t.cout, t.cin_g, t.groups, t.kh, t.kw = c["cout"], c["cin_g"], c["groups"], c["kh"], c["kw"]
             t.p[0] = self.wptr(key)
             t.p[1] = self.packs.data_ptr() + 4 * off
+            t.p[2] = self._g_ptr
             ops.append(t)
+        return ops
+
+    def _alloc_wino_scratch(self):
+        """One V / M pair (transform-domain input / product) shared by all Winograd convs of the step."""
+        v = m = 64
+        for op in self.plan.fwd:
+            if op.kind == "conv" and self._is_wino(self.plan.convs[op.wkey]):
+                t = -(-op.y.h // 4) * -(-op.y.w // 4)
+                v, m = max(v, 64 * t * op.x.c), max(m, 64 * t * op.y.c)
+                if op.dx:
+                    t = -(-op.x.h // 4) * -(-op.x.w // 4)
+                    v, m = max(v, 64 * t * op.y.c), max(m, 64 * t * op.x.c)
+        self.wino_v = torch.empty(self.n * v, dtype=torch.float32, device=self.device)
+        self.wino_m = torch.empty(self.n * m, dtype=torch.float32, device=self.device)
+
+    def _wino_conv(self, xin, yout, pad, wptr, lead, accumulate):
+        """WINO_IN -> 64 batched GEMMs on the conv kernel -> WINO_OUT for one 5x5 stride-1 convolution of the view
+        `xin` (hvn_view, zero padding `pad`) into the view `yout`."""
+        ty, tx = -(-yout.h // 4), -(-yout.w // 4)
+        t1, cin, cout = ty * tx, xin.c, yout.c
+
+        def tview(ptr, h, c):
+            v = L.hvn_view()
+            v.base, v.sn, v.sy, v.sx, v.h, v.w, v.c, v.sc = ptr, 64 * t1 * c, t1 * c, c, h, t1, c, 1
+            return v
+        vp, mp = self.wino_v.data_ptr(), self.wino_m.data_ptr()
+        ops = [self._net(kind=OP_WINO_IN, kh=ty, kw=tx, pad_t=pad, pad_l=pad, x=xin, y=tview(vp, 64, cin), w=self._bt_ptr)]
+        g = dict(kind=OP_CONV, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, relu=0, cout=cout, tile_n=_tile_n(cout), groups=1,
+                 x=tview(vp, 1, cin), y=tview(mp, 1, cout), w=wptr, nbatch=64)
+        t = self._net(**g)
+        o = self._keep[-1]
+        o.batch_stride[0], o.batch_stride[1], o.batch_stride[2] = t1 * cin, lead * cin, t1 * cout
+        ops.append(t)
+        kw = dict(kind=OP_WINO_OUT, kh=ty, kw=tx, relu=0, cout=cout, x=tview(mp, 64, cout), y=yout, w=self._at_ptr)
+        if accumulate:
+            kw["res"] = yout
+        ops.append(self._net(**kw))
         return ops
 
     # -- views -------------------------------------------------------------------------------------------
@@ -185,6 +237,9 @@ class TrainEngine:
             return [self._net(kind=OP_CONV0, kh=7, kw=7, stride=1, pad_t=op.pad, pad_l=op.pad, relu=0, cout=64, x_dtype=0, x=x,
                               y=self._view(op.y), w=self.pack_ptr(op.wkey, 2),
                               bias=self.zero_bias.data_ptr())]
+        if op.kind == "conv" and self._is_wino(self.plan.convs[op.wkey]) and op.stride == 1 and op.res is None:
+            off, lead = self._pack_off[(op.wkey, 3)]
+            return self._wino_conv(self._view(op.x), self._view(op.y), op.pad[0], self.packs.data_ptr() + 4 * off, lead, False)
         if op.kind == "conv":
             kw = dict(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=op.stride, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.y.c,
                       tile_n=_tile_n(op.y.c), groups=op.groups, x=self._view(op.x), y=self._view(op.y),
@@ -238,6 +293,9 @@ class TrainEngine:
             t.x, t.dy = self._view(op.x), self._view(op.dy)
             t.p[0] = self.gptr(op.wkey)
             return [t]
+        if op.kind == "dgrad" and self._is_wino(self.plan.convs[op.wkey]):
+            off, lead = self._pack_off[(op.wkey, 4)]
+            return self._wino_conv(self._view(op.dy), self._view(op.dx), op.pad[0], self.packs.data_ptr() + 4 * off, lead, True)
         if op.kind == "dgrad":
             dx = self._view(op.dx)
             return [self._net(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=1, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.dx.c,

@@ -61,7 +61,7 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           n = m + 4: x = input view (zero padding pad_t/pad_l), y = V as [n*n][tiles][c] per sample (y.h = n*n = 36
  *           or 64 selects m, y.w = tiles), kh x kw = tile grid, w = B^T (n x n),
  *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [n*n][tiles][cout] per sample, w = A^T (m x n), kh x kw = tile grid
- *           covering y (a partial last tile's surplus outputs are dropped),
+ *           covering y (a partial last tile's surplus outputs are dropped); res = y: accumulate (y += ...),
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
  *   PREDMAP y.base = [n][h][w][3|4] = [argmax(tp)?, softmax(np)[1], hv0, hv1]
@@ -139,7 +139,9 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *                data gradients (stride-1 conv of the -- possibly dilated -- output gradient, res = y to accumulate)
  *   PACK_W       p[0] = weights, p[1] = packed copy for the conv kernel; mode 0 forward ([lead_pad][cin/32][taps][32],
  *                groups expanded block-diagonally), 1 data-gradient (transposed, taps flipped:
- *                [lead_pad][cout/32][taps][32]), 2 conv0 ([7][7][3][64] x 1/255); cout, cin_g, groups, kh, kw
+ *                [lead_pad][cout/32][taps][32]), 2 conv0 ([7][7][3][64] x 1/255); 3 / 4 Winograd F(4x4,5x5) transform
+ *                U = G g G^T of a 5x5 conv for the forward / data-gradient pass ([64][lead_pad][k/32][32], p[2] = G
+ *                [8][5]); cout, cin_g, groups, kh, kw
  *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[2c] (zero on entry and exit),
  *                p[1] = save[4c] (scale, shift, mean, rstd), p[2] = gamma, p[3] = beta, p[4] = running_mean,
  *                p[5] = running_var (updated: momentum, unbiased variance); eps, momentum

@@ -81,6 +81,32 @@ def test_pack_weights_forward_and_dgrad(cout, cin_g, k, groups):
         assert torch.equal(dst.cpu(), torch.from_numpy(want).reshape(-1)), (mode, lead, _tile_n(cin))
 
 
+@pytest.mark.parametrize("cout,cin", [(256, 1024), (64, 256), (128, 512)])
+def test_winograd_weight_transforms(cout, cin):
+    """pack modes 3 / 4: U = G g G^T of the forward weights and of the flipped, transposed data-gradient weights,
+    in the batched-GEMM layout, against hover_net_amd.winograd.transform_weights (float64)."""
+    import train_interp
+    from hover_net_amd import lib as L
+    from hover_net_amd import winograd as WG
+    from hover_net_amd.plan import _tile_n
+    w = torch.randn(cout, cin, 5, 5) * 0.05
+    src = chlast(w)
+    gm = torch.tensor(WG.MATS[4][1].reshape(-1), dtype=torch.float32).cuda()
+    for mode in (3, 4):
+        wt = w if mode == 3 else train_interp.dgrad_weights(w, 1)
+        rows, k = wt.shape[0], wt.shape[1]
+        lead = (rows + _tile_n(rows) - 1) // _tile_n(rows) * _tile_n(rows)
+        u = WG.transform_weights(wt.numpy().astype(np.float64), 4)                  # [64, rows, k]
+        want = np.zeros((64, lead, k), np.float32)
+        want[:, :rows] = u
+        dst = torch.full((want.size,), 7.0, device="cuda")
+        t = L.hvn_top()
+        t.kind, t.mode, t.lead_pad, t.cout, t.cin_g, t.groups, t.kh, t.kw = 2, mode, lead, cout, cin, 1, 5, 5
+        t.p[0], t.p[1], t.p[2] = src.data_ptr(), dst.data_ptr(), gm.data_ptr()
+        run_tops([t], 1)
+        close(dst.cpu().view(64, lead, k), torch.from_numpy(want), 2e-6, "U mode %d" % mode)
+
+
 WG_CASES = [  # n, H, W, cin, cout, k, stride, pad(lo,hi), groups, dy step
     (2, 20, 20, 64, 64, 3, 1, (1, 1), 1, 1),
     (2, 24, 24, 128, 256, 1, 1, (0, 0), 1, 1),
