@@ -74,29 +74,51 @@ __global__ __launch_bounds__(256) void hvn_pack_w(const PackArgs p, long total)
 // (rows = cin, k = cout, taps flipped: g'[r][s] = g[4-r][4-s]).
 __global__ __launch_bounds__(256) void hvn_pack_wino(const PackArgs p, long total)
 {
+    // one thread = one (row, k) filter: 25 taps in, all 64 transform positions out (k fastest: coalesced stores)
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int K = p.mode == 3 ? p.cin_g : p.cout;
     const int rows = p.mode == 3 ? p.cout : p.cin_g;
     const int k = (int)(i % K);
-    long t = i / K;
-    const int row = (int)(t % p.lead_pad);
-    const int pos = (int)(t / p.lead_pad);
-    const int a = pos >> 3, b = pos & 7;
-    double acc = 0.0;
-    if (row < rows) {
-        const int co = p.mode == 3 ? row : k, ci = p.mode == 3 ? k : row;
-        const float *g = p.src + (long)co * 25 * p.cin_g + ci;
+    const int row = (int)(i / K);
+    const long plane = (long)p.lead_pad * K;
+    float *dst = p.dst + (long)row * K + k;
+    if (row >= rows) {
+#pragma unroll
+        for (int pos = 0; pos < 64; ++pos) dst[pos * plane] = 0.f;
+        return;
+    }
+    const int co = p.mode == 3 ? row : k, ci = p.mode == 3 ? k : row;
+    const float *g = p.src + (long)co * 25 * p.cin_g + ci;
+    double gm[40];
+#pragma unroll
+    for (int e = 0; e < 40; ++e) gm[e] = (double)p.gmat[e];
+    double tmp[8][5];   // G g
+#pragma unroll
+    for (int s2 = 0; s2 < 5; ++s2) {
+        double col[5];
+#pragma unroll
         for (int r = 0; r < 5; ++r) {
-            double inner = 0.0;
-            for (int s2 = 0; s2 < 5; ++s2) {
-                const int tap = p.mode == 3 ? r * 5 + s2 : (4 - r) * 5 + (4 - s2);
-                inner += (double)g[(long)tap * p.cin_g] * (double)p.gmat[b * 5 + s2];
-            }
-            acc += (double)p.gmat[a * 5 + r] * inner;
+            const int tap = p.mode == 3 ? r * 5 + s2 : (4 - r) * 5 + (4 - s2);
+            col[r] = (double)g[(long)tap * p.cin_g];
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) acc += gm[a * 5 + r] * col[r];
+            tmp[a][s2] = acc;
         }
     }
-    p.dst[i] = (float)acc;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < 5; ++s2) acc += tmp[a][s2] * gm[b * 5 + s2];
+            dst[(a * 8 + b) * plane] = (float)acc;
+        }
 }
 
 int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream)
@@ -104,7 +126,7 @@ int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream)
     long total;
     if (a.mode == 3 || a.mode == 4) {
         if (a.groups != 1 || a.taps != 25 || !a.gmat) return -1;
-        total = 64L * a.lead_pad * (a.mode == 3 ? a.cin_g : a.cout);
+        total = (long)a.lead_pad * (a.mode == 3 ? a.cin_g : a.cout);
         hipLaunchKernelGGL(hvn_pack_wino, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
         return launch_ok();
     }
@@ -356,27 +378,43 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
         rstd = *(const f32x4 *)(p.save + 3 * p.C + q * 4);
     }
     const unsigned rows = (unsigned)p.N * p.H * p.W, W = p.W, H = p.H;   // < 2^31 (validated on the host)
-    for (unsigned r = blockIdx.y * rper + rsub; r < rows && act; r += gridDim.y * rper) {
-        const unsigned t = r / W;
-        const unsigned x = r - t * W;
-        const unsigned n = t / H;
-        const unsigned y = t - n * H;
-        const f32x4 z = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
-        if (MODE == 0) {
+    const unsigned rstep = gridDim.y * rper;
+    // four independent rows per iteration: the loads of all four are in flight before any is consumed
+    for (unsigned r0 = blockIdx.y * rper + rsub; r0 < rows && act; r0 += 4 * rstep) {
+        f32x4 z[4], a[4], da[4];
+        bool ok[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] += (double)z[e];
-                s[4 + e] += (double)z[e] * (double)z[e];
+        for (int u = 0; u < 4; ++u) {
+            const unsigned r = r0 + u * rstep;
+            ok[u] = r < rows;
+            const unsigned rr = ok[u] ? r : r0;
+            const unsigned t = rr / W;
+            const unsigned x = rr - t * W;
+            const unsigned n = t / H;
+            const unsigned y = t - n * H;
+            z[u] = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
+            if (MODE == 1) {
+                a[u] = *(const f32x4 *)(p.a + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4);
+                da[u] = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
             }
-        } else {
-            const f32x4 a = *(const f32x4 *)(p.a + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4);
-            const f32x4 da = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float g = a[e] > 0.f ? da[e] : 0.f;
-                const float xh = (z[e] - mean[e]) * rstd[e];
-                s[e] += (double)g;
-                s[4 + e] += (double)(g * xh);
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += (double)z[u][e];
+                    s[4 + e] += (double)z[u][e] * (double)z[u][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = a[u][e] > 0.f ? da[u][e] : 0.f;
+                    const float xh = (z[u][e] - mean[e]) * rstd[e];
+                    s[e] += (double)g;
+                    s[4 + e] += (double)(g * xh);
+                }
             }
         }
     }
@@ -479,8 +517,9 @@ static void bn_grid(const BnArgs &a, dim3 &grid, int &lq)
     if (lq < 1) lq = 1;
     const long rows = (long)a.N * a.H * a.W;
     const int rper = 256 / lq;
-    long gy = (rows + rper * 16 - 1) / (rper * 16);   // >= 16 rows per thread
-    if (gy > 1024) gy = 1024;
+    long gy = (rows + rper * 8 - 1) / (rper * 8);     // >= 8 rows (two 4-row iterations) per thread
+    const long cap = 8192 / ((cq + lq - 1) / lq);         // ~8192 workgroups per launch at most
+    if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
     grid = dim3((unsigned)((cq + lq - 1) / lq), (unsigned)gy);
 }

@@ -519,3 +519,43 @@ def test_two_rank_step_equals_dataparallel_semantics():
         assert _rel_l2(got, g64) < 5e-2, (k, _rel_l2(got, g64))
         checked += 1
     assert checked == 262
+
+
+def test_two_phase_schedule_runs_and_learns(tmp_path):
+    """run_phases over get_config's two phases (freeze -> all layers, weights carried over) on a repeated
+    synthetic batch: the loss falls, the frozen encoder keeps its weights in phase 0 and moves in phase 1, the
+    per-epoch checkpoint is in the reference's {"desc": state_dict} format and loads strictly."""
+    from hover_net_amd import arch, net_desc, train
+    mode, nt = "original", None
+    cfg = train.get_config(nt, mode)
+    sd0 = None
+
+    class Fixed:                                             # the same batch every step: the loss must fall
+        def __init__(self, bs, steps):
+            self.b = next(iter(train.SyntheticLoader(bs, 1, mode, nt, seed=77)))
+            self.steps = steps
+
+        def __iter__(self):
+            return iter([self.b] * self.steps)
+
+    def loaders(pi, bs):
+        return {"train": Fixed(2, 6), "valid": Fixed(2, 1)}
+
+    # deterministic start: the seeded synthetic checkpoint instead of the random init of create_model
+    from hover_net_amd.synth import synth_state_dict
+    sd0 = synth_state_dict(mode, nt, seed=2)
+    torch.save({"desc": sd0}, str(tmp_path / "init.tar"))
+    cfg["phase_list"][0]["run_info"]["net"]["pretrained"] = str(tmp_path / "init.tar")
+    hist, net = train.run_phases(cfg, loaders, log_dir=str(tmp_path / "log"), nr_epochs=2)
+    assert [h["phase"] for h in hist] == [0, 0, 1, 1] and all(h["steps"] == 6 and h["valid_steps"] == 1 for h in hist)
+    losses = [h["train"]["overall_loss"] for h in hist]
+    assert all(np.isfinite(losses)) and losses[1] < losses[0] and losses[3] < losses[0], losses
+    ck0 = torch.load(str(tmp_path / "log" / "00" / "net_epoch=2.tar"))["desc"]
+    ck1 = torch.load(str(tmp_path / "log" / "01" / "net_epoch=2.tar"))["desc"]
+    assert list(ck0.keys()) == list(arch.param_table(mode, nt).keys())
+    net_desc.create_model(mode=mode, nr_types=nt, input_ch=3).load_state_dict(ck1, strict=True)
+    k_frozen, k_dec = "d2.units.3.conv2.weight", "decoder.np.u3.conva.weight"
+    assert torch.equal(ck0[k_frozen], sd0[k_frozen])                       # phase 0: encoder frozen
+    assert not torch.equal(ck0[k_dec], sd0[k_dec])                         # decoder trained
+    assert not torch.equal(ck1[k_frozen], ck0[k_frozen])                   # phase 1: everything trains
+    assert float(ck1["d2.units.3.conv2/bn.num_batches_tracked"]) == 24.0   # 2 phases x 2 epochs x 6 train steps
