@@ -106,9 +106,14 @@ struct WgradArgs {
     int N, KH, KW, stride, pad_t, pad_l, groups, Cin_g;
     int tiles_m, tiles_n;
     unsigned rows_per_split;
+    int nbatch;           // > 1: blockIdx.z selects one of nbatch independent problems
+    long xb, db, wb;      // element strides of x, dy, dw between them
 };
 int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream);
+int hvn_launch_wino_dy(const struct WinoArgs &a, hipStream_t stream);
+int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, int cin, hipStream_t stream);
 
+#define HVN_BN_MAX_PARTS 256
 struct BnArgs {
     const float *z;       // conv output (pre-normalisation)
     long zsn, zsy, zsx;
@@ -119,12 +124,12 @@ struct BnArgs {
     long gsn, gsy, gsx;
     float *dz;            // backward: gradient of z (accumulated), may be null
     long dsn, dsy, dsx;
-    double *ws;           // [2*C] zeroed reduction workspace (handed back zeroed)
+    double *ws;           // [HVN_BN_MAX_PARTS][2*C] partial sums (no initialisation needed)
     float *save;          // [4*C] scale, shift, mean, rstd
     float *coef;          // [3*C] backward coefficients
     const float *gamma, *beta;
     float *dgamma, *dbeta, *running_mean, *running_var;
-    int N, H, W, C, lq;
+    int N, H, W, C, lq, nparts;
     float eps, momentum;
 };
 int hvn_launch_bn_forward(BnArgs a, hipStream_t stream);

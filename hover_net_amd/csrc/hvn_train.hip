@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    const float *px = p.x + (long)blockIdx.z * p.xb;      // batched launch: blockIdx.z = one of nbatch independent problems
+    const float *pdy = p.dy + (long)blockIdx.z * p.db;
+    float *pdw = p.dw + (long)blockIdx.z * p.wb;
     int bid = blockIdx.x;
     const int tm = bid % p.tiles_m;
     bid /= p.tiles_m;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (arow[j] < r_end) v = *(const f32x4 *)(p.dy + (long)an[j] * p.dsn + (long)ay[j] * p.dsy + (long)ax[j] * p.dsx + m0 + a_c4 * 4);
+            if (arow[j] < r_end) v = *(const f32x4 *)(pdy + (long)an[j] * p.dsn + (long)ay[j] * p.dsy + (long)ax[j] * p.dsx + m0 + a_c4 * 4);
             ra[j] = v;
             arow[j] += 32;
             advance(an[j], ay[j], ax[j]);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int iy = by[j] * p.stride + tr - p.pad_t, ix = bx[j] * p.stride + tq - p.pad_l;
             if (brow[j] < r_end && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *(const f32x4 *)(p.x + (long)bn_[j] * p.xsn + (long)iy * p.xsy + (long)ix * p.xsx + n0 + b_c4 * 4);
+                v = *(const f32x4 *)(px + (long)bn_[j] * p.xsn + (long)iy * p.xsy + (long)ix * p.xsx + n0 + b_c4 * 4);
             rb[j] = v;
             brow[j] += 32;
             advance(bn_[j], by[j], bx[j]);
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
                     cg = ci - (co / og) * p.Cin_g;
                     if (cg < 0 || cg >= p.Cin_g) continue;
                 }
-                unsafeAtomicAdd(p.dw + ((long)co * taps + tap) * p.Cin_g + cg, acc[i][j][r]);
+                unsafeAtomicAdd(pdw + ((long)co * taps + tap) * p.Cin_g + cg, acc[i][j][r]);
             }
         }
 }
@@ -324,7 +327,8 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream)
     a.tiles_n = a.Cin / BN;
     const long tiles = (long)a.tiles_m * a.tiles_n * a.KH * a.KW;
     const long R = (long)a.N * a.Ho * a.Wo;
-    long ksplit = (1536 + tiles - 1) / tiles;            // ~3 workgroups per slot of the 512 the chip holds
+    const int nb = a.nbatch > 1 ? a.nbatch : 1;
+    long ksplit = (1536 + tiles * nb - 1) / (tiles * nb); // ~3 workgroups per slot of the 512 the chip holds
     const long max_split = (R + 255) / 256;              // at least 8 k-steps per workgroup
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
@@ -338,7 +342,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream)
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)ksplit, (unsigned)nb), dim3(256), lds, stream, a);
     return launch_ok();
 }
 
@@ -356,12 +360,118 @@ int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream)
     return -1;   // (64|32) x (64|32)-only channel counts do not occur in this network
 }
 
+
+// =========================================================================================
+// Weight gradient of a 5x5 stride-1 conv in the Winograd F(4x4,5x5) domain:
+//   dM = A dY A^T per 4x4 output tile (hvn_wino_dy), dU[pos] = sum_tiles dM[pos]^T V[pos] (64 batched
+//   hvn_conv_wgrad_f32 problems over the tiles, V = the forward pass's transformed input, kept), dg += G^T dU G
+//   (hvn_wino_dw).  4 instead of 25 multiplies per output pixel, like the forward pass.
+// =========================================================================================
+template <int VW>
+__global__ __launch_bounds__(256) void hvn_wino_dy(const WinoArgs p, long total)
+{
+    typedef float VT __attribute__((ext_vector_type(VW)));
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cvn = p.C / VW;
+    const int cv = (int)(i % cvn);
+    long t = i / cvn;
+    const int T1 = p.ty * p.tx;
+    const int tile = (int)(t % T1);
+    const int n = (int)(t / T1);
+    const int tyi = tile / p.tx, txi = tile - tyi * p.tx;
+    float at[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) at[k] = p.mat[k];  // A^T [4][8], wave-uniform
+    const float *src = p.x + (long)n * p.xsn + cv * VW;
+    VT tmp[8][4];   // tmp[a][q] = sum_p AT[p][a] d[p][q]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        VT d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int yy = 4 * tyi + r, xx = 4 * txi + q;
+            d[r] = (yy < p.H && xx < p.W) ? *(const VT *)(src + (long)yy * p.xsy + (long)xx * p.xsx) : (VT)(0.f);
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            VT s = (VT)(0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = __builtin_elementwise_fma((VT)(at[r * 8 + a]), d[r], s);
+            tmp[a][q] = s;
+        }
+    }
+    float *dst = p.y + (long)n * p.ysn + (long)tile * p.ysx + cv * VW;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            VT s = (VT)(0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = __builtin_elementwise_fma((VT)(at[q * 8 + b]), tmp[a][q], s);
+            *(VT *)(dst + (long)(a * 8 + b) * p.ysy) = s;
+        }
+}
+
+int hvn_launch_wino_dy(const WinoArgs &a, hipStream_t stream)
+{
+    if (a.C % 2) return -1;
+    const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
+    hipLaunchKernelGGL(hvn_wino_dy<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    return launch_ok();
+}
+
+// dg[co][r][s][ci] += sum_{a,b} G[a][r] dU[a*8+b][co][ci] G[b][s]; one thread = one (co, ci) filter
+__global__ __launch_bounds__(256) void hvn_wino_dw(const float *du, float *dg, const float *gmat, int cout, int cin, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ci = (int)(i % cin);
+    const int co = (int)(i / cin);
+    const long plane = (long)cout * cin;
+    double gm[40];
+#pragma unroll
+    for (int e = 0; e < 40; ++e) gm[e] = (double)gmat[e];
+    double tmp[5][8];   // tmp[r][b] = sum_a G[a][r] dU[a][b]
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        double col[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) col[a] = (double)du[(long)(a * 8 + b) * plane + i];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) acc += gm[a * 5 + r] * col[a];
+            tmp[r][b] = acc;
+        }
+    }
+    float *dst = dg + (long)co * 25 * cin + ci;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 5; ++s2) {
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc += tmp[r][b] * gm[b * 5 + s2];
+            dst[(long)(r * 5 + s2) * cin] += (float)acc;
+        }
+}
+
+int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, int cin, hipStream_t stream)
+{
+    const long total = (long)cout * cin;
+    hipLaunchKernelGGL(hvn_wino_dw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, du, dg, gmat, cout, cin, total);
+    return launch_ok();
+}
+
 // =========================================================================================
 // BatchNorm (train) + ReLU
 // =========================================================================================
 // Per-channel reductions over (n, y, x) of an NHWC view.  MODE 0: sum z, sum z^2.  MODE 1: sum g, sum g*xhat with
 // g = da * (a > 0), xhat = (z - mean) * rstd.  A thread owns one channel quad (LQ lanes per row, 256/LQ rows per
-// block pass), accumulates in double, the block combines through LDS and adds to ws[2*c + {0,1}] with f64 atomics.
+// block pass), accumulates in double (8 rows in flight), the block combines through LDS and writes one partial per
+// (row block, channel) to ws[block][2*c + {0,1}]; the finalize kernels sum the partials in a fixed order.
 template <int MODE>
 __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
 {
@@ -379,12 +489,12 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
     }
     const unsigned rows = (unsigned)p.N * p.H * p.W, W = p.W, H = p.H;   // < 2^31 (validated on the host)
     const unsigned rstep = gridDim.y * rper;
-    // four independent rows per iteration: the loads of all four are in flight before any is consumed
-    for (unsigned r0 = blockIdx.y * rper + rsub; r0 < rows && act; r0 += 4 * rstep) {
-        f32x4 z[4], a[4], da[4];
-        bool ok[4];
+    constexpr int UN = 8;   // independent rows per iteration: all their loads are in flight before any is consumed
+    for (unsigned r0 = blockIdx.y * rper + rsub; r0 < rows && act; r0 += UN * rstep) {
+        f32x4 z[UN], a[UN], da[UN];
+        bool ok[UN];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const unsigned r = r0 + u * rstep;
             ok[u] = r < rows;
             const unsigned rr = ok[u] ? r : r0;
@@ -399,7 +509,7 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UN; ++u) {
             if (!ok[u]) continue;
             if (MODE == 0) {
 #pragma unroll
@@ -425,10 +535,12 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
         for (int k = 1; k < rper; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += red[threadIdx.x + k * LQ][e];
+        // one partial per (row block, channel): no atomics, summed by the finalize kernel in a fixed order
+        double *part = p.ws + (long)blockIdx.y * 2 * p.C;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            unsafeAtomicAdd(p.ws + 2 * (q * 4 + e), s[e]);
-            unsafeAtomicAdd(p.ws + 2 * (q * 4 + e) + 1, s[4 + e]);
+            part[2 * (q * 4 + e)] = s[e];
+            part[2 * (q * 4 + e) + 1] = s[4 + e];
         }
     }
 }
@@ -439,11 +551,14 @@ __global__ void hvn_bn_final(const BnArgs p)
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.C) return;
     const double n = (double)p.N * p.H * p.W;
-    const double mean = p.ws[2 * c] / n;
-    double var = p.ws[2 * c + 1] / n - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < p.nparts; ++k) {
+        s1 += p.ws[(long)k * 2 * p.C + 2 * c];
+        s2 += p.ws[(long)k * 2 * p.C + 2 * c + 1];
+    }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    p.ws[2 * c] = 0.0;      // the workspace is handed back zeroed
-    p.ws[2 * c + 1] = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)p.eps);
     const double sc = (double)p.gamma[c] * rstd;
     p.save[c] = (float)sc;
@@ -461,9 +576,11 @@ __global__ void hvn_bn_bwd_final(const BnArgs p)
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.C) return;
     const double n = (double)p.N * p.H * p.W;
-    const double s1 = p.ws[2 * c], s2 = p.ws[2 * c + 1];
-    p.ws[2 * c] = 0.0;
-    p.ws[2 * c + 1] = 0.0;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < p.nparts; ++k) {
+        s1 += p.ws[(long)k * 2 * p.C + 2 * c];
+        s2 += p.ws[(long)k * 2 * p.C + 2 * c + 1];
+    }
     p.dgamma[c] += (float)s2;
     p.dbeta[c] += (float)s1;
     p.coef[c] = p.gamma[c] * p.save[3 * p.C + c];
@@ -509,26 +626,31 @@ __global__ __launch_bounds__(256) void hvn_bn_apply(const BnArgs p, long total)
     }
 }
 
-static void bn_grid(const BnArgs &a, dim3 &grid, int &lq)
+static void bn_grid(BnArgs &a, dim3 &grid)
 {
     const int cq = a.C / 4;
-    lq = 64;
+    int lq = 64;
     while (lq > cq) lq >>= 1;      // largest power of two <= min(64, cq)
     if (lq < 1) lq = 1;
     const long rows = (long)a.N * a.H * a.W;
     const int rper = 256 / lq;
-    long gy = (rows + rper * 8 - 1) / (rper * 8);     // >= 8 rows (two 4-row iterations) per thread
-    const long cap = 8192 / ((cq + lq - 1) / lq);         // ~8192 workgroups per launch at most
+    const int gx = (cq + lq - 1) / lq;
+    long gy = (rows + rper * 16 - 1) / (rper * 16);   // >= 16 rows (two 8-row iterations) per thread
+    long cap = 1024 / gx;                               // ~1024 workgroups: bandwidth comes from the 8 loads in flight
+    if (cap > HVN_BN_MAX_PARTS) cap = HVN_BN_MAX_PARTS;
+    if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
     if (gy < 1) gy = 1;
-    grid = dim3((unsigned)((cq + lq - 1) / lq), (unsigned)gy);
+    a.lq = lq;
+    a.nparts = (int)gy;
+    grid = dim3((unsigned)gx, (unsigned)gy);
 }
 
 int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
 {
     if (a.C % 4 || (long)a.N * a.H * a.W * (a.C / 4) >= (1L << 31)) return -1;
     dim3 grid;
-    bn_grid(a, grid, a.lq);
+    bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<0>, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 255) / 256), dim3(256), 0, stream, a);
     const long total = (long)a.N * a.H * a.W * (a.C / 4);
@@ -542,7 +664,7 @@ int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
 {
     if (a.C % 4 || (long)a.N * a.H * a.W * (a.C / 4) >= (1L << 31)) return -1;
     dim3 grid;
-    bn_grid(a, grid, a.lq);
+    bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<1>, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 255) / 256), dim3(256), 0, stream, a);
     if (a.dz) {

@@ -71,7 +71,9 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
         a.dw = (float *)t->p[0];
         a.N = batch; a.KH = t->kh; a.KW = t->kw; a.stride = t->stride; a.pad_t = t->pad_t; a.pad_l = t->pad_l;
         a.groups = t->groups > 1 ? t->groups : 1; a.Cin_g = a.Cin / a.groups;
-        if (a.Wo < 11 || a.Ho < 2) return tfail(HVN_E_ARG, "wgrad: output extent too small for the row walker", idx);
+        a.nbatch = t->nbatch > 1 ? t->nbatch : 1;
+        a.xb = t->batch_stride[0]; a.db = t->batch_stride[1]; a.wb = t->batch_stride[2];
+        if (a.Wo < 11 || (a.Ho < 2 && a.Wo < 64)) return tfail(HVN_E_ARG, "wgrad: output extent too small for the row walker", idx);
         if ((long)batch * a.Ho * a.Wo >= (1L << 31)) return tfail(HVN_E_ARG, "wgrad: too many rows", idx);
         int rc = hvn_launch_wgrad(a, s);
         if (rc == -1) return tfail(HVN_E_ARG, "wgrad: unsupported channel counts", idx);
@@ -116,6 +118,21 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
         if (rc == -1) return tfail(HVN_E_ARG, "head backward: 1..16 output channels", idx);
         return rc;
     }
+    case HVN_T_WINO_DY: {
+        WinoArgs a;
+        memset(&a, 0, sizeof(a));
+        if (!view_ok(t->x) || !t->y.base || !al16(t->y.base) || !t->p[0]) return tfail(HVN_E_ARG, "wino_dy: bad arguments", idx);
+        a.x = (const float *)t->x.base; a.xsn = t->x.sn; a.xsy = t->x.sy; a.xsx = t->x.sx;
+        a.y = (float *)t->y.base; a.ysn = t->y.sn; a.ysy = t->y.sy; a.ysx = t->y.sx;
+        a.mat = (const float *)t->p[0];
+        a.N = batch; a.H = t->x.h; a.W = t->x.w; a.C = t->x.c; a.ty = t->kh; a.tx = t->kw; a.m = 4;
+        if (t->y.h != 64 || t->y.w != a.ty * a.tx || t->y.c != a.C || 4 * a.ty < a.H || 4 * a.tx < a.W)
+            return tfail(HVN_E_ARG, "wino_dy: dM must be [64][tiles][c] and the tiles must cover dy", idx);
+        return hvn_launch_wino_dy(a, s);
+    }
+    case HVN_T_WINO_DW:
+        if (!t->p[0] || !t->p[1] || !t->p[2] || t->cout <= 0 || t->cin_g <= 0) return tfail(HVN_E_ARG, "wino_dw: bad arguments", idx);
+        return hvn_launch_wino_dw((const float *)t->p[0], (float *)t->p[1], (const float *)t->p[2], t->cout, t->cin_g, s);
     default:
         return tfail(HVN_E_ARG, "unknown kind", idx);
     }

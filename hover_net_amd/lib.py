@@ -28,7 +28,8 @@ class hvn_top(ctypes.Structure):
     """One launch of the training step (include/hvn.h, training section)."""
     _fields_ = [(k, ctypes.c_int32) for k in ("kind", "kh", "kw", "stride", "pad_t", "pad_l", "groups", "cout", "cin_g", "mode", "lead_pad", "_pad")] + \
                [("x", hvn_view), ("y", hvn_view), ("dx", hvn_view), ("dy", hvn_view), ("p", ctypes.c_void_p * 6),
-                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("net", ctypes.POINTER(hvn_op))]
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("net", ctypes.POINTER(hvn_op)),
+                ("batch_stride", ctypes.c_int64 * 3), ("nbatch", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
 
 
 class hvn_loss(ctypes.Structure):

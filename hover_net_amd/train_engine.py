@@ -23,7 +23,7 @@ from . import train_plan as TP
 from . import winograd as WG
 from .plan import OP_CONV, OP_CONV0, OP_HEAD, OP_UPADD, OP_WINO_IN, OP_WINO_OUT, _tile_n
 
-T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD_BWD = 1, 2, 3, 4, 5, 6, 7, 8
+T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD_BWD, T_WINO_DY, T_WINO_DW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 MOMENTUM = 0.1
 
 
@@ -45,11 +45,21 @@ class TrainEngine:
         data_elems, garena_elems = P.layout(self.n)
         dev = self.device
         self.arena = torch.empty(max(data_elems, 64), dtype=torch.float32, device=dev)
-        # gradient slab + gradient arena in one allocation (one memset per step)
-        self._gtotal = self._slab_elems + garena_elems
+        # 5x5 stride-1 convs (decoder conva, 51 % of the forward FLOPs) run as Winograd F(4x4,5x5) like the inference
+        # plan (plan.py:conv_winograd) in all three passes: forward, data gradient, and the weight gradient in the
+        # transform domain; HVN_TRAIN_WINOGRAD=0 keeps them direct
+        self.use_wino = os.environ.get("HVN_TRAIN_WINOGRAD", "1") != "0"
+        self._du_off, du_total = {}, 0
+        for key, c in P.convs.items():
+            if self._is_wino(c) and c["train"]:
+                self._du_off[key] = du_total
+                du_total += _align(64 * c["cout"] * c["cin_g"])
+        # gradient slab + gradient arena + Winograd-domain weight gradients in one allocation (one memset per step)
+        self._gtotal = self._slab_elems + garena_elems + du_total
         self.gmem = torch.zeros(self._gtotal, dtype=torch.float32, device=dev)
         self.gslab = self.gmem[:self._slab_elems]
-        self.garena = self.gmem[self._slab_elems:]
+        self.garena = self.gmem[self._slab_elems:self._slab_elems + garena_elems]
+        self.wino_du = self.gmem[self._slab_elems + garena_elems:]
         self._point_grads()
         g = P.geo
         self.img = torch.empty((self.n, g["inp"], g["inp"], 3), dtype=torch.uint8, device=dev)
@@ -62,7 +72,7 @@ class TrainEngine:
         self.sums = torch.zeros(64, dtype=torch.float64, device=dev)
         self.sobel_ws = torch.empty((self.n, ho, ho, 2), dtype=torch.float32, device=dev)
         cmax = max(P.bns.values())
-        self.bn_ws = torch.zeros(2 * cmax, dtype=torch.float64, device=dev)
+        self.bn_ws = torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev)     # HVN_BN_MAX_PARTS partial sums
         self.bn_coef = torch.empty(3 * cmax, dtype=torch.float32, device=dev)
         self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
         self._bn_save_off, off = {}, 0
@@ -70,9 +80,6 @@ class TrainEngine:
             self._bn_save_off[k] = off
             off += 4 * c
         self.zero_bias = torch.zeros(64, dtype=torch.float32, device=dev)
-        # 5x5 stride-1 convs (decoder conva, 51 % of the forward FLOPs) and their data gradients run as Winograd
-        # F(4x4,5x5) like the inference plan (plan.py:conv_winograd); HVN_TRAIN_WINOGRAD=0 keeps them direct
-        self.use_wino = os.environ.get("HVN_TRAIN_WINOGRAD", "1") != "0"
         at, gm, bt = WG.MATS[4]
         self.wino_mats = torch.tensor(list(bt.reshape(-1)) + list(at.reshape(-1)) + list(gm.reshape(-1)), dtype=torch.float32, device=dev)
         self._bt_ptr, self._at_ptr, self._g_ptr = (self.wino_mats.data_ptr() + 4 * o for o in (0, 64, 96))
@@ -170,29 +177,40 @@ class TrainEngine:
         return ops
 
     def _alloc_wino_scratch(self):
-        """One V / M pair (transform-domain input / product) shared by all Winograd convs of the step."""
+        """Transform-domain tensors: every trained Winograd conv keeps its forward V (the weight gradient reads it
+        again); one more V and one M are shared by the data gradients / products of the step."""
         v = m = 64
+        self.wino_vs = {}
         for op in self.plan.fwd:
             if op.kind == "conv" and self._is_wino(self.plan.convs[op.wkey]):
                 t = -(-op.y.h // 4) * -(-op.y.w // 4)
-                v, m = max(v, 64 * t * op.x.c), max(m, 64 * t * op.y.c)
+                m = max(m, 64 * t * op.y.c)
+                if op.train:
+                    self.wino_vs[op.wkey] = torch.empty(self.n * 64 * t * op.x.c, dtype=torch.float32, device=self.device)
+                else:
+                    v = max(v, 64 * t * op.x.c)
                 if op.dx:
                     t = -(-op.x.h // 4) * -(-op.x.w // 4)
                     v, m = max(v, 64 * t * op.y.c), max(m, 64 * t * op.x.c)
         self.wino_v = torch.empty(self.n * v, dtype=torch.float32, device=self.device)
         self.wino_m = torch.empty(self.n * m, dtype=torch.float32, device=self.device)
 
-    def _wino_conv(self, xin, yout, pad, wptr, lead, accumulate):
+    @staticmethod
+    def _tview(ptr, t1, h, c):
+        """[64][tiles][c]-per-sample transform-domain tensor as a view (h = 64: all positions, h = 1: one position)."""
+        v = L.hvn_view()
+        v.base, v.sn, v.sy, v.sx, v.h, v.w, v.c, v.sc = ptr, 64 * t1 * c, t1 * c, c, h, t1, c, 1
+        return v
+
+    def _wino_conv(self, xin, yout, pad, wptr, lead, accumulate, vbuf=None):
         """WINO_IN -> 64 batched GEMMs on the conv kernel -> WINO_OUT for one 5x5 stride-1 convolution of the view
         `xin` (hvn_view, zero padding `pad`) into the view `yout`."""
         ty, tx = -(-yout.h // 4), -(-yout.w // 4)
         t1, cin, cout = ty * tx, xin.c, yout.c
 
         def tview(ptr, h, c):
-            v = L.hvn_view()
-            v.base, v.sn, v.sy, v.sx, v.h, v.w, v.c, v.sc = ptr, 64 * t1 * c, t1 * c, c, h, t1, c, 1
-            return v
-        vp, mp = self.wino_v.data_ptr(), self.wino_m.data_ptr()
+            return self._tview(ptr, t1, h, c)
+        vp, mp = (self.wino_v if vbuf is None else vbuf).data_ptr(), self.wino_m.data_ptr()
         ops = [self._net(kind=OP_WINO_IN, kh=ty, kw=tx, pad_t=pad, pad_l=pad, x=xin, y=tview(vp, 64, cin), w=self._bt_ptr)]
         g = dict(kind=OP_CONV, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, relu=0, cout=cout, tile_n=_tile_n(cout), groups=1,
                  x=tview(vp, 1, cin), y=tview(mp, 1, cout), w=wptr, nbatch=64)
@@ -239,7 +257,8 @@ class TrainEngine:
                               bias=self.zero_bias.data_ptr())]
         if op.kind == "conv" and self._is_wino(self.plan.convs[op.wkey]) and op.stride == 1 and op.res is None:
             off, lead = self._pack_off[(op.wkey, 3)]
-            return self._wino_conv(self._view(op.x), self._view(op.y), op.pad[0], self.packs.data_ptr() + 4 * off, lead, False)
+            return self._wino_conv(self._view(op.x), self._view(op.y), op.pad[0], self.packs.data_ptr() + 4 * off, lead, False,
+                                   vbuf=self.wino_vs.get(op.wkey))
         if op.kind == "conv":
             kw = dict(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=op.stride, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.y.c,
                       tile_n=_tile_n(op.y.c), groups=op.groups, x=self._view(op.x), y=self._view(op.y),
@@ -287,6 +306,24 @@ class TrainEngine:
             t.p[3], t.p[4] = self.gptr(k + ".weight"), self.gptr(k + ".bias")
             t.p[5] = self.bn_coef.data_ptr()
             return [t]
+        if op.kind == "wgrad" and op.wkey in self._du_off and op.stride == 1:
+            # Winograd-domain weight gradient: dM = A dY A^T, dU[pos] = dM[pos]^T V[pos] (64 batched problems), dg += G^T dU G
+            ty, tx = -(-op.dy.h // 4), -(-op.dy.w // 4)
+            t1, cin, cout = ty * tx, op.x.c, op.dy.c
+            du = self.wino_du.data_ptr() + 4 * self._du_off[op.wkey]
+            t.kind, t.kh, t.kw = T_WINO_DY, ty, tx
+            t.x, t.y = self._view(op.dy), self._tview(self.wino_m.data_ptr(), t1, 64, cout)
+            t.p[0] = self._at_ptr
+            g = L.hvn_top()
+            g.kind, g.kh, g.kw, g.stride, g.groups, g.nbatch = T_WGRAD, 1, 1, 1, 1, 64
+            g.x = self._tview(self.wino_vs[op.wkey].data_ptr(), t1, 1, cin)
+            g.dy = self._tview(self.wino_m.data_ptr(), t1, 1, cout)
+            g.p[0] = du
+            g.batch_stride[0], g.batch_stride[1], g.batch_stride[2] = t1 * cin, t1 * cout, cout * cin
+            w = L.hvn_top()
+            w.kind, w.cout, w.cin_g = T_WINO_DW, cout, cin
+            w.p[0], w.p[1], w.p[2] = du, self.gptr(op.wkey), self._g_ptr
+            return [t, g, w]
         if op.kind == "wgrad":
             t.kind = T_WGRAD
             t.kh, t.kw, t.stride, t.pad_t, t.pad_l, t.groups = op.kh, op.kw, op.stride, op.pad[0], op.pad[0], op.groups

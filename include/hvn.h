@@ -142,7 +142,7 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *                [lead_pad][cout/32][taps][32]), 2 conv0 ([7][7][3][64] x 1/255); 3 / 4 Winograd F(4x4,5x5) transform
  *                U = G g G^T of a 5x5 conv for the forward / data-gradient pass ([64][lead_pad][k/32][32], p[2] = G
  *                [8][5]); cout, cin_g, groups, kh, kw
- *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[2c] (zero on entry and exit),
+ *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[256][2c] (scratch for the partial sums),
  *                p[1] = save[4c] (scale, shift, mean, rstd), p[2] = gamma, p[3] = beta, p[4] = running_mean,
  *                p[5] = running_var (updated: momentum, unbiased variance); eps, momentum
  *   BN_BWD       x = z, y = a, dy = grad a, dx = grad z (+=, base NULL: none); p[0] = ws, p[1] = save, p[2] = gamma,
@@ -153,15 +153,23 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *   UPADD_BWD    dy = grad of nearest2x(lo) + skip; dx = grad lo (+= 2x2 sums, nullable), y = grad skip (+=, nullable)
  *   HEAD_BWD     x = head input [h][w][64], dx = its grad (+=), p[0] = logit grad NCHW, p[1] = W [cout][64],
  *                p[2] = grad W (+=), p[3] = grad bias (+=); cout
+ *   WGRAD with nbatch > 1: nbatch independent problems, problem b at x.base + b*batch_stride[0], dy.base +
+ *                b*batch_stride[1], p[0] + b*batch_stride[2] (elements) -- the 64 transform positions of the
+ *                Winograd-domain weight gradient of a 5x5 conv:
+ *   WINO_DY      dM = A dY A^T per 4x4 tile of the output gradient: x = dy view, y = dM as [64][tiles][c] per sample,
+ *                p[0] = A^T [4][8], kh x kw = tile grid
+ *   WINO_DW      grad g [cout][25][cin] (p[1]) += G^T dU G of dU [64][cout][cin] (p[0]), p[2] = G [8][5]; cout, cin_g
  */
 enum { HVN_T_NET = 1, HVN_T_PACK_W = 2, HVN_T_BN_FWD = 3, HVN_T_BN_BWD = 4, HVN_T_WGRAD = 5, HVN_T_CONV0_WGRAD = 6,
-       HVN_T_UPADD_BWD = 7, HVN_T_HEAD_BWD = 8 };
+       HVN_T_UPADD_BWD = 7, HVN_T_HEAD_BWD = 8, HVN_T_WINO_DY = 9, HVN_T_WINO_DW = 10 };
 typedef struct hvn_top {
     int32_t kind, kh, kw, stride, pad_t, pad_l, groups, cout, cin_g, mode, lead_pad, _pad;
     hvn_view x, y, dx, dy;
     void *p[6];          /* dev */
     float eps, momentum;
     const hvn_op *net;   /* host */
+    int64_t batch_stride[3]; /* WGRAD with nbatch > 1 */
+    int32_t nbatch, _pad2;
 } hvn_top;
 HVN_API int hvn_run_train_plan(const hvn_top *ops, int n_ops, int batch, void *stream);
 HVN_API const char *hvn_train_last_error(void);

@@ -199,7 +199,7 @@ def test_bn_relu_forward_backward(n, H, W, C, crop, step):
     dab = torch.randn(n, h, w, C, generator=g).cuda()
     dzb = torch.randn(n, H * step, W * step, C + 32, generator=g).cuda()
     dz0 = dzb.cpu().clone()
-    ws = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    ws = torch.full((256 * 2 * C,), 1e30, dtype=torch.float64, device="cuda")     # partial-sum scratch: contents irrelevant
     save, coef = torch.zeros(4 * C, device="cuda"), torch.zeros(3 * C, device="cuda")
     gm, bt, rmc, rvc = gamma.cuda(), beta.cuda(), rm.clone().cuda(), rv.clone().cuda()
     dgam, dbet = torch.ones(C, device="cuda"), torch.ones(C, device="cuda")
@@ -215,7 +215,6 @@ def test_bn_relu_forward_backward(n, H, W, C, crop, step):
     close(ab, a_ref, 1e-5, "bn a")
     close(rmc, rm_ref, 1e-5, "running mean")
     close(rvc, rv_ref, 1e-5, "running var")
-    assert float(ws.abs().max()) == 0.0
     tb = L.hvn_top()
     tb.kind, tb.x, tb.y, tb.dy = 4, zv, view_of(ab), view_of(dab)
     tb.dx = view_of(dzb, crop * step, crop * step, h, w, 32, C, step=step)
@@ -372,8 +371,8 @@ def _rel_l2(a, b):
     return float((a.double() - b.double()).norm()) / (float(b.double().norm()) + 1e-30)
 
 
-@pytest.mark.parametrize("case", ["orig5_freeze", "orig5_full", "fastseg_full"])
-def test_training_step_matches_oracle(case):
+@pytest.mark.parametrize("case,wino", [("orig5_freeze", "1"), ("orig5_freeze", "0"), ("orig5_full", "1"), ("fastseg_full", "1")])
+def test_training_step_matches_oracle(case, wino, monkeypatch):
     """forward (train-mode BN) -> losses -> backward on the HIP path vs the training oracle: loss terms, logits,
     running stats, and every parameter gradient within a small multiple of torch-fp32's own distance to a
     float64 run of the same oracle."""
@@ -382,6 +381,7 @@ def test_training_step_matches_oracle(case):
     from hover_net_amd.synth import synth_state_dict, synth_train_batch
     from hover_net_amd.train_engine import TrainEngine
     from oracle import train_torch
+    monkeypatch.setenv("HVN_TRAIN_WINOGRAD", wino)      # the 5x5 convs as Winograd F(4x4,5x5) (default) or direct
     gold, mode, nt, freeze = load_case(case)
     n = int(gold["n"])
     sd = synth_state_dict(mode, nt, seed=int(gold["wseed"]))
@@ -415,13 +415,16 @@ def test_training_step_matches_oracle(case):
     if os.path.isdir(out_dir):
         import json
         json.dump({k: {"hip_vs_f64": a, "torch_f32_vs_f64": b} for k, (a, b) in errs.items()},
-                  open(os.path.join(out_dir, "train_grad_err_%s.json" % case), "w"), indent=0)
+                  open(os.path.join(out_dir, "train_grad_err_%s_w%s.json" % (case, wino)), "w"), indent=0)
     worst = max(errs.items(), key=lambda kv: kv[1][0])
     print("worst relative L2 gradient error vs float64 (hip, torch fp32):", worst)
-    # per tensor: relative L2 distance to the float64 gradient within 4x torch-fp32's own distance, or 2e-3
-    # (sequential fp32 accumulation over up to 10^5 pixels per weight-gradient element vs torch's blocked sums)
+    # per tensor: relative L2 distance to the float64 gradient within 6x torch-fp32's own distance, or 5e-3 -- the
+    # median distance of torch-fp32 itself on this problem (sequential fp32 accumulation over up to 10^5 pixels per
+    # weight-gradient element and the Winograd transforms of the 5x5 convs vs torch's blocked direct sums)
     for k, (e_hip, e_t32) in errs.items():
-        assert e_hip <= max(4.0 * e_t32, 2e-3), (k, e_hip, e_t32)
+        assert e_hip <= max(6.0 * e_t32, 5e-3), (k, e_hip, e_t32)
+    med_hip, med_t32 = np.median([a for a, _ in errs.values()]), np.median([b for _, b in errs.values()])
+    assert med_hip <= 2.0 * med_t32 + 1e-4, (med_hip, med_t32)
     # goldens from the reference itself: gradient norms (fp32 noise level)
     for k, has, norm in zip(gold["grad_keys"], gold["grad_has"], gold["grad_norms"]):
         if has:
@@ -559,3 +562,49 @@ def test_two_phase_schedule_runs_and_learns(tmp_path):
     assert not torch.equal(ck0[k_dec], sd0[k_dec])                         # decoder trained
     assert not torch.equal(ck1[k_frozen], ck0[k_frozen])                   # phase 1: everything trains
     assert float(ck1["d2.units.3.conv2/bn.num_batches_tracked"]) == 24.0   # 2 phases x 2 epochs x 6 train steps
+
+
+@pytest.mark.parametrize("n,H,cin,cout,pad", [(2, 34, 64, 32, 0), (2, 24, 256, 64, 2), (1, 66, 128, 128, 0)])
+def test_winograd_domain_weight_gradient(n, H, cin, cout, pad):
+    """WINO_IN (forward V) -> WINO_DY -> 64 batched WGRAD problems -> WINO_DW against the direct weight gradient."""
+    import train_interp
+    from hover_net_amd import lib as L
+    from hover_net_amd import winograd as WG
+    from hover_net_amd.train_plan import TOp
+    g = torch.Generator().manual_seed(8)
+    ho = H + 2 * pad - 4
+    ty = -(-ho // 4)
+    t1 = ty * ty
+    x = torch.randn(n, H, H, cin, generator=g).relu().cuda()
+    dy = (torch.randn(n, ho, ho, cout, generator=g) * 0.1).cuda()
+    at, gm, bt = WG.MATS[4]
+    mats = torch.tensor(list(bt.reshape(-1)) + list(at.reshape(-1)) + list(gm.reshape(-1)), dtype=torch.float32).cuda()
+    V = torch.zeros(n * 64 * t1 * cin, device="cuda")
+    DM = torch.zeros(n * 64 * t1 * cout, device="cuda")
+    dU = torch.zeros(64 * cout * cin, device="cuda")
+    dW = torch.ones(cout * 25 * cin, device="cuda")
+
+    def tview(t, h, c):
+        v = L.hvn_view()
+        v.base, v.sn, v.sy, v.sx, v.h, v.w, v.c, v.sc = t.data_ptr(), 64 * t1 * c, t1 * c, c, h, t1, c, 1
+        return v
+    o = L.hvn_op()
+    o.kind, o.kh, o.kw, o.pad_t, o.pad_l = 6, ty, ty, pad, pad
+    o.x, o.y, o.w = view_of(x), tview(V, 64, cin), mats.data_ptr()
+    t0 = L.hvn_top()
+    t0.kind, t0.net = 1, ctypes.pointer(o)
+    t1_ = L.hvn_top()
+    t1_.kind, t1_.kh, t1_.kw = 9, ty, ty
+    t1_.x, t1_.y = view_of(dy), tview(DM, 64, cout)
+    t1_.p[0] = mats.data_ptr() + 4 * 64
+    t2 = L.hvn_top()
+    t2.kind, t2.kh, t2.kw, t2.stride, t2.groups, t2.nbatch = 5, 1, 1, 1, 1, 64
+    t2.x, t2.dy = tview(V, 1, cin), tview(DM, 1, cout)
+    t2.p[0] = dU.data_ptr()
+    t2.batch_stride[0], t2.batch_stride[1], t2.batch_stride[2] = t1 * cin, t1 * cout, cout * cin
+    t3 = L.hvn_top()
+    t3.kind, t3.cout, t3.cin_g = 10, cout, cin
+    t3.p[0], t3.p[1], t3.p[2] = dU.data_ptr(), dW.data_ptr(), mats.data_ptr() + 4 * 96
+    run_tops([t0, t1_, t2, t3], n)
+    want = train_interp.wgrad_ref(TOp("wgrad", "t", stride=1, pad=(pad, pad), groups=1), x.cpu(), dy.cpu(), (cout, cin, 5, 5))
+    close(dW.cpu().view(cout, 5, 5, cin).permute(0, 3, 1, 2) - 1.0, want, 1e-4, "winograd-domain wgrad")
