@@ -545,17 +545,39 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
     }
 }
 
-// forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
-__global__ void hvn_bn_final(const BnArgs p)
+// Sum of the row-block partials of channel c: 8 lanes per channel read interleaved partials, LDS combine.
+// Block = 32 channels x 8 part-lanes; returns the totals to part-lane 0.
+__device__ inline bool bn_part_sums(const BnArgs &p, double &s1, double &s2, int &c)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
-    const double n = (double)p.N * p.H * p.W;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < p.nparts; ++k) {
-        s1 += p.ws[(long)k * 2 * p.C + 2 * c];
-        s2 += p.ws[(long)k * 2 * p.C + 2 * c + 1];
+    __shared__ double red[256][2];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < p.C)
+        for (int k = pl; k < p.nparts; k += 8) {
+            a += p.ws[(long)k * 2 * p.C + 2 * c];
+            b += p.ws[(long)k * 2 * p.C + 2 * c + 1];
+        }
+    red[threadIdx.x][0] = a;
+    red[threadIdx.x][1] = b;
+    __syncthreads();
+    if (pl != 0 || c >= p.C) return false;
+    for (int k = 1; k < 8; ++k) {
+        a += red[cl + 32 * k][0];
+        b += red[cl + 32 * k][1];
     }
+    s1 = a;
+    s2 = b;
+    return true;
+}
+
+// forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
+__global__ __launch_bounds__(256) void hvn_bn_final(const BnArgs p)
+{
+    double s1, s2;
+    int c;
+    if (!bn_part_sums(p, s1, s2, c)) return;
+    const double n = (double)p.N * p.H * p.W;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -571,16 +593,12 @@ __global__ void hvn_bn_final(const BnArgs p)
 }
 
 // backward finalize: dgamma += sum g*xhat, dbeta += sum g; coefficients of the dz formula
-__global__ void hvn_bn_bwd_final(const BnArgs p)
+__global__ __launch_bounds__(256) void hvn_bn_bwd_final(const BnArgs p)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
+    double s1, s2;
+    int c;
+    if (!bn_part_sums(p, s1, s2, c)) return;
     const double n = (double)p.N * p.H * p.W;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < p.nparts; ++k) {
-        s1 += p.ws[(long)k * 2 * p.C + 2 * c];
-        s2 += p.ws[(long)k * 2 * p.C + 2 * c + 1];
-    }
     p.dgamma[c] += (float)s2;
     p.dbeta[c] += (float)s1;
     p.coef[c] = p.gamma[c] * p.save[3 * p.C + c];
@@ -652,7 +670,7 @@ int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
     dim3 grid;
     bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<0>, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
     const long total = (long)a.N * a.H * a.W * (a.C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -666,7 +684,7 @@ int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
     dim3 grid;
     bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<1>, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
     if (a.dz) {
         const long total = (long)a.N * a.H * a.W * (a.C / 4);
         long blocks = (total + 255) / 256;
