@@ -215,11 +215,8 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
     }
     auto advance = [&](int &n, int &y, int &x) {
         x += 32;
-        if (x >= p.Wo) { x -= p.Wo; ++y; }
-        if (x >= p.Wo) { x -= p.Wo; ++y; }
-        if (x >= p.Wo) { x -= p.Wo; ++y; }
-        if (y >= p.Ho) { y -= p.Ho; ++n; }
-        if (y >= p.Ho) { y -= p.Ho; ++n; }
+        while (x >= p.Wo) { x -= p.Wo; ++y; }     // at most a few trips: 32 pixels rarely span more than two rows
+        while (y >= p.Ho) { y -= p.Ho; ++n; }
     };
 
     f32x4 ra[PA], rb[PB];

@@ -2,7 +2,7 @@
 """Training-step timing on one MI355X (BASELINE cfg 5 shapes, single GPU): phase 0 (freeze, batch 16) and phase 1
 (all layers, batch 4) of opt.py:23-142, CoNSeP 'original' mode with 5 types, synthetic batch, FusedAdam.
 Prints one JSON line per phase: ms per step split into forward / loss+backward / optimizer, steps/s, and the
-executed conv FLOPs per step (forward + data-gradient + weight-gradient) over the step time.
+direct-convolution (algorithmic) conv FLOPs per step (forward + data-gradient + weight-gradient; the 5x5 convs execute 6x fewer as Winograd) over the step time.
 usage: python tools/train_bench.py [--steps 10] [--warmup 3] [--phase 0|1|both]"""
 import argparse
 import json
