@@ -84,7 +84,7 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.w = op->w; a.bias = op->bias;
         a.y = (float *)op->y.base;
         a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
-        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.pad = op->pad_t; a.relu = op->relu;
+        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w; a.pad = op->pad_t; a.relu = op->relu; a.out_bf16 = op->act_dtype == 1;
         if (op->kh != 7 || op->kw != 7 || op->x.c != 3 || op->y.c != 64 || !op->w || !op->bias)
             return fail(HVN_E_ARG, "conv0: expects 7x7x3->64 with bias%s", "");
         if (!aligned16(a.y) || (a.ysx & 3) || (a.ysy & 3) || (a.ysn & 3)) return fail(HVN_E_ARG, "conv0: output view not 16-byte aligned%s", "");
@@ -126,8 +126,11 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.nbatch = op->nbatch > 1 ? op->nbatch : 1;
         a.xb = op->batch_stride[0]; a.wb = op->batch_stride[1]; a.yb = op->batch_stride[2];
         if (a.nbatch > 1 && ((a.xb | a.wb | a.yb) & 3)) return fail(HVN_E_ARG, "conv: batch strides must keep 16-byte alignment%s", "");
+        const bool bf16 = op->act_dtype == 1;
+        if (bf16 && (((a.xsx | a.xsy | a.xsn) & 7) || (a.x2 && ((a.x2sx | a.x2sy | a.x2sn) & 7)) || a.nbatch > 1))
+            return fail(HVN_E_ARG, "conv(bf16): input strides must be multiples of 8 elements; no batched launch%s", "");
         if (g_prof) prof_mark(s);
-        int rc = hvn_launch_conv(a, op->tile_n, s);
+        int rc = bf16 ? hvn_launch_conv_bf16(a, op->tile_n, s) : hvn_launch_conv(a, op->tile_n, s);
         if (g_prof) prof_mark(s);
         if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "conv: launch failed (tile_n=%s%ld)", "", op->tile_n);
         return 0;
@@ -168,7 +171,9 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.ssn = op->res.sn; a.ssy = op->res.sy; a.ssx = op->res.sx;
         a.y = (float *)op->y.base;
         a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx;
-        a.N = batch; a.H = op->y.h; a.W = op->y.w; a.C = op->y.c;
+        a.N = batch; a.H = op->y.h; a.W = op->y.w; a.C = op->y.c; a.bf16 = op->act_dtype == 1;
+        if (a.bf16 && ((a.lsx | a.lsy | a.lsn | a.ssx | a.ssy | a.ssn | a.ysx | a.ysy | a.ysn) & 7))
+            return fail(HVN_E_ARG, "upadd(bf16): strides must be multiples of 8 elements%s", "");
         if (!a.lo || !a.skip || !a.y) return fail(HVN_E_ARG, "upadd: null pointer%s", "");
         if (op->x.h * 2 != a.H || op->x.w * 2 != a.W || op->res.h != a.H || op->res.w != a.W || op->x.c != a.C || op->res.c != a.C)
             return fail(HVN_E_ARG, "upadd: shape mismatch%s", "");
@@ -182,7 +187,8 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.xsn = op->x.sn; a.xsy = op->x.sy; a.xsx = op->x.sx;
         a.w = op->w; a.bias = op->bias;
         a.y = (float *)op->y.base;
-        a.N = batch; a.H = op->x.h; a.W = op->x.w; a.Cout = op->cout;
+        a.N = batch; a.H = op->x.h; a.W = op->x.w; a.Cout = op->cout; a.in_bf16 = op->act_dtype == 1;
+        if (a.in_bf16 && ((a.xsx | a.xsy | a.xsn) & 7)) return fail(HVN_E_ARG, "head(bf16): strides must be multiples of 8 elements%s", "");
         if (op->x.c != 64 || !a.w || !a.bias || !a.x || !a.y) return fail(HVN_E_ARG, "head: expects 64 input channels, weights and bias%s", "");
         if (!aligned16(a.x) || ((a.xsx | a.xsy | a.xsn) & 3)) return fail(HVN_E_ARG, "head: input view not 16-byte aligned%s", "");
         return hvn_launch_head(a, s);

@@ -1,0 +1,342 @@
+// hvn_conv_bf16.hip -- the implicit-GEMM convolution of hvn_conv.hip with bf16 activations / weights and fp32
+// accumulation on the gfx950 bf16 matrix cores (BASELINE cfg 3: "fast" mode, batch 64, bf16).
+//
+// Same GEMM view, tile (128 pixels x {128,64,32} output channels per 256-thread workgroup), staging geometry and
+// fusions (prologue BN+ReLU on the input, epilogue bias / ReLU / residual / block-closing BN-ReLU, fused 1x1
+// shortcut as a second reduction source) as the fp32 kernel; what changes:
+//   * a k-step is 64 channels (still 128 B per row, so loads / LDS rows keep their byte layout), one
+//     v_mfma_f32_32x32x16_bf16 consumes the 16 B a lane reads with one ds_read_b128 (8 bf16; the k-labelling inside
+//     a step is arbitrary as long as A and B agree, which they do: both read the same byte offsets of their rows);
+//   * 16 MFMAs x 32 cycles = 512 matrix cycles per k-step and wave instead of 4096, far less than the HBM / L2
+//     latency, so the global loads run THREE k-steps ahead through a ring of four register stages;
+//   * input channel counts that are a multiple of 32 but not of 64 (the dense units' 288, 352, ...): the upper half
+//     of the last k-step is loaded as zeros (buffer range check) and the packed weights carry zeros there;
+//   * grouped convs (dense-unit conv2) run as block-diagonal dense GEMMs (tiny layers, the bf16 pipe is 16x faster);
+//   * the epilogue works in fp32 on the LDS-transposed accumulators and rounds to bf16 (RNE, v_cvt_pk_bf16_f32) on
+//     the store; residuals are read as bf16.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvn_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define BKH 64      // reduction elements per k-step
+#define LDH 72      // LDS row pitch in bf16 elements (144 B: conflict-free ds_read_b128 / ds_write_b128)
+
+__device__ inline float bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ inline float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ inline uint32_t pack_bf(float a, float b)
+{
+    bf16x2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2>
+__global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
+{
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int PA = BM / 32, PB = BN / 32;  // staging passes (32 rows of 8 x 16 B per pass)
+    constexpr int EP_LD = BN + 4;              // epilogue tile row length (floats)
+    static_assert(WAVES_M * WAVES_N == 4, "256 threads");
+    static_assert(BM * EP_LD * 4 <= 2 * (BM + BN) * LDH * 2, "epilogue tile must fit in the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
+    uint16_t *As = smem16;                    // [2][BM][LDH]
+    uint16_t *Bs = smem16 + 2 * BM * LDH;     // [2][BN][LDH]
+    const uint16_t *px = (const uint16_t *)p.x;
+    const uint16_t *pw = (const uint16_t *)p.w;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int NT = p.n_tiles;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int n_tile = seq % NT;
+    const int m_tile = (seq / NT) * 8 + xcd;
+    if (m_tile >= (int)p.m_tiles) return;
+    const unsigned m0 = (unsigned)m_tile * BM;
+    const int n0 = n_tile * BN;
+    const unsigned M = (unsigned)p.M;
+
+    const int srow = tid >> 3;       // 0..31
+    const int scol = (tid & 7) * 8;  // element offset inside the 64-wide k chunk
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+    const unsigned n_blk = m0 / HoWo;
+    const long padoff = (long)p.pad_t * p.xsy + (long)p.pad_l * p.xsx;
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned a_voff[PA];
+    int a_iy[PA], a_ix[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const unsigned m = m0 + srow + 32 * j;
+        const bool ok = m < M;
+        const unsigned mm = ok ? m : m0;
+        const unsigned n = mm / HoWo;
+        const unsigned rem = mm - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        a_iy[j] = ok ? (int)oy * p.stride - p.pad_t : -(1 << 28);
+        a_ix[j] = ok ? (int)ox * p.stride - p.pad_l : -(1 << 28);
+        a_voff[j] = ok ? (unsigned)(((long)(n - n_blk) * p.xsn + (long)(oy * p.stride) * p.xsy + (long)(ox * p.stride) * p.xsx + scol) * 2) : OOB;
+    }
+    const uint16_t *xblk = px + (long)n_blk * p.xsn - padoff;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void *)xblk, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)pw, 0, 0x7fffffff, 0x00020000);
+    unsigned a2_voff[PA];
+    const uint16_t *x2blk = HAS_X2 ? (const uint16_t *)p.x2 + (long)n_blk * p.x2sn : px;
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc((void *)x2blk, 0, 0x7fffffff, 0x00020000);
+    if constexpr (HAS_X2) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const unsigned m = m0 + srow + 32 * j;
+            const bool ok = m < M;
+            const unsigned mm = ok ? m : m0;
+            const unsigned n = mm / HoWo;
+            const unsigned rem = mm - n * HoWo;
+            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+            a2_voff[j] = ok ? (unsigned)(((long)(n - n_blk) * p.x2sn + (long)(oy * p.stride2) * p.x2sy + (long)(ox * p.stride2) * p.x2sx + scol) * 2) : OOB;
+        }
+    }
+    const int kchunks = (p.Cin + BKH - 1) / BKH;
+    const bool tail_half = (p.Cin % BKH) != 0 && scol >= 32;       // this thread's 8 channels lie past Cin in the last chunk
+    const int KT1 = p.KH * p.KW * kchunks;
+    const int KT = KT1 + (HAS_X2 ? p.Cin2 / BKH : 0);
+    const long Ktot = (long)KT * BKH;
+    unsigned w_voff[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) w_voff[j] = (unsigned)(((long)(n0 + srow + 32 * j) * Ktot + scol) * 2);
+    const bool has_pre = HAS_PRE && p.pre_s != nullptr;
+
+    struct Stage {
+        u32x4 ra[PA], rb[PB];
+        int ch;   // HAS_PRE: first input channel of this thread's 8 (the prologue constants are fetched at store time)
+    };
+    Stage st[4];
+    int ld_r = 0, ld_s = 0, ld_c = 0;  // tap row / col / channel chunk of the NEXT load
+
+    auto load_global = [&](Stage &s, int kt) {
+        int a_soff = (int)(((long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BKH) * 2);
+        const int w_soff = kt * (BKH * 2);
+        const bool second = HAS_X2 && kt >= KT1;
+        if constexpr (HAS_X2) a_soff = second ? (kt - KT1) * (BKH * 2) : a_soff;
+        const bool zero_half = tail_half && ld_c == kchunks - 1 && !second;
+        if constexpr (HAS_PRE) s.ch = zero_half ? 0 : ld_c * BKH + scol;      // any valid index for the zero-weighted tail
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            unsigned vo = a_voff[j];
+            if constexpr (PADDED) {
+                const bool ok = (unsigned)(a_iy[j] + ld_r) < (unsigned)p.H && (unsigned)(a_ix[j] + ld_s) < (unsigned)p.W;
+                vo = ok ? vo : OOB;
+            }
+            vo = zero_half ? OOB : vo;
+            if constexpr (HAS_X2) {
+                vo = second ? a2_voff[j] : vo;
+                s.ra[j] = __builtin_amdgcn_raw_buffer_load_b128(second ? rsrc_a2 : rsrc_a, vo, a_soff, 0);
+            } else
+                s.ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, a_soff, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) s.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], w_soff, 0);
+        if (++ld_s == p.KW) {
+            ld_s = 0;
+            if (++ld_r == p.KH) {
+                ld_r = 0;
+                ++ld_c;
+            }
+        }
+    };
+    auto store_lds = [&](Stage &s, int buf) {
+        uint16_t *a = As + buf * BM * LDH;
+        uint16_t *b = Bs + buf * BN * LDH;
+        f32x4 ps0, ps1, pb0, pb1;
+        if constexpr (HAS_PRE) {
+            if (has_pre) {      // 32 B each, L1/L2 resident (one [Cin] array pair per layer)
+                ps0 = *(const f32x4 *)(p.pre_s + s.ch);
+                ps1 = *(const f32x4 *)(p.pre_s + s.ch + 4);
+                pb0 = *(const f32x4 *)(p.pre_b + s.ch);
+                pb1 = *(const f32x4 *)(p.pre_b + s.ch + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            u32x4 v = s.ra[j];
+            if constexpr (HAS_PRE) {
+                if (has_pre) {  // pre-activation BN + ReLU on the 8 bf16 channels of this thread, in fp32
+                    const float s_[8] = {ps0.x, ps0.y, ps0.z, ps0.w, ps1.x, ps1.y, ps1.z, ps1.w};
+                    const float b_[8] = {pb0.x, pb0.y, pb0.z, pb0.w, pb1.x, pb1.y, pb1.z, pb1.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = fmaxf(fmaf(bf_lo(v[e]), s_[2 * e], b_[2 * e]), 0.f);
+                        const float hi = fmaxf(fmaf(bf_hi(v[e]), s_[2 * e + 1], b_[2 * e + 1]), 0.f);
+                        v[e] = pack_bf(lo, hi);
+                    }
+                }
+            }
+            *(u32x4 *)(a + (srow + 32 * j) * LDH + scol) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(u32x4 *)(b + (srow + 32 * j) * LDH + scol) = s.rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int cur) {
+        const uint16_t *a = As + cur * BM * LDH + (wm * WM + l31) * LDH + 8 * lh;
+        const uint16_t *b = Bs + cur * BN * LDH + (wn * WN + l31) * LDH + 8 * lh;
+#pragma unroll
+        for (int q = 0; q < BKH / 16; ++q) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(a + i * 32 * LDH + q * 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + j * 32 * LDH + q * 16));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ring of four register stages: the loads of k-step t+3 are issued while step t computes
+    load_global(st[0], 0);
+    if (KT > 1) load_global(st[1], 1);
+    if (KT > 2) load_global(st[2], 2);
+    store_lds(st[0], 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = kt + u;
+            if (t < KT) {
+                if (t + 3 < KT) load_global(st[(u + 3) & 3], t + 3);
+                compute(t & 1);
+                if (t + 1 < KT) store_lds(st[(u + 1) & 3], (t + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: accumulators -> fp32 LDS tile -> bias / ReLU / residual / post BN-ReLU -> bf16 ----
+    float *ep = (float *)smem16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ep[row * EP_LD + wn * WN + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int CH = BN / 4;
+    constexpr int RPP = 256 / CH;
+    const int ecol = (tid % CH) * 4;
+    const int erow0 = tid / CH;
+    const int co = n0 + ecol;
+    const bool cok = co < p.Cout;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, qs = {1.f, 1.f, 1.f, 1.f}, qb = bias;
+    const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr;
+    if (cok) {
+        if (p.bias) bias = *(const f32x4 *)(p.bias + co);
+        if (has_post) {
+            qs = *(const f32x4 *)(p.post_s + co);
+            qb = *(const f32x4 *)(p.post_b + co);
+        }
+    }
+    const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+    const float post_lo = has_post ? 0.f : -__builtin_inff();
+    uint16_t *py = (uint16_t *)p.y;
+    const uint16_t *pres = (const uint16_t *)p.res;
+    for (int it = 0; it < BM / RPP; ++it) {
+        const int rr = erow0 + it * RPP;
+        const unsigned m = m0 + rr;
+        if (!(m < M && cok)) continue;
+        const unsigned n = m / HoWo;
+        const unsigned rem = m - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol);
+        v.x = fmaxf(v.x + bias.x, relu_lo);
+        v.y = fmaxf(v.y + bias.y, relu_lo);
+        v.z = fmaxf(v.z + bias.z, relu_lo);
+        v.w = fmaxf(v.w + bias.w, relu_lo);
+        if (has_res) {
+            const u32x2 r2 = *(const u32x2 *)(pres + (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co);
+            v.x += bf_lo(r2.x);
+            v.y += bf_hi(r2.x);
+            v.z += bf_lo(r2.y);
+            v.w += bf_hi(r2.y);
+        }
+        v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
+        v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
+        v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
+        v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
+        u32x2 o;
+        o.x = pack_bf(v.x, v.y);
+        o.y = pack_bf(v.z, v.w);
+        *(u32x2 *)(py + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co) = o;
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2>
+static int launch_bf16(const ConvArgs &a, hipStream_t stream)
+{
+    ConvArgs p = a;
+    p.m_tiles = (p.M + BM - 1) / BM;
+    p.n_tiles = (p.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDH * sizeof(uint16_t);
+    static bool attr_done = false;
+    auto kern = hvn_conv_igemm_bf16<BM, BN, WAVES_M, WAVES_N, PADDED, HAS_PRE, HAS_X2>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    const long groups = (p.m_tiles + 7) / 8;
+    const long grid = groups * 8 * p.n_tiles;
+    if (grid <= 0 || grid > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream)
+{
+    if (a.Cin % 32 != 0 || a.Cin <= 0 || a.Cout % 4 != 0 || a.nbatch > 1) return -1;
+    if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
+    const long span = 2 * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
+    if (span < 0 || span * 2 >= (1L << 31)) return -1;
+    const long kt = (long)a.KH * a.KW * ((a.Cin + BKH - 1) / BKH) + (a.x2 ? a.Cin2 / BKH : 0);
+    if ((long)(a.Cout + 128) * kt * BKH * 2 >= (1L << 31)) return -1;
+    const bool padded = a.pad_t > 0 || a.pad_l > 0 || (a.Ho - 1) * a.stride - a.pad_t + a.KH > a.H ||
+                        (a.Wo - 1) * a.stride - a.pad_l + a.KW > a.W;
+    if (padded && a.pre_s) return -1;
+    if (a.x2) {
+        if (padded || a.Cin2 % BKH || a.Cin % BKH || a.pre_s) return -1;
+        if (tile_n == 128) return launch_bf16<128, 128, 2, 2, false, false, true>(a, stream);
+        if (tile_n == 64) return launch_bf16<128, 64, 4, 1, false, false, true>(a, stream);
+        return -1;
+    }
+    switch (tile_n) {
+    case 128:
+        if (a.pre_s) return launch_bf16<128, 128, 2, 2, false, true, false>(a, stream);
+        return padded ? launch_bf16<128, 128, 2, 2, true, false, false>(a, stream) : launch_bf16<128, 128, 2, 2, false, false, false>(a, stream);
+    case 64:
+        if (a.pre_s) return launch_bf16<128, 64, 4, 1, false, true, false>(a, stream);
+        return padded ? launch_bf16<128, 64, 4, 1, true, false, false>(a, stream) : launch_bf16<128, 64, 4, 1, false, false, false>(a, stream);
+    case 32:
+        if (a.pre_s) return launch_bf16<128, 32, 4, 1, false, true, false>(a, stream);
+        return padded ? launch_bf16<128, 32, 4, 1, true, false, false>(a, stream) : launch_bf16<128, 32, 4, 1, false, false, false>(a, stream);
+    default: return -1;
+    }
+}

@@ -26,6 +26,7 @@ struct ConvArgs {
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);
+int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream);   // x, res, y, x2, w are bf16; bias / scales fp32
 
 struct Conv0Args {
     const void *img;      // uint8 or float32
@@ -38,6 +39,7 @@ struct Conv0Args {
     long ysn, ysy, ysx;
     int N, Ho, Wo, pad;
     int relu;             // 1: ReLU after the bias (inference, BN folded); 0: raw conv output (training)
+    int out_bf16;         // y is bf16 (cfg 3) instead of fp32
 };
 int hvn_launch_conv0(const Conv0Args &a, hipStream_t stream);
 
@@ -49,6 +51,7 @@ struct UpAddArgs {
     float *y;
     long ysn, ysy, ysx;
     int N, H, W, C;  // output extent
+    int bf16;        // all three tensors are bf16
 };
 int hvn_launch_upadd(const UpAddArgs &a, hipStream_t stream);
 
@@ -59,6 +62,7 @@ struct HeadArgs {
     const float *bias;  // [cout]
     float *y;           // NCHW [N][cout][H][W]
     int N, H, W, Cout;
+    int in_bf16;        // x is bf16 (the logits stay fp32)
 };
 int hvn_launch_head(const HeadArgs &a, hipStream_t stream);
 

@@ -13,6 +13,15 @@
 #include "hvn_kernels.h"
 
 // ---------------------------------------------------------------------------------------
+typedef __bf16 hvn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ inline float hvn_bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ inline float hvn_bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ inline uint32_t hvn_pack_bf(float a, float b)
+{
+    hvn_bf16x2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
 #define C0_T 16              // output tile edge
 #define C0_P (C0_T + 6)      // patch edge
 template <typename T>
@@ -48,10 +57,21 @@ __global__ __launch_bounds__(256) void hvn_conv0(const Conv0Args p)
     const int oy = oy0 + ty, ox = ox0 + tx;
     const float lo = p.relu ? 0.f : -__builtin_inff();
     if (oy < p.Ho && ox < p.Wo) {
-        float *y = p.y + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx;
+        const long yoff = (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx;
+        if (p.out_bf16) {   // bf16 activations (RNE)
+            uint16_t *y = (uint16_t *)p.y + yoff;
 #pragma unroll
-        for (int c = 0; c < 64; c += 4)
-            *(float4 *)(y + c) = make_float4(fmaxf(acc[c], lo), fmaxf(acc[c + 1], lo), fmaxf(acc[c + 2], lo), fmaxf(acc[c + 3], lo));
+            for (int c = 0; c < 64; c += 4) {
+                hvn_bf16x2 h0 = {(__bf16)fmaxf(acc[c], lo), (__bf16)fmaxf(acc[c + 1], lo)};
+                hvn_bf16x2 h1 = {(__bf16)fmaxf(acc[c + 2], lo), (__bf16)fmaxf(acc[c + 3], lo)};
+                *(uint2 *)(y + c) = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+            }
+        } else {
+            float *y = p.y + yoff;
+#pragma unroll
+            for (int c = 0; c < 64; c += 4)
+                *(float4 *)(y + c) = make_float4(fmaxf(acc[c], lo), fmaxf(acc[c + 1], lo), fmaxf(acc[c + 2], lo), fmaxf(acc[c + 3], lo));
+        }
     }
 }
 
@@ -83,8 +103,40 @@ __global__ __launch_bounds__(256) void hvn_upadd(const UpAddArgs p, long total4)
     }
 }
 
+// bf16 activations: 8 channels (16 B) per thread, the sum in fp32
+__global__ __launch_bounds__(256) void hvn_upadd_bf16(const UpAddArgs p, long total8)
+{
+    const int c8n = p.C >> 3;
+    const uint16_t *lo = (const uint16_t *)p.lo, *skip = (const uint16_t *)p.skip;
+    uint16_t *yo = (uint16_t *)p.y;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        long t = i / c8n;
+        const int x = (int)(t % p.W);
+        t /= p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const uint4 a = *(const uint4 *)(lo + (long)n * p.lsn + (long)(y >> 1) * p.lsy + (long)(x >> 1) * p.lsx + c8 * 8);
+        const uint4 b = *(const uint4 *)(skip + (long)n * p.ssn + (long)y * p.ssy + (long)x * p.ssx + c8 * 8);
+        uint4 o;
+        o.x = hvn_pack_bf(hvn_bf_lo(a.x) + hvn_bf_lo(b.x), hvn_bf_hi(a.x) + hvn_bf_hi(b.x));
+        o.y = hvn_pack_bf(hvn_bf_lo(a.y) + hvn_bf_lo(b.y), hvn_bf_hi(a.y) + hvn_bf_hi(b.y));
+        o.z = hvn_pack_bf(hvn_bf_lo(a.z) + hvn_bf_lo(b.z), hvn_bf_hi(a.z) + hvn_bf_hi(b.z));
+        o.w = hvn_pack_bf(hvn_bf_lo(a.w) + hvn_bf_lo(b.w), hvn_bf_hi(a.w) + hvn_bf_hi(b.w));
+        *(uint4 *)(yo + (long)n * p.ysn + (long)y * p.ysy + (long)x * p.ysx + c8 * 8) = o;
+    }
+}
+
 int hvn_launch_upadd(const UpAddArgs &a, hipStream_t stream)
 {
+    if (a.bf16) {
+        if (a.C % 8) return -1;
+        const long total8 = (long)a.N * a.H * a.W * (a.C / 8);
+        long blocks = (total8 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(hvn_upadd_bf16, dim3((unsigned)blocks), dim3(256), 0, stream, a, total8);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (a.C % 4) return -1;
     const long total4 = (long)a.N * a.H * a.W * (a.C / 4);
     long blocks = (total4 + 255) / 256;
@@ -102,15 +154,26 @@ __global__ __launch_bounds__(256) void hvn_head(const HeadArgs p, long total)
     long t = i / p.W;
     const int y = (int)(t % p.H);
     const int n = (int)(t / p.H);
-    const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
+    const long xoff = (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
     float v[64];
+    if (p.in_bf16) {
+        const uint16_t *src = (const uint16_t *)p.x + xoff;
 #pragma unroll
-    for (int c = 0; c < 64; c += 4) {
-        const float4 q = *(const float4 *)(src + c);
-        v[c] = q.x;
-        v[c + 1] = q.y;
-        v[c + 2] = q.z;
-        v[c + 3] = q.w;
+        for (int c = 0; c < 64; c += 8) {
+            const uint4 q = *(const uint4 *)(src + c);
+            v[c] = hvn_bf_lo(q.x); v[c + 1] = hvn_bf_hi(q.x); v[c + 2] = hvn_bf_lo(q.y); v[c + 3] = hvn_bf_hi(q.y);
+            v[c + 4] = hvn_bf_lo(q.z); v[c + 5] = hvn_bf_hi(q.z); v[c + 6] = hvn_bf_lo(q.w); v[c + 7] = hvn_bf_hi(q.w);
+        }
+    } else {
+        const float *src = p.x + xoff;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            const float4 q = *(const float4 *)(src + c);
+            v[c] = q.x;
+            v[c + 1] = q.y;
+            v[c + 2] = q.z;
+            v[c + 3] = q.w;
+        }
     }
     const long plane = (long)p.H * p.W;
     float *dst = p.y + (long)n * p.Cout * plane + (long)y * p.W + x;

@@ -26,9 +26,31 @@ def _view_struct(v, base_ptr, sn, itemsize=4):
     return s
 
 
+def to_bf16_bits(a):
+    """float32 array -> bfloat16 bit patterns (uint16), round to nearest even."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + 0x7FFF)) >> 16).astype(np.uint16)
+
+
+def repack_conv_bf16(w32):
+    """[cout_pad, cin/32, taps, 32] fp32 (plan._pack_conv) -> [cout_pad, ceil(cin/64), taps, 64] bf16 bits: the bf16
+    kernel's k-step is 64 channels; an odd number of 32-channel slabs gets a zero slab (the kernel loads zeros there)."""
+    cp, s32, taps, _ = w32.shape
+    if s32 % 2:
+        w32 = np.concatenate([w32, np.zeros((cp, 1, taps, 32), np.float32)], 1)
+        s32 += 1
+    w = w32.reshape(cp, s32 // 2, 2, taps, 32).transpose(0, 1, 3, 2, 4).reshape(cp, s32 // 2, taps, 64)
+    return to_bf16_bits(w)
+
+
 class Engine:
-    def __init__(self, plan, max_batch=32, device="cuda", n_split=None):
+    def __init__(self, plan, max_batch=32, device="cuda", n_split=None, dtype="fp32"):
         L.require_gpu()
+        assert dtype in ("fp32", "bf16")
+        self.dtype = dtype
+        self.isz = 4 if dtype == "fp32" else 2          # bytes per activation element
+        if dtype == "bf16" and any(op.kind in (PL.OP_WINO_IN, PL.OP_WINO_OUT) for op in plan.ops):
+            raise ValueError("the bf16 path runs direct convolutions: build the plan with winograd=0")
         self.plan = plan
         self.max_batch = int(max_batch)
         self.device = torch.device(device)
@@ -42,7 +64,8 @@ class Engine:
         self.split_decoder = os.environ.get("HVN_SPLIT_DECODER", "0") != "0"
         self._streams = None
         self._upload_params()
-        self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32, device=self.device)
+        self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32 if dtype == "fp32" else torch.int16,
+                                 device=self.device)
         self.logits = {br: torch.empty((self.max_batch, b.c, b.h, b.w), dtype=torch.float32, device=self.device)
                        for br, b in plan.logits.items()}
         self.pred_map = None
@@ -66,8 +89,15 @@ class Engine:
             arrays.append((total, a))
             total += (a.size + 63) // 64 * 64
 
+        w16, off16, tot16 = [], {}, 0
         for i, op in enumerate(self.plan.ops):
-            put((i, "w"), op.w)
+            if self.dtype == "bf16" and op.kind == PL.OP_CONV:
+                wb = repack_conv_bf16(op.w).ravel()
+                off16[i] = tot16
+                w16.append((tot16, wb))
+                tot16 += (wb.size + 127) // 128 * 128
+            else:
+                put((i, "w"), op.w)
             put((i, "bias"), op.bias)
             if op.pre is not None:
                 put((i, "pre_s"), op.pre[0])
@@ -80,6 +110,13 @@ class Engine:
             host[off:off + a.size] = a
         self.params = torch.from_numpy(host).to(self.device)
         self._poff = offs
+        self._poff16 = off16
+        self.params16 = None
+        if tot16:
+            h16 = np.zeros(tot16, np.uint16)
+            for off, a in w16:
+                h16[off:off + a.size] = a
+            self.params16 = torch.from_numpy(h16.view(np.int16)).to(self.device)
 
     def _pptr(self, i, name):
         off = self._poff.get((i, name))
@@ -91,6 +128,7 @@ class Engine:
         sn = P.arena_per_sample
         for i, op in enumerate(P.ops):
             o = self.ops[i]
+            o.act_dtype = 1 if self.dtype == "bf16" else 0
             o.kind, o.kh, o.kw, o.stride = op.kind, op.kh, op.kw, op.stride
             o.pad_t, o.pad_l, o.relu, o.cout, o.tile_n, o.x_dtype = op.pad_t, op.pad_l, op.relu, op.cout, op.tile_n, 0
             o.groups = int(op.extra.get("groups", 1))
@@ -112,14 +150,16 @@ class Engine:
                 if v is None:
                     continue
                 if v.buf.offset >= 0:
-                    setattr(o, fld, _view_struct(v, abase + 4 * v.buf.offset, sn))
+                    setattr(o, fld, _view_struct(v, abase + self.isz * v.buf.offset, sn, self.isz))
             if op.kind == PL.OP_CONV0:
                 o.x.h, o.x.w, o.x.c = op.x.h, op.x.w, 3  # base / strides set per call
             if op.kind == PL.OP_HEAD:
                 br = op.y.buf.name.split(".")[1]
                 o.y.base = self.logits[br].data_ptr()
                 o.y.h, o.y.w, o.y.c = op.y.h, op.y.w, op.y.c
-            o.w = self._pptr(i, "w")
+            o.w = self._pptr(i, "w") if i not in self._poff16 else self.params16.data_ptr() + 2 * self._poff16[i]
+            if i in self._poff16:
+                o.groups = 1        # grouped convs run as block-diagonal dense GEMMs on the bf16 pipe
             o.bias = self._pptr(i, "bias")
             o.pre_scale, o.pre_shift = self._pptr(i, "pre_s"), self._pptr(i, "pre_b")
             o.post_scale, o.post_shift = self._pptr(i, "post_s"), self._pptr(i, "post_b")
@@ -175,7 +215,7 @@ class Engine:
                         elif op.kind == PL.OP_CONV0 and fld == "x":
                             pass  # set per call
                         else:
-                            v.base += 4 * first * v.sn
+                            v.base += self.isz * first * v.sn
                 if op.kind == PL.OP_PREDMAP and o.w:
                     o.w += 4 * first * (self.plan.nr_types or 0) * self.plan.pred_map.h * self.plan.pred_map.w
             self._sub_ops[key] = ops
@@ -280,5 +320,6 @@ class Engine:
     def buffer(self, view, n):
         """Test hook: the activation window `view` of the first n samples as a tensor view."""
         b = view.buf
-        t = self.arena[:n, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
+        arena = self.arena if self.dtype == "fp32" else self.arena.view(torch.bfloat16)
+        t = arena[:n, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
         return t[:, view.y0:view.y0 + view.h, view.x0:view.x0 + view.w, view.c0:view.c0 + view.c]

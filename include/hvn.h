@@ -74,7 +74,10 @@ typedef struct hvn_op {
     hvn_view x2;         /* CONV, 1x1 only: optional second input (base NULL = none), sampled with spatial stride `_rsv` */
     const float *w, *bias, *pre_scale, *pre_shift, *post_scale, *post_shift; /* dev */
     int64_t batch_stride[3]; /* CONV with nbatch > 1: element strides of x, w, y between problems */
-    int32_t nbatch, _pad2;
+    int32_t nbatch;
+    int32_t act_dtype;   /* 0: fp32 activations / weights; 1: bf16 activations (x, res, y, x2) and packed weights
+                            ([cout_pad][ceil(x.c/64)][kh*kw][64] bf16, zero-filled past x.c), fp32 accumulation, fp32 bias /
+                            scales; CONV0 (bf16 output), CONV, UPADD, HEAD (bf16 input, fp32 logits) honour it */
 } hvn_op;
 
 /* -- library ---------------------------------------------------------------------- */

@@ -20,7 +20,7 @@ def rand_conv_weight(rng, cout, cin_g, k):
 
 
 def run_conv_case(n, xbuf_shape, xview, ybuf_shape, yview, wt, *, stride=1, pad=(0, 0), groups=1, bn=False, relu=0, pre=False,
-                  res=False, post=False, seed=0, inplace_res=False):
+                  res=False, post=False, seed=0, inplace_res=False, dtype="fp32"):
     """Builds one CONV op over strided views, runs it on the GPU and with the torch
     interpreter.  xview / yview = (y0, x0, h, w, c0, c).  Returns (got, want) NHWC tensors of the
     WHOLE output buffer (so writes outside the view would be caught)."""
@@ -51,16 +51,25 @@ def run_conv_case(n, xbuf_shape, xview, ybuf_shape, yview, wt, *, stride=1, pad=
         kw["res"] = rv
     op = P.conv("case", xv, yv, wt, stride=stride, pad=pad, groups=groups, relu=relu, **kw)
     P.pack()
-    eng = Engine(P, max_batch=n)
+    eng = Engine(P, max_batch=n, dtype=dtype)
     g = torch.Generator().manual_seed(seed)
-    eng.arena.copy_(torch.randn(eng.arena.shape, generator=g))
-    A = plan_interp.Arena(P, n)
-    A.flat.copy_(eng.arena.cpu())
+    if dtype == "bf16":
+        # bf16 path: the arena holds bf16; the reference sees the same (rounded) inputs and bf16-rounded weights, so
+        # what is left is the accumulation order and the rounding of the output to bf16
+        eng.arena.view(torch.bfloat16).copy_(torch.randn(eng.arena.shape, generator=g))
+        op.w = np.ascontiguousarray(torch.from_numpy(op.w).to(torch.bfloat16).float().numpy())
+        A = plan_interp.Arena(P, n)
+        A.flat.copy_(eng.arena.view(torch.bfloat16).float().cpu())
+    else:
+        eng.arena.copy_(torch.randn(eng.arena.shape, generator=g))
+        A = plan_interp.Arena(P, n)
+        A.flat.copy_(eng.arena.cpu())
     eng.run_raw(n)
     torch.cuda.synchronize()
     r = A.view(op.res).clone() if op.res is not None else None
     A.view(op.y).copy_(plan_interp.conv_ref(op, A.view(op.x).clone(), r))
     b = yb
-    got = eng.arena.cpu()[:, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
+    arena = eng.arena.view(torch.bfloat16).float().cpu() if dtype == "bf16" else eng.arena.cpu()
+    got = arena[:, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
     want = A.tensor(b)
     return got, want

@@ -1,0 +1,126 @@
+"""-m gpu: the bf16 path (BASELINE cfg 3: bf16 weights / activations, fp32 accumulation on the bf16 matrix cores).
+
+No reference bf16 exists, so the tolerances are declared here:
+* per kernel, against the fp32 interpreter fed the SAME bf16-rounded inputs and weights: 1.5 % of the output scale
+  (what remains is accumulation order and the rounding of the output to bf16, 2^-9 relative);
+* whole network, against the fp32 goldens made by the reference: logits within 6e-2 abs (mean abs error < 1.5e-2) on
+  logits of scale ~1-5, p_nuc within 2e-2, and the type-argmax / nucleus-threshold decisions agree on > 98 % / 99.5 %
+  of the pixels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _w(cout, cin_g, k, seed=1):
+    from gpu_util import rand_conv_weight
+    return rand_conv_weight(np.random.default_rng(seed), cout, cin_g, k)
+
+
+def _close(got, want, rtol=1.5e-2):
+    assert torch.isfinite(got).all()
+    scale = float(want.abs().max()) + 1e-6
+    err = float((got - want).abs().max())
+    assert err <= rtol * scale, "max err %.3e on scale %.3e" % (err, scale)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 256), (128, 512), (2048, 1024), (32, 32), (288, 128), (352, 128)])
+def test_bf16_conv1x1(cin, cout):
+    from gpu_util import run_conv_case
+    n, s = 2, 13
+    got, want = run_conv_case(n=n, xbuf_shape=(s, s, cin), xview=(0, 0, s, s, 0, cin), ybuf_shape=(s, s, cout), yview=(0, 0, s, s, 0, cout),
+                              wt=_w(cout, cin, 1), bn=True, relu=1, dtype="bf16")
+    _close(got, want)
+
+
+def test_bf16_prologue_residual_post_and_windows():
+    from gpu_util import run_conv_case
+    n, s = 2, 17
+    got, want = run_conv_case(n=n, xbuf_shape=(s, s, 64), xview=(0, 0, s, s, 0, 64), ybuf_shape=(s, s, 256), yview=(0, 0, s, s, 0, 256),
+                              wt=_w(256, 64, 1), res=True, post=True, dtype="bf16")
+    _close(got, want)
+    # prologue on a 288-channel window of a 512-channel concat buffer (odd number of 32-channel slabs: zero-filled tail)
+    got, want = run_conv_case(n=n, xbuf_shape=(s, s, 512), xview=(2, 2, s - 4, s - 4, 0, 288), ybuf_shape=(s - 4, s - 4, 128),
+                              yview=(0, 0, s - 4, s - 4, 0, 128), wt=_w(128, 288, 1), pre=True, bn=True, relu=1, dtype="bf16")
+    _close(got, want)
+    # in-place residual
+    got, want = run_conv_case(n=1, xbuf_shape=(20, 20, 64), xview=(0, 0, 20, 20, 0, 64), ybuf_shape=(20, 20, 128), yview=(0, 0, 20, 20, 0, 128),
+                              wt=_w(128, 64, 1), res=True, inplace_res=True, dtype="bf16")
+    _close(got, want)
+
+
+@pytest.mark.parametrize("k,stride,pad,cin,cout,groups", [(3, 1, (1, 1), 64, 64, 1), (3, 2, (0, 1), 128, 128, 1), (3, 1, (0, 0), 128, 32, 4),
+                                                          (5, 1, (0, 0), 128, 32, 4), (5, 1, (2, 2), 256, 64, 1), (3, 1, (0, 0), 512, 128, 1)])
+def test_bf16_spatial_convs(k, stride, pad, cin, cout, groups):
+    from gpu_util import run_conv_case
+    n, s = 2, 20
+    so = (s + pad[0] + pad[1] - k) // stride + 1
+    # grouped conv writes a 32-channel window of a wider concat buffer (dense unit)
+    ybuf = (so, so, cout + 64)
+    got, want = run_conv_case(n=n, xbuf_shape=(s, s, cin), xview=(0, 0, s, s, 0, cin), ybuf_shape=ybuf, yview=(0, 0, so, so, 64, cout),
+                              wt=_w(cout, cin // groups, k), stride=stride, pad=pad, groups=groups, bn=True, relu=1, dtype="bf16")
+    _close(got[..., 64:], want[..., 64:])
+
+
+def _run_net(name, dtype):
+    from hover_net_amd import net_desc, run_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    g = np.load(os.path.join(GOLD, "net_%s.npz" % name))
+    mode, nt = str(g["mode"]), int(g["nr_types"])
+    nt = None if nt < 0 else nt
+    net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
+    net.load_state_dict(synth_state_dict(mode, nt, seed=int(g["wseed"])), strict=True)
+    net.compute_dtype = dtype
+    net = net.to("cuda").eval()
+    size = 270 if mode == "original" else 256
+    tiles = torch.from_numpy(synth_tiles(int(g["n"]), size, seed=int(g["tseed"])))
+    pred = run_desc.infer_step_device(tiles, net)
+    eng = net.engine(tiles.shape[0])
+    logits = {k: v[:tiles.shape[0]].cpu() for k, v in eng.logits.items()}
+    return g, nt, logits, pred.cpu()
+
+
+@pytest.mark.parametrize("name", ["fast6", "orig5"])
+def test_bf16_network_within_declared_tolerance(name):
+    g, nt, logits, pred = _run_net(name, "bf16")
+    crop = int(g["crop"])
+    worst = 0.0
+    for k, v in logits.items():
+        ref = torch.from_numpy(g["logits_" + k])
+        if crop > 0:
+            o = (v.shape[2] - crop) // 2
+            v = v[:, :, o:o + crop, o:o + crop]
+        err = (v - ref).abs()
+        worst = max(worst, float(err.max()))
+        assert float(err.max()) < 6e-2 and float(err.mean()) < 1.5e-2, (k, float(err.max()), float(err.mean()))
+    pm = torch.from_numpy(g["pred_map"])
+    if crop > 0:
+        o = (pred.shape[1] - crop) // 2
+        pred = pred[:, o:o + crop, o:o + crop]
+    c0 = 0 if nt is None else 1
+    assert float((pred[..., c0] - pm[..., c0]).abs().max()) < 2e-2
+    assert float(((pred[..., c0] >= 0.5) == (pm[..., c0] >= 0.5)).float().mean()) > 0.995
+    if nt is not None:
+        assert float((pred[..., 0] == pm[..., 0]).float().mean()) > 0.98
+    print("bf16 %s: worst logit error %.4f" % (name, worst))
+
+
+def test_bf16_batch_invariance_and_dtype_switch():
+    """The same tile alone and inside a batch gives identical bf16 logits; switching compute_dtype rebuilds the plan."""
+    from hover_net_amd import net_desc, run_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    net = net_desc.create_model(mode="fast", nr_types=None, input_ch=3)
+    net.load_state_dict(synth_state_dict("fast", None, seed=4), strict=True)
+    net = net.to("cuda").eval()
+    net.compute_dtype = "bf16"
+    tiles = torch.from_numpy(synth_tiles(5, 256, seed=9))
+    a = run_desc.infer_step_device(tiles, net).cpu().clone()
+    b = run_desc.infer_step_device(tiles[3:4], net).cpu()
+    assert torch.equal(a[3:4], b)
+    net.compute_dtype = "fp32"
+    c = run_desc.infer_step_device(tiles, net).cpu()
+    assert float((a[..., 0] - c[..., 0]).abs().max()) < 2e-2 and not torch.equal(a, c)
