@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16 (cfg 3 only: --dtype bf16)
 
 
 def main():
@@ -38,6 +39,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--quiet-net-output", action="store_true",
+                    help="bias the NP head of the random-init checkpoint towards background, so that the network's own output "
+                         "holds no nuclei and the instance-separation load of the step comes from the structured maps only "
+                         "(the 'fast'-mode random init otherwise emits tile-filling blobs, the flood's worst case)")
+    ap.add_argument("--dtype", default="fp32", choices=("fp32", "bf16"),
+                    help="fp32 = the headline configuration (BASELINE cfg 2); bf16 = cfg 3 (use with --mode fast --nr-types 6 --batch 64)")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,9 +68,12 @@ def main():
     nt = args.nr_types if args.nr_types > 0 else None
     size = 270 if args.mode == "original" else 256
     sd = synth_state_dict(args.mode, nt, seed=0)
+    if args.quiet_net_output:
+        sd["decoder.np.u0.conv.bias"] = torch.tensor([8.0, -8.0])
     net = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
     net.load_state_dict(sd, strict=True)
     net.max_batch = args.batch
+    net.compute_dtype = args.dtype
     net = net.to(dev).eval()
     tiles = torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank)).to(dev)  # resident in HBM
     # A random-init network emits maps without nuclei (0 instances -> the watershed has nothing to
@@ -104,7 +114,7 @@ def main():
     n_inst = int(out[2].sum().item())
 
     result = {
-        "metric": "tiles/sec (270x270, batch 32) end-to-end incl. watershed",
+        "metric": "tiles/sec (%dx%d, batch %d) end-to-end incl. watershed" % (size, size, args.batch),
         "value": world * args.batch * args.steps / dt,
         "unit": "tiles/s",
         "n_gpus": world,
@@ -114,12 +124,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "fp32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 tiles per GPU, "
-                               "random-init checkpoint (seeded), network + infer_step epilogue + on-GPU watershed post-proc "
+                               "random-init checkpoint (seeded%s), network + infer_step epilogue + on-GPU watershed post-proc "
                                "(of the network output AND of a resident batch of structured synthetic maps, see bench.py)"
-                               % (args.mode, nt, args.batch, size, size),
+                               % (args.mode, nt, args.batch, size, size, ", NP head biased to background" if args.quiet_net_output else ""),
                    "global_batch": world * args.batch, "instances_last_step": n_inst, "parallelism": "tile-sharded x%d" % world},
     }
 
@@ -157,13 +167,15 @@ def main():
         # (tools/pmc_traffic.py, gfx950 x2 correction on FETCH_SIZE); cannot be collected live
         traffic = None
         tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5:
+        if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5 and args.dtype == "fp32":
             traffic = json.load(open(tpath))["hbm_bytes_per_step"]
-        result["roofline"] = {"bound": "mfma", "kernel": "hvn_conv_igemm_f32", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+        peak = PEAK_FP32_MATRIX_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+        result["roofline"] = {"bound": "mfma", "kernel": "hvn_conv_igemm_f32" if args.dtype == "fp32" else "hvn_conv_igemm_bf16",
+                              "achieved": achieved, "peak": peak,
+                              "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                               "traffic_unit": "HBM bytes per step (all conv launches; rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                               "launches_per_step": launches, "conv_ms_per_step": ms, "conv_gflop_per_step": conv_flops / 1e9,
-                              "executed": {"achieved": executed, "frac": executed / PEAK_FP32_MATRIX_TFLOPS, "gflop_per_step": exec_flops / 1e9,
+                              "executed": {"achieved": executed, "frac": executed / peak, "gflop_per_step": exec_flops / 1e9,
                                            "note": "MFMA FLOPs issued after Winograd F(4x4,5x5) on the 5x5 convs; `achieved` above is "
                                                    "direct-convolution (algorithmic) FLOPs over the same time, transforms included"}}
 

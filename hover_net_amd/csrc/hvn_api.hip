@@ -148,9 +148,14 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.ty = op->kh; a.tx = op->kw; a.pad = op->pad_t; a.relu = op->relu;
         a.accum = (!in && op->res.base != nullptr) ? 1 : 0;
         if (a.accum && op->res.base != op->y.base) return fail(HVN_E_ARG, "wino_out: res must alias y (accumulate in place)%s", "");
-        const int n2 = in ? op->y.h : op->x.h;       // transform positions: 36 -> F(2x2,5x5), 64 -> F(4x4,5x5)
-        a.m = n2 == 36 ? 2 : n2 == 64 ? 4 : 0;
-        if (!a.m) return fail(HVN_E_ARG, "winograd transform: %s%ld transform positions (36 or 64 expected)", "", (long)n2);
+        const int n2 = in ? op->y.h : op->x.h;       // transform positions (m + r - 1)^2
+        if (op->stride > 1 && op->_rsv > 1) {         // explicit F(m x m, r x r): stride = m, _rsv = r
+            a.m = op->stride; a.r = op->_rsv;
+        } else {                                     // legacy encoding by the number of positions: 5x5 filters
+            a.m = n2 == 36 ? 2 : n2 == 64 ? 4 : 0; a.r = 5;
+        }
+        if (!a.m || (a.m + a.r - 1) * (a.m + a.r - 1) != n2 || !((a.m == 2 && a.r == 5) || (a.m == 4 && (a.r == 5 || a.r == 3))))
+            return fail(HVN_E_ARG, "winograd transform: %s%ld transform positions do not match F(2,5) / F(4,5) / F(4,3)", "", (long)n2);
         if (!a.x || !a.y || !a.mat || a.ty <= 0 || a.tx <= 0 || (a.C & 3)) return fail(HVN_E_ARG, "winograd transform: bad descriptor%s", "");
         if (!aligned16(a.x) || !aligned16(a.y) || ((a.xsn | a.xsy | a.xsx | a.ysn | a.ysy | a.ysx) & 3))
             return fail(HVN_E_ARG, "winograd transform: views not 16-byte aligned%s", "");

@@ -241,52 +241,61 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
                 ep[row * EP_LD + wn * WN + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
-    constexpr int CH = BN / 4;
+    constexpr int CH = BN / 8;            // 8 output channels (16 B of bf16) per thread
     constexpr int RPP = 256 / CH;
-    const int ecol = (tid % CH) * 4;
+    const int ecol = (tid % CH) * 8;
     const int erow0 = tid / CH;
     const int co = n0 + ecol;
-    const bool cok = co < p.Cout;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, qs = {1.f, 1.f, 1.f, 1.f}, qb = bias;
+    const bool cok = co < p.Cout;         // Cout is a multiple of 8 on this path (validated on the host)
+    f32x4 bias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, qs[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, qb[2] = {bias[0], bias[0]};
     const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr;
     if (cok) {
-        if (p.bias) bias = *(const f32x4 *)(p.bias + co);
-        if (has_post) {
-            qs = *(const f32x4 *)(p.post_s + co);
-            qb = *(const f32x4 *)(p.post_b + co);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (p.bias) bias[h] = *(const f32x4 *)(p.bias + co + 4 * h);
+            if (has_post) {
+                qs[h] = *(const f32x4 *)(p.post_s + co + 4 * h);
+                qb[h] = *(const f32x4 *)(p.post_b + co + 4 * h);
+            }
         }
     }
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
     const float post_lo = has_post ? 0.f : -__builtin_inff();
     uint16_t *py = (uint16_t *)p.y;
     const uint16_t *pres = (const uint16_t *)p.res;
-    for (int it = 0; it < BM / RPP; ++it) {
-        const int rr = erow0 + it * RPP;
-        const unsigned m = m0 + rr;
-        if (!(m < M && cok)) continue;
-        const unsigned n = m / HoWo;
-        const unsigned rem = m - n * HoWo;
-        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
-        f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol);
-        v.x = fmaxf(v.x + bias.x, relu_lo);
-        v.y = fmaxf(v.y + bias.y, relu_lo);
-        v.z = fmaxf(v.z + bias.z, relu_lo);
-        v.w = fmaxf(v.w + bias.w, relu_lo);
-        if (has_res) {
-            const u32x2 r2 = *(const u32x2 *)(pres + (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co);
-            v.x += bf_lo(r2.x);
-            v.y += bf_hi(r2.x);
-            v.z += bf_lo(r2.y);
-            v.w += bf_hi(r2.y);
+    if (erow0 < BM) {
+        for (int it = 0; it < (BM + RPP - 1) / RPP; ++it) {
+            const int rr = erow0 + it * RPP;
+            const unsigned m = m0 + rr;
+            if (rr >= BM || !(m < M && cok)) continue;
+            const unsigned n = m / HoWo;
+            const unsigned rem = m - n * HoWo;
+            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+            u32x4 r4 = {0u, 0u, 0u, 0u};
+            if (has_res) r4 = *(const u32x4 *)(pres + (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co);
+            u32x4 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol + 4 * h);
+                v.x = fmaxf(v.x + bias[h].x, relu_lo);
+                v.y = fmaxf(v.y + bias[h].y, relu_lo);
+                v.z = fmaxf(v.z + bias[h].z, relu_lo);
+                v.w = fmaxf(v.w + bias[h].w, relu_lo);
+                if (has_res) {
+                    v.x += bf_lo(r4[2 * h]);
+                    v.y += bf_hi(r4[2 * h]);
+                    v.z += bf_lo(r4[2 * h + 1]);
+                    v.w += bf_hi(r4[2 * h + 1]);
+                }
+                v.x = fmaxf(fmaf(v.x, qs[h].x, qb[h].x), post_lo);
+                v.y = fmaxf(fmaf(v.y, qs[h].y, qb[h].y), post_lo);
+                v.z = fmaxf(fmaf(v.z, qs[h].z, qb[h].z), post_lo);
+                v.w = fmaxf(fmaf(v.w, qs[h].w, qb[h].w), post_lo);
+                o[2 * h] = pack_bf(v.x, v.y);
+                o[2 * h + 1] = pack_bf(v.z, v.w);
+            }
+            *(u32x4 *)(py + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co) = o;
         }
-        v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
-        v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
-        v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
-        v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
-        u32x2 o;
-        o.x = pack_bf(v.x, v.y);
-        o.y = pack_bf(v.z, v.w);
-        *(u32x2 *)(py + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co) = o;
     }
 }
 
@@ -312,7 +321,8 @@ static int launch_bf16(const ConvArgs &a, hipStream_t stream)
 
 int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream)
 {
-    if (a.Cin % 32 != 0 || a.Cin <= 0 || a.Cout % 4 != 0 || a.nbatch > 1) return -1;
+    if (a.Cin % 32 != 0 || a.Cin <= 0 || a.Cout % 8 != 0 || a.nbatch > 1) return -1;
+    if ((((uintptr_t)a.y) & 15) || ((a.ysn | a.ysy | a.ysx) & 7) || (a.res && ((((uintptr_t)a.res) & 15) || ((a.rsn | a.rsy | a.rsx) & 7)))) return -1;   // 16-byte epilogue accesses
     if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
     const long span = 2 * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
     if (span < 0 || span * 2 >= (1L << 31)) return -1;

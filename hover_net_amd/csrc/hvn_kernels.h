@@ -83,6 +83,7 @@ struct WinoArgs {
     int N, H, W, C;       // WINO_IN: input window extent / channels; WINO_OUT: output extent / cout
     int ty, tx, pad, relu;
     int m;                // output tile edge: 2 or 4
+    int r;                // filter edge: 5 or 3 (n = m + r - 1)
     int accum;            // WINO_OUT: y += result (data gradients accumulate)
 };
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream);

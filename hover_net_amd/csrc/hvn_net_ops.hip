@@ -234,7 +234,8 @@ int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream)
 }
 
 // ---------------------------------------------------------------------------------------
-// Winograd F(m x m, 5x5) transforms (m = 2 or 4, n = m + 4) around the batched GEMM of the 5x5 decoder convs
+// Winograd F(m x m, r x r) transforms (n = m + r - 1: F(2,5), F(4,5) for the 5x5 decoder convs, F(4,3) for the
+// encoder's stride-1 3x3 convs with K >= 256) around the batched GEMM
 // (net_desc.py:45,52,59 conva; 51 % of the network's FLOPs).  y = A^T [ (G g G^T) .* (B^T d B) ] A:
 // n^2 multiplications per m^2 outputs instead of 25 m^2 (hover_net_amd/winograd.py derives the matrices).
 // Both kernels are HBM-bound byte movers: one thread = one tile x VW channels, consecutive threads on
@@ -243,10 +244,10 @@ template <int VW> struct WVec;
 template <> struct WVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 template <> struct WVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 
-template <int MO, int VW>
+template <int MO, int R, int VW>
 __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
 {
-    constexpr int NW = MO + 4;
+    constexpr int NW = MO + R - 1;
     typedef typename WVec<VW>::T VT;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -297,20 +298,24 @@ __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
 
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream)
 {
-    if (a.m == 2) {
+    if (a.m == 2 && a.r == 5) {
         const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
-        hipLaunchKernelGGL((hvn_wino_in<2, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
-    } else {
+        hipLaunchKernelGGL((hvn_wino_in<2, 5, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 4 && a.r == 3) {
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
+        hipLaunchKernelGGL((hvn_wino_in<4, 3, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 4 && a.r == 5) {
         const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
-        hipLaunchKernelGGL((hvn_wino_in<4, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
-    }
+        hipLaunchKernelGGL((hvn_wino_in<4, 5, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else
+        return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int MO, int VW>
+template <int MO, int R, int VW>
 __global__ __launch_bounds__(256) void hvn_wino_out(const WinoArgs p, long total)
 {
-    constexpr int NW = MO + 4;
+    constexpr int NW = MO + R - 1;
     typedef typename WVec<VW>::T VT;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -362,12 +367,16 @@ __global__ __launch_bounds__(256) void hvn_wino_out(const WinoArgs p, long total
 
 int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream)
 {
-    if (a.m == 2) {
+    if (a.m == 2 && a.r == 5) {
         const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
-        hipLaunchKernelGGL((hvn_wino_out<2, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
-    } else {
+        hipLaunchKernelGGL((hvn_wino_out<2, 5, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 4 && a.r == 3) {
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 4);
+        hipLaunchKernelGGL((hvn_wino_out<4, 3, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 4 && a.r == 5) {
         const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
-        hipLaunchKernelGGL((hvn_wino_out<4, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
-    }
+        hipLaunchKernelGGL((hvn_wino_out<4, 5, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else
+        return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

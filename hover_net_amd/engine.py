@@ -138,6 +138,7 @@ class Engine:
                 o.batch_stride[bi] = int(bs)
             if op.kind in (PL.OP_WINO_IN, PL.OP_WINO_OUT):
                 o.kh, o.kw = op.extra["tiles"]
+                o.stride, o._rsv = op.extra["m"], op.extra.get("r", 5)      # F(m x m, r x r)
             if op.kind == PL.OP_PREDMAP:
                 o.x.base = self.logits["np"].data_ptr()
                 o.res.base = self.logits["hv"].data_ptr()

@@ -223,28 +223,30 @@ class Plan:
         return self.add(op)
 
     def conv_winograd(self, name, x, y, wt, *, pad=(0, 0), bn=None, relu=0, share_in=False, m=4):
-        """5x5 stride-1 conv as Winograd F(m x m, 5x5): WINO_IN (shared between convs that read the same view with
-        the same padding) -> batched CONV over the (m+4)^2 transform positions -> WINO_OUT (+bias, ReLU).
-        Output extents that are not a multiple of m get a partial last tile (its surplus outputs are not written)."""
+        """r x r (5x5 or 3x3) stride-1 conv as Winograd F(m x m, r x r): WINO_IN (shared between convs that read the
+        same view with the same padding) -> batched CONV over the (m+r-1)^2 transform positions -> WINO_OUT (+bias,
+        ReLU).  Output extents that are not a multiple of m get a partial last tile (its surplus outputs are not
+        written)."""
         from . import winograd as WG
 
         cout, cin, kh, kw = wt.shape
-        assert (kh, kw) == (5, 5) and m in (2, 4) and x.c == cin and y.c == cout
-        assert y.h == x.h + pad[0] + pad[1] - 4
-        at, _g, bt = WG.MATS[m]
-        n2 = (m + 4) ** 2
+        assert kh == kw and (kh, m) in ((5, 2), (5, 4), (3, 4)) and x.c == cin and y.c == cout
+        r = kh
+        assert y.h == x.h + pad[0] + pad[1] - (r - 1)
+        at, _g, bt = WG.mats(m, r)
+        n2 = (m + r - 1) ** 2
         s = b = None
         if bn is not None:
             s, b = bn
             wt = wt * s[:, None, None, None]
         ty, tx = -(-y.h // m), -(-y.w // m)
         t1 = ty * tx
-        key = (id(x.buf), x.y0, x.x0, x.h, x.w, x.c0, x.c, pad[0], m)
+        key = (id(x.buf), x.y0, x.x0, x.h, x.w, x.c0, x.c, pad[0], m, r)
         cache = self.__dict__.setdefault("_wino_in", {})
         if key not in cache:
             vbuf = self.buf(name + ".V", n2, t1, cin)
             op = Op(OP_WINO_IN, name + ".wino_in", x=x, y=View(vbuf), w=np.ascontiguousarray(bt, np.float32),
-                    pad_t=pad[0], pad_l=pad[0], extra={"tiles": (ty, tx), "shared": share_in, "m": m})
+                    pad_t=pad[0], pad_l=pad[0], extra={"tiles": (ty, tx), "shared": share_in, "m": m, "r": r})
             self.add(op)
             cache[key] = vbuf
         vbuf = cache[key]
@@ -256,12 +258,12 @@ class Plan:
         packed[:, :cout] = u.reshape(n2, cout, cin // 32, 1, 32)
         g = Op(OP_CONV, name + ".wino_gemm", x=View(vbuf, 0, 0, 1, t1), y=View(mbuf, 0, 0, 1, t1), w=packed, cout=cout, tile_n=tn)
         g.extra.update(nbatch=n2, batch_strides=(t1 * cin, cout_pad * cin, t1 * cout), cin_real=cin, groups=1,
-                       algo_flops=2.0 * y.h * y.w * cout * cin * 25, exec_flops=2.0 * n2 * t1 * cout * cin)
+                       algo_flops=2.0 * y.h * y.w * cout * cin * r * r, exec_flops=2.0 * n2 * t1 * cout * cin)
         self.add(g)
         for bb in (vbuf, mbuf):   # the batched launch touches every row of V and M
             bb.last = max(bb.last, len(self.ops) - 1)
         o = Op(OP_WINO_OUT, name + ".wino_out", x=View(mbuf), y=y, w=np.ascontiguousarray(at, np.float32),
-               bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m})
+               bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m, "r": r})
         return self.add(o)
 
     # -- memory planning --------------------------------------------------------
@@ -295,6 +297,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     if winograd is None:
         winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
     wino_m = 4 if winograd is True else int(winograd)
+    wino3 = int(os.environ.get("HVN_WINOGRAD3", "256"))      # minimum channel count for F(4x4,3x3) in the encoder; 0 = off
     P = Plan(mode, nr_types)
     g = P.geo
     k = g["k"]
@@ -325,8 +328,13 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
             P.conv(p + "conv1", cur, t1, W(p + "conv1.weight"), bn=BN(p + "conv1/bn"), relu=1,
                    pre=None if i == 0 else BN(p + "preact/bn"))
             t2 = View(P.buf(p + "t2", ho, ho, c2))
-            P.conv(p + "conv2", t1, t2, W(p + "conv2.weight"), stride=st, pad=_tf_same(t1.h, 3, st),
-                   bn=BN(p + "conv2/bn"), relu=1)
+            if st == 1 and winograd and wino3 and c1 >= wino3:
+                # stride-1 3x3 with K >= 256 (d2, d3): Winograd F(4x4,3x3), 2.25 instead of 9 multiplies per output;
+                # below that the transform-domain tensors make the layer HBM-bound (d0: K = 64, d1: K = 128)
+                P.conv_winograd(p + "conv2", t1, t2, W(p + "conv2.weight"), pad=_tf_same(t1.h, 3, 1), bn=BN(p + "conv2/bn"), relu=1, m=4)
+            else:
+                P.conv(p + "conv2", t1, t2, W(p + "conv2.weight"), stride=st, pad=_tf_same(t1.h, 3, st),
+                       bn=BN(p + "conv2/bn"), relu=1)
             last = i == units - 1
             out = View(P.buf(name + ".out", ho, ho, c3)) if last else acc
             if i == 0:

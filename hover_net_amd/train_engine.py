@@ -211,14 +211,14 @@ class TrainEngine:
         def tview(ptr, h, c):
             return self._tview(ptr, t1, h, c)
         vp, mp = (self.wino_v if vbuf is None else vbuf).data_ptr(), self.wino_m.data_ptr()
-        ops = [self._net(kind=OP_WINO_IN, kh=ty, kw=tx, pad_t=pad, pad_l=pad, x=xin, y=tview(vp, 64, cin), w=self._bt_ptr)]
+        ops = [self._net(kind=OP_WINO_IN, kh=ty, kw=tx, stride=4, _rsv=5, pad_t=pad, pad_l=pad, x=xin, y=tview(vp, 64, cin), w=self._bt_ptr)]
         g = dict(kind=OP_CONV, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, relu=0, cout=cout, tile_n=_tile_n(cout), groups=1,
                  x=tview(vp, 1, cin), y=tview(mp, 1, cout), w=wptr, nbatch=64)
         t = self._net(**g)
         o = self._keep[-1]
         o.batch_stride[0], o.batch_stride[1], o.batch_stride[2] = t1 * cin, lead * cin, t1 * cout
         ops.append(t)
-        kw = dict(kind=OP_WINO_OUT, kh=ty, kw=tx, relu=0, cout=cout, x=tview(mp, 64, cout), y=yout, w=self._at_ptr)
+        kw = dict(kind=OP_WINO_OUT, kh=ty, kw=tx, stride=4, _rsv=5, relu=0, cout=cout, x=tview(mp, 64, cout), y=yout, w=self._at_ptr)
         if accumulate:
             kw["res"] = yout
         ops.append(self._net(**kw))

@@ -57,9 +57,10 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           nbatch > 1: `nbatch` independent problems in one launch; problem b reads x.base + b*batch_stride[0],
  *           w + b*batch_stride[1] and writes y.base + b*batch_stride[2] (elements) -- the n*n transform-domain
  *           products of a Winograd convolution,
- *   WINO_IN  Winograd F(m x m, 5x5) input transform of a 5x5 stride-1 conv (net_desc.py:45,52,59 conva), m = 2 or 4,
- *           n = m + 4: x = input view (zero padding pad_t/pad_l), y = V as [n*n][tiles][c] per sample (y.h = n*n = 36
- *           or 64 selects m, y.w = tiles), kh x kw = tile grid, w = B^T (n x n),
+ *   WINO_IN  Winograd F(m x m, r x r) input transform of a stride-1 conv: F(2,5) / F(4,5) for the 5x5 decoder convs
+ *           (net_desc.py:45,52,59 conva), F(4,3) for the encoder's 3x3 convs (net_utils.py:186-196), n = m + r - 1:
+ *           x = input view (zero padding pad_t/pad_l), y = V as [n*n][tiles][c] per sample (y.w = tiles),
+ *           kh x kw = tile grid, w = B^T (n x n), stride = m, _rsv = r (both 0: r = 5 and m from y.h = 36 | 64),
  *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [n*n][tiles][cout] per sample, w = A^T (m x n), kh x kw = tile grid
  *           covering y (a partial last tile's surplus outputs are dropped); res = y: accumulate (y += ...),
  *   UPADD   y = nearest2x(x) + res

@@ -91,10 +91,10 @@ def wino_in_ref(op, x):
     """x [N,h,w,c] -> V [N,n*n,T,c] with T = ty*tx tiles (row-major), n = m + 4."""
     ty, tx = op.extra["tiles"]
     m = op.extra["m"]
-    n_ = m + 4
+    n_ = m + op.extra.get("r", 5) - 1
     bt = torch.from_numpy(op.w)                       # [n,n]
     pt = op.pad_t
-    need_h, need_w = m * ty + 4, m * tx + 4
+    need_h, need_w = m * ty + (n_ - m), m * tx + (n_ - m)
     xp = F.pad(x.permute(0, 3, 1, 2), (pt, need_w - x.shape[2] - pt, pt, need_h - x.shape[1] - pt))
     tiles = xp.unfold(2, n_, m).unfold(3, n_, m)      # [N,c,ty,tx,n,n]
     v = torch.einsum("ai,nctsij,bj->nabtsc", bt, tiles, bt)
@@ -111,7 +111,7 @@ def wino_out_ref(op, mm):
     """mm [N,n2,T,cout] -> y [N,ho,wo,cout] (partial last tiles cropped)."""
     ty, tx = op.extra["tiles"]
     m = op.extra["m"]
-    n_ = m + 4
+    n_ = m + op.extra.get("r", 5) - 1
     at = torch.from_numpy(op.w)                        # [m,n]
     nb, _, _, co = mm.shape
     mm = mm.reshape(nb, n_, n_, ty, tx, co)

@@ -146,13 +146,13 @@ def test_conv1x1_fused_shortcut_second_input(stride2, cin2, cout):
     _check(got, want)
 
 
-@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("m,k", [(2, 5), (4, 5), (4, 3)])
 @pytest.mark.parametrize("cin,cout,s,pad,bn", [(64, 128, 14, (0, 0), False), (256, 64, 12, (2, 2), True), (1024, 256, 10, (0, 0), False),
-                                               (64, 32, 17, (0, 0), True)])
-def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn, m):
-    """WINO_IN -> batched GEMM -> WINO_OUT (F(m x m,5x5)) against a direct fp32 5x5 convolution, writing into a
-    channel window of a wider buffer like the dense-block concat; output extents that are not a multiple of m
-    exercise the partial last tile."""
+                                               (64, 32, 17, (0, 0), True), (512, 512, 33, (1, 1), True)])
+def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn, m, k):
+    """WINO_IN -> batched GEMM -> WINO_OUT (F(m x m, k x k): F(2,5), F(4,5), F(4,3)) against a direct fp32
+    convolution, writing into a channel window of a wider buffer like the dense-block concat; output extents that
+    are not a multiple of m exercise the partial last tile."""
     import plan_interp
     import torch.nn.functional as F
     from gpu_util import MiniPlan, rand_conv_weight
@@ -161,12 +161,12 @@ def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn, m):
 
     rng = np.random.default_rng(7)
     n = 2
-    so = s + pad[0] + pad[1] - 4
+    so = s + pad[0] + pad[1] - (k - 1)
     P = MiniPlan()
     x = PL.View(P.buf("x", s, s, cin))
     ybuf = P.buf("y", so, so, cout + 32)
     y = PL.View(ybuf, 0, 0, so, so, 32, cout)
-    wt = rand_conv_weight(rng, cout, cin, 5)
+    wt = rand_conv_weight(rng, cout, cin, k)
     kw = dict(bn=(rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.2, cout)), relu=1) if bn else {}
     P.conv_winograd("w", x, y, wt, pad=pad, m=m, **kw)
     ybuf.first = 0      # keep the output buffer live from the start so the packer cannot lend its space to V / M
