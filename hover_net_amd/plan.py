@@ -297,7 +297,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     if winograd is None:
         winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
     wino_m = 4 if winograd is True else int(winograd)
-    wino3 = int(os.environ.get("HVN_WINOGRAD3", "256"))      # minimum channel count for F(4x4,3x3) in the encoder; 0 = off
+    wino3 = int(os.environ.get("HVN_WINOGRAD3", "128"))      # minimum channel count for F(4x4,3x3) in the encoder; 0 = off
     P = Plan(mode, nr_types)
     g = P.geo
     k = g["k"]
@@ -329,8 +329,8 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
                    pre=None if i == 0 else BN(p + "preact/bn"))
             t2 = View(P.buf(p + "t2", ho, ho, c2))
             if st == 1 and winograd and wino3 and c1 >= wino3:
-                # stride-1 3x3 with K >= 256 (d2, d3): Winograd F(4x4,3x3), 2.25 instead of 9 multiplies per output;
-                # below that the transform-domain tensors make the layer HBM-bound (d0: K = 64, d1: K = 128)
+                # stride-1 3x3 with K >= 128 (d1, d2, d3): Winograd F(4x4,3x3), 2.25 instead of 9 multiplies per output;
+                # below that the transform-domain tensors make the layer HBM-bound (d0: K = 64); measured 453 (off) / 484 (K >= 256) / 497 (K >= 128) tiles/s
                 P.conv_winograd(p + "conv2", t1, t2, W(p + "conv2.weight"), pad=_tf_same(t1.h, 3, 1), bn=BN(p + "conv2/bn"), relu=1, m=4)
             else:
                 P.conv(p + "conv2", t1, t2, W(p + "conv2.weight"), stride=st, pad=_tf_same(t1.h, 3, st),
@@ -366,9 +366,11 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
             p = pb + uname + "."
             ctot = cmid + units * arch.DENSE_GROWTH
             cat = View(P.buf(p + "cat", cat_sz, cat_sz, ctot))
-            if k == 5 and winograd:
+            if winograd and (k == 5 or wino3):
                 # the u3 input is the same for every branch: its transform runs once, before the branch lanes fork
-                P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"), m=wino_m)
+                # (5x5: F(wino_m, 5); the 'fast' mode's 3x3: F(4, 3))
+                P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"),
+                                m=wino_m if k == 5 else 4)
             else:
                 P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
             c = cmid
@@ -387,9 +389,9 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
             P.add(Op(OP_UPADD, p + "upadd", x=uo, res=skip, y=nxt))
             cur_in = nxt
         u1 = View(P.buf(pb + "u1", g["out"], g["out"], 64))
-        if k == 5 and winograd:
+        if winograd and (k == 5 or wino3):
             P.conv_winograd(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
-                            bn=BN(pb + "u0.bn"), relu=1, m=wino_m)
+                            bn=BN(pb + "u0.bn"), relu=1, m=wino_m if k == 5 else 4)
         else:
             P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
                    bn=BN(pb + "u0.bn"), relu=1)
