@@ -456,10 +456,14 @@ struct HItem {  // heap item with its value inline: one dependent LDS read per h
 
 // Returns the number of tie events seen (saturating at 2).  `swap_first_tie`: at the first tie event pop the
 // OTHER tied item first -- used to prove a 2-way tie harmless (both orders give the same labels).
-template <bool INLINE_VAL, typename VP, typename OP>
-__device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, bool swap_first_tie)
+// HM = heap mode: 0 = 8-byte items (value looked up in VAL), 1 = 16-byte items with the value inline, 2 = inline items
+// with the first `cap` slots (the top levels of the heap, where every pop's sift-down spends its time) in LDS
+// (`heap_raw`) and the rest in HBM (`heap_far`, indexed by the same slot number): windows larger than the LDS.
+template <int HM, typename VP, typename OP>
+__device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, bool swap_first_tie, HItem *heap_far = nullptr, int cap = 0)
 {
     typedef unsigned long long u64;
+    constexpr bool INLINE_VAL = HM != 0;
     HItem *h16 = (HItem *)heap_raw;
     u64 *h8 = (u64 *)heap_raw;
     const int A = bh * bw;
@@ -467,7 +471,11 @@ __device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, b
     int ties = 0;
     auto less = [](double va, u64 a, double vb, u64 b) { return va != vb ? va < vb : (a >> 32) < (b >> 32); };
     auto get = [&](int i, u64 &it, double &v) {
-        if constexpr (INLINE_VAL) {
+        if constexpr (HM == 2) {
+            const HItem t = i < cap ? h16[i] : heap_far[i];
+            it = t.ai;
+            v = t.v;
+        } else if constexpr (INLINE_VAL) {
             const HItem t = h16[i];
             it = t.ai;
             v = t.v;
@@ -477,7 +485,10 @@ __device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, b
         }
     };
     auto put = [&](int i, u64 it, double v) {
-        if constexpr (INLINE_VAL) h16[i] = HItem{v, it};
+        if constexpr (HM == 2) {
+            if (i < cap) h16[i] = HItem{v, it};
+            else heap_far[i] = HItem{v, it};
+        } else if constexpr (INLINE_VAL) h16[i] = HItem{v, it};
         else h8[i] = it;
     };
     auto push = [&](u64 it, double itv) {
@@ -552,15 +563,18 @@ __device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, b
         const int nb[4] = {idx - bw, idx - 1, idx + 1, idx + bw};  // neighbour order of skimage
         const bool ok[4] = {y > 0, x > 0, x < bw - 1, y < bh - 1};
         int oq[4];
+        double nv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) oq[k] = ok[k] ? out[nb[k]] : -1;  // four independent LDS reads in flight
+        for (int k = 0; k < 4; ++k) oq[k] = ok[k] ? out[nb[k]] : -1;  // four independent reads in flight
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nv[k] = (HM == 2 && ok[k]) ? val[nb[k]] : 0.;  // HBM values: fetched together, not one per push
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (oq[k] != 0) continue;  // -1: not in the mask / this component, >0: already labelled
             const int q = nb[k];
             age += 1;
             out[q] = lab;
-            push(((u64)age << 32) | (unsigned)q, val[q]);
+            push(((u64)age << 32) | (unsigned)q, HM == 2 ? nv[k] : val[q]);
         }
     }
     return ties;
@@ -569,6 +583,7 @@ __device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, b
 #define WS_AMAX 7600  // largest window replayed out of LDS (8-byte heap items: 20 B per pixel -> 152 KB)
 #define WS_AMAX16 5400  // ... with the value inline in the heap item (28 B per pixel)
 #define WS_LDS_BYTES (WS_AMAX * 20)
+#define WS_MIN_CAP 1024  // oversized windows: at least this many heap slots (the top 10 levels) stay in LDS
 
 // planes that are dead by now are re-used: par2 = ymin, hraw = ymax, vraw = xmin, cnt = xmax,
 // lab = "component holds a marker", par = component list
@@ -627,20 +642,33 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     u64 *heap;
     const bool in_lds = A <= WS_AMAX;
     const bool inline_val = A <= WS_AMAX16;
+    HItem *heap_far = nullptr;
+    int cap = 0;
     if (in_lds) {
         val = (double *)lds;
         heap = (u64 *)(lds + (size_t)8 * A);
         out = (int32_t *)(lds + (size_t)(inline_val ? 24 : 16) * A);
     } else {
-        // oversized window: same replay out of HBM scratch (dist / overall / heap planes are dead by now)
+        // oversized window: values (and, beyond ~34k pixels, labels) stay in HBM scratch (dist / overall / heap planes are
+        // dead by now); the top `cap` slots of the heap -- where every pop's sift-down runs -- and the label window live
+        // in LDS, the deeper heap levels in HBM
         if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, A);
         __syncthreads();
         const long off = *s_flag;
         __syncthreads();
         if (off + A > b.P) return true;  // scratch exhausted (overlapping boxes): leave it to the whole-tile replay
         val = b.dist + g0 + off;
-        out = (int32_t *)(b.overall + g0) + off;
-        heap = b.heap + 2 * g0 + off;
+        heap_far = (HItem *)(b.heap + 2 * g0) + off;
+        const size_t out_bytes = (size_t)4 * A;
+        if (out_bytes + (size_t)16 * WS_MIN_CAP <= WS_LDS_BYTES) {
+            out = (int32_t *)lds;
+            heap = (u64 *)(lds + ((out_bytes + 15) & ~(size_t)15));
+            cap = (int)((WS_LDS_BYTES - ((out_bytes + 15) & ~(size_t)15)) / 16);
+        } else {
+            out = (int32_t *)(b.overall + g0) + off;
+            heap = (u64 *)lds;
+            cap = WS_LDS_BYTES / 16;
+        }
     }
     auto stage = [&]() {
         for (int t = threadIdx.x; t < A; t += 64) {
@@ -655,8 +683,9 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     auto flood = [&](bool swap_first) {
         if (threadIdx.x == 0) {
             if (!in_lds) __threadfence();
-            *s_flag = inline_val ? ws_flood_window<true>(heap, val, out, bh, bw, swap_first)
-                                 : ws_flood_window<false>(heap, val, out, bh, bw, swap_first);
+            *s_flag = !in_lds ? ws_flood_window<2>(heap, val, out, bh, bw, swap_first, heap_far, cap)
+                      : inline_val ? ws_flood_window<1>(heap, val, out, bh, bw, swap_first)
+                                   : ws_flood_window<0>(heap, val, out, bh, bw, swap_first);
             if (!in_lds) __threadfence();
         }
         __syncthreads();
