@@ -226,6 +226,16 @@ int hvn_run_op(const hvn_op *op, int batch, void *stream)
     return rc;
 }
 
+int hvn_extract_patches(const uint8_t *img, int h, int w, const int32_t *coords, int n_patches, int win, int pad_t, int pad_l,
+                        uint8_t *out, void *stream)
+{
+    if (!img || !coords || !out || h <= 0 || w <= 0 || n_patches <= 0 || win <= 0 || pad_t < 0 || pad_l < 0)
+        return fail(HVN_E_ARG, "extract_patches: bad arguments%s", "");
+    int rc = hvn_launch_extract_patches(img, h, w, coords, n_patches, win, pad_t, pad_l, out, (hipStream_t)stream);
+    if (rc) return fail(HVN_E_LAUNCH, "extract_patches: launch failed%s", "");
+    return 0;
+}
+
 int hvn_run_plan(const hvn_op *ops, int n_ops, int batch, void *stream)
 {
     if (!ops || n_ops <= 0 || batch <= 0) return fail(HVN_E_ARG, "run_plan: bad arguments%s", "");

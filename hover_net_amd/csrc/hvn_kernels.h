@@ -66,6 +66,9 @@ struct HeadArgs {
 };
 int hvn_launch_head(const HeadArgs &a, hipStream_t stream);
 
+int hvn_launch_extract_patches(const uint8_t *img, int H, int W, const int32_t *coords, int P, int win, int pad_t, int pad_l, uint8_t *out,
+                               hipStream_t stream);
+
 struct PredMapArgs {
     const float *tp, *np, *hv;  // NCHW logits
     float *y;                   // [N][H][W][3|4]

@@ -380,3 +380,43 @@ int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream)
         return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---------------------------------------------------------------------------------------
+// Patch extraction with numpy "reflect" padding folded in (infer/tile.py:46-94 _prepare_patching + the loader's
+// crop, dataloader/infer_loader.py:59-72): out[p][y][x][c] = img[refl(cy[p] + y - pad_t)][refl(cx[p] + x - pad_l)][c]
+// with refl the mirror-without-edge-repeat index map (period 2(n-1)).  The source image is uploaded once; the
+// (win/step)^2-fold overlap of the patches is produced on the GPU instead of crossing PCIe.
+__device__ inline int hvn_reflect(int i, int n)
+{
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    int j = i % p;
+    if (j < 0) j += p;
+    return j < n ? j : p - j;
+}
+
+__global__ __launch_bounds__(256) void hvn_extract_patches_k(const uint8_t *img, int H, int W, const int32_t *coords, int win, int pad_t,
+                                                              int pad_l, uint8_t *out, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % win);
+    long t = i / win;
+    const int y = (int)(t % win);
+    const int p = (int)(t / win);
+    const int sy = hvn_reflect(coords[2 * p] + y - pad_t, H), sx = hvn_reflect(coords[2 * p + 1] + x - pad_l, W);
+    const uint8_t *s = img + ((long)sy * W + sx) * 3;
+    uint8_t *d = out + i * 3;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
+int hvn_launch_extract_patches(const uint8_t *img, int H, int W, const int32_t *coords, int P, int win, int pad_t, int pad_l, uint8_t *out,
+                               hipStream_t stream)
+{
+    const long total = (long)P * win * win;
+    hipLaunchKernelGGL(hvn_extract_patches_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, H, W, coords, win, pad_t, pad_l,
+                       out, total);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

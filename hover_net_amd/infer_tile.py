@@ -48,6 +48,42 @@ def prepare_patching(img, window_size, mask_size):
     return padded, info
 
 
+def patch_grid(shape, window_size, mask_size):
+    """The patch grid of `prepare_patching` without materialising the padded image: -> (patch_info int32 [P,4],
+    pad_tl).  infer/tile.py:60-90."""
+    step = mask_size
+    im_h, im_w = shape[0], shape[1]
+    last_h = int((math.ceil((im_h - mask_size) / step) + 1) * step)
+    last_w = int((math.ceil((im_w - mask_size) / step) + 1) * step)
+    ys = np.arange(0, last_h, step, dtype=np.int32)
+    xs = np.arange(0, last_w, step, dtype=np.int32)
+    info = np.empty((len(xs) * len(ys), 4), np.int32)
+    k = 0
+    for ci, x in enumerate(xs):
+        for ri, y in enumerate(ys):
+            info[k] = (y, x, ri, ci)
+            k += 1
+    return info, (window_size - step) // 2
+
+
+def extract_patches_device(img_dev, info, window_size, pad_tl):
+    """img_dev: uint8 device tensor [H,W,3] (unpadded) -> uint8 device tensor [P,win,win,3]: reflect padding and the
+    overlapping crops are produced on the GPU (hvn_extract_patches), so each source pixel crosses PCIe once."""
+    import ctypes
+
+    from . import lib as L
+
+    L.require_gpu()
+    assert img_dev.dtype == torch.uint8 and img_dev.is_cuda and img_dev.dim() == 3 and img_dev.shape[2] == 3
+    img_dev = img_dev.contiguous()
+    coords = torch.from_numpy(np.ascontiguousarray(info[:, :2], np.int32)).to(img_dev.device)
+    out = torch.empty((info.shape[0], window_size, window_size, 3), dtype=torch.uint8, device=img_dev.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(img_dev.device).cuda_stream)
+    L.check(L.lib().hvn_extract_patches(img_dev.data_ptr(), img_dev.shape[0], img_dev.shape[1], coords.data_ptr(), info.shape[0],
+                                        window_size, pad_tl, pad_tl, out.data_ptr(), stream), "hvn_extract_patches")
+    return out
+
+
 def extract_patches(padded, info, window_size):
     """uint8 [P, win, win, 3] (infer_loader.py:59-72 without the worker processes)."""
     out = np.empty((info.shape[0], window_size, window_size, padded.shape[2]), padded.dtype)
@@ -136,13 +172,16 @@ def process_images(images, model, nr_types=None, batch_size=32, return_centroids
     win = 270 if net.mode == "original" else 256
     msk = 80 if net.mode == "original" else 164   # run_infer.py:145-150
     dev = next(net.parameters()).device
-    infos, patches, owners = [], [], []
+    infos, patches = [], []
     for i, img in enumerate(images):
-        padded, info = prepare_patching(img, win, msk)
+        if dev.type == "cuda":      # source image up once, reflect padding + overlapping crops on the GPU
+            info, pad_tl = patch_grid(img.shape, win, msk)
+            patches.append(extract_patches_device(torch.from_numpy(np.ascontiguousarray(img)).to(dev), info, win, pad_tl))
+        else:                       # host geometry (CPU tests of the sharding logic)
+            padded, info = prepare_patching(img, win, msk)
+            patches.append(torch.from_numpy(extract_patches(padded, info, win)))
         infos.append(info)
-        patches.append(extract_patches(padded, info, win))
-        owners += [i] * info.shape[0]
-    all_patches = torch.from_numpy(np.concatenate(patches, 0))
+    all_patches = torch.cat(patches, 0)
     pred = run_sharded(all_patches, lambda b: run_desc.infer_step_device(b.to(dev), model), batch_size)
     _, rank, world = _dist()
     results = [None] * len(images)

@@ -49,6 +49,7 @@ EXPORTS = (
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_postproc_workspace_bytes", "hvn_postproc",
     "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
     "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
+    "hvn_extract_patches",
 )
 
 
@@ -99,6 +100,8 @@ def lib():
         L.hvn_trace_contours.restype = ctypes.c_long
         L.hvn_trace_contours.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+        L.hvn_extract_patches.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_train_last_error.restype = ctypes.c_char_p
         L.hvn_run_train_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.hvn_loss_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -97,6 +97,12 @@ HVN_API int    hvn_profile_enable(int on);
 HVN_API double hvn_profile_conv_ms(void);
 HVN_API int    hvn_profile_conv_launches(void);
 
+/* -- patch extraction: infer/tile.py:46-94 _prepare_patching (numpy "reflect" padding) + dataloader/infer_loader.py:59-72
+ * img: dev uint8 [h][w][3] (the UNPADDED source image); coords: dev int32 [n_patches][2] = (y, x) top-left corners in the
+ * padded frame (patch_info[:, :2]); out: dev uint8 [n_patches][win][win][3]; pad_t / pad_l = (win - step) / 2. */
+HVN_API int hvn_extract_patches(const uint8_t *img, int h, int w, const int32_t *coords, int n_patches, int win,
+                                int pad_t, int pad_l, uint8_t *out, void *stream);
+
 /* -- instance separation: post_proc.py:26-90 __proc_np_hv ---------------------------- */
 /* bytes of device workspace needed for `n` maps of h x w */
 HVN_API size_t hvn_postproc_workspace_bytes(int n, int h, int w);

@@ -107,3 +107,26 @@ def test_two_rank_gloo_sharding_equals_single_process(n_items):
     # single-process batching differs from the per-rank batching, results must not
     np.testing.assert_allclose(outs[0], want, rtol=0, atol=1e-6)
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("shape,win,msk", [((270, 270, 3), 270, 80), ((1000, 1000, 3), 270, 80), ((333, 517, 3), 256, 164), ((50, 61, 3), 270, 80)])
+def test_patch_grid_equals_prepare_patching(shape, win, msk):
+    img = np.zeros(shape, np.uint8)
+    _padded, info = T.prepare_patching(img, win, msk)
+    info2, pad_tl = T.patch_grid(shape, win, msk)
+    assert np.array_equal(info, info2) and pad_tl == (win - msk) // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,win,msk", [((270, 270, 3), 270, 80), ((401, 333, 3), 270, 80), ((333, 517, 3), 256, 164), ((50, 61, 3), 270, 80)])
+def test_device_patch_extraction_equals_host_reflect_padding(shape, win, msk):
+    """hvn_extract_patches (reflect padding folded into the gather) against numpy's pad + crop, including an image
+    smaller than the padding (repeated reflections)."""
+    import torch
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    padded, info = T.prepare_patching(img, win, msk)
+    want = T.extract_patches(padded, info, win)
+    info2, pad_tl = T.patch_grid(shape, win, msk)
+    got = T.extract_patches_device(torch.from_numpy(img).cuda(), info2, win, pad_tl).cpu().numpy()
+    assert np.array_equal(got, want)
