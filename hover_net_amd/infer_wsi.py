@@ -204,9 +204,15 @@ class WsiInference:
             region = slide.read_region(chunk[0][0][::-1], (chunk[0][1] - chunk[0][0])[::-1])
             rel = plist[:, 0, 0] - chunk[0, 0]                    # patch input top-left inside the chunk
             win = int(self.pin[0])
-            patches = np.stack([region[y:y + win, x:x + win] for y, x in rel])
-            out = infer_tile.run_sharded(torch.from_numpy(np.ascontiguousarray(patches)),
-                                         lambda b: run_desc.infer_step_device(b.to(self.device), self.model), self.batch_size)
+            if self.device.type == "cuda":
+                # the chunk goes up once (300 MB for 10000^2); the overlapping 270^2 crops (11x the bytes) are gathered on
+                # the GPU (hvn_extract_patches; every crop is in bounds, so its reflect rule never fires)
+                region_dev = torch.from_numpy(np.ascontiguousarray(region[..., :3])).to(self.device)
+                patches = infer_tile.extract_patches_device(region_dev, rel.astype(np.int32), win, 0)
+                del region_dev
+            else:
+                patches = torch.from_numpy(np.ascontiguousarray(np.stack([region[y:y + win, x:x + win] for y, x in rel])))
+            out = infer_tile.run_sharded(patches, lambda b: run_desc.infer_step_device(b.to(self.device), self.model), self.batch_size)
             # output top-left in the slide = input top-left + diff // 2 (the placement rule of _assemble_and_flush,
             # wsi.py:235-258; patch_info[:, 1] is offset by the FULL diff in the reference and only feeds the mask test)
             otl = torch.from_numpy((plist[:, 0, 0] + (self.pin - self.pout) // 2).astype(np.int64)).to(self.device)

@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Whole-slide path timing on one MI355X (BASELINE cfg 4, scaled to one GPU): a synthetic S x S RGB slide behind
+`ArraySlide` (OpenSlide is not on the box), all-tissue mask.
+  stage 1  `WsiInference.raw_prediction`: chunk read -> patch gather on the GPU -> network -> scatter into the
+           HBM-resident prediction map.  The random-init checkpoint's NP head is biased to background (see bench.py
+           --quiet-net-output) because its raw output is not a nucleus map.
+  stage 2  `WsiInference.stitch_instances` on a structured synthetic prediction map of the same size (painted nuclei at
+           CoNSeP density): grid / boundary / cross tiles post-processed on the GPU + the sequential merge.
+usage: python tools/wsi_bench.py [--size 8192] [--mode original] [--nr-types 5]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hover_net_amd import infer_wsi, net_desc  # noqa: E402
+from hover_net_amd.synth import synth_pred_maps, synth_state_dict  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--mode", default="original")
+    ap.add_argument("--nr-types", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="fp32")
+    args = ap.parse_args()
+    nt = args.nr_types if args.nr_types > 0 else None
+    S = args.size
+    sd = synth_state_dict(args.mode, nt, seed=0)
+    sd["decoder.np.u0.conv.bias"] = torch.tensor([8.0, -8.0])
+    net = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
+    net.load_state_dict(sd, strict=True)
+    net.max_batch = args.batch
+    net.compute_dtype = args.dtype
+    net = net.to("cuda").eval()
+    rng = np.random.default_rng(0)
+    tile = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    slide = infer_wsi.ArraySlide(np.tile(tile, (S // 512 + 1, S // 512 + 1, 1))[:S, :S])
+    wsi = infer_wsi.WsiInference(net, nr_types=nt, batch_size=args.batch)
+    mask = np.ones((S // 32, S // 32), np.uint8)
+    wsi.raw_prediction(infer_wsi.ArraySlide(slide.array[:1024, :1024]), np.ones((32, 32), np.uint8))   # warm-up (plan, arena)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pm = wsi.raw_prediction(slide, mask)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter() - t0
+    _c, pinfo = infer_wsi.get_chunk_patch_info(np.array([S, S]), wsi.chunk_shape, wsi.pin, wsi.pout)
+    n_patch = int(pinfo.shape[0])
+    del pm
+    # stage 2 on a structured map: 512^2 painted blocks tiled over the slide (nuclei at CoNSeP density: 3.8 per 80^2)
+    blk = synth_pred_maps(4, 512, 512, nt, seed=3, k_lo=2, k_hi=6)[0]
+    reps = S // 512 + 1
+    rows = [np.concatenate([blk[(r + c) % 4] for c in range(reps)], 1) for r in range(reps)]
+    full = torch.from_numpy(np.ascontiguousarray(np.concatenate(rows, 0)[:S, :S])).to("cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inst_map, info = wsi.stitch_instances(full, mask)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter() - t0
+    grid, boundary, cross = infer_wsi.get_tile_info(np.array([S, S]), wsi.tile_shape, wsi.ambiguous_size)
+    print(json.dumps({"slide": [S, S], "mode": args.mode, "dtype": args.dtype, "patches": n_patch, "stage1_s": t1, "patches_per_s": n_patch / t1,
+                      "stage2_s": t2, "tiles": [int(grid.shape[0]), int(boundary.shape[0]), int(cross.shape[0])], "instances": len(info),
+                      "mpix_per_s_stage2": S * S / 1e6 / t2}))
+
+
+if __name__ == "__main__":
+    main()
