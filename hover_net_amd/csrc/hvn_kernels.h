@@ -193,3 +193,8 @@ int hvn_launch_adam(float *w, const float *g, float *m, float *v, long n, float 
 
 struct hvn_op;
 int hvn_internal_run_one(const hvn_op *op, int batch, hipStream_t s);
+
+// ---- training targets (hvn_targets.hip) ---------------------------------------------------------
+size_t hvn_targets_ws_bytes(int n, int h, int w);
+int hvn_launch_gen_targets(const int32_t *ann, int n, int h, int w, int ch, int cw, float *hv, int32_t *np_map, void *ws, size_t ws_bytes,
+                           hipStream_t stream);

@@ -188,6 +188,19 @@ int hvn_loss_backward(const hvn_loss *l, void *stream)
     return rc == -2 ? tfail(HVN_E_LAUNCH, "loss backward launch failed", -1) : rc;
 }
 
+size_t hvn_gen_targets_workspace_bytes(int n, int h, int w) { return (n > 0 && h > 0 && w > 0) ? hvn_targets_ws_bytes(n, h, w) : 0; }
+
+int hvn_gen_targets(const int32_t *ann, int n, int h, int w, int crop_h, int crop_w, float *hv_map, int32_t *np_map, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    if (!ann || !hv_map || !np_map || !workspace || n <= 0 || h <= 0 || w <= 0 || crop_h <= 0 || crop_w <= 0 || crop_h > h || crop_w > w ||
+        (long)h * w >= (1L << 31))
+        return tfail(HVN_E_ARG, "gen_targets: bad arguments", -1);
+    int rc = hvn_launch_gen_targets(ann, n, h, w, crop_h, crop_w, hv_map, np_map, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc == -4) return tfail(HVN_E_SIZE, "gen_targets: workspace too small", -1);
+    return rc == -2 ? tfail(HVN_E_LAUNCH, "gen_targets launch failed", -1) : rc;
+}
+
 int hvn_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                   void *stream)
 {

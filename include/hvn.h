@@ -204,6 +204,14 @@ typedef struct hvn_loss {
 HVN_API int hvn_loss_forward(const hvn_loss *l, void *stream);
 HVN_API int hvn_loss_backward(const hvn_loss *l, void *stream);
 
+/* Training targets: models/hovernet/targets.py:100-116 gen_targets (gen_instance_hv_map :17-96 with fix_mirror_padding,
+ * remove_small_objects(30) on the crop, the unclamped 2-px box widening and its skip-at-the-near-border consequence).
+ * ann: dev int32 [n][h][w] instance ids (0 = background); hv_map: dev float32 [n][crop_h][crop_w][2] = (x, y) offsets in
+ * [-1, 1]; np_map: dev int32 [n][crop_h][crop_w] in {0, 1}.  Bit-exact with the reference. */
+HVN_API size_t hvn_gen_targets_workspace_bytes(int n, int h, int w);
+HVN_API int hvn_gen_targets(const int32_t *ann, int n, int h, int w, int crop_h, int crop_w, float *hv_map, int32_t *np_map,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* torch.optim.Adam (opt.py:38-44: lr 1e-4, betas (0.9, 0.999), eps 1e-8, no weight decay) over flat dev slabs;
  * step = 1 for the first update. */
 HVN_API int hvn_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
