@@ -19,7 +19,7 @@ static int fail(int code, const char *fmt, const char *a = "", long b = 0)
 
 extern "C" {
 
-int hvn_version(void) { return 100; }
+int hvn_version(void) { return 101; }   // 1.01: + training step, bf16 path, patch extraction, target generation
 
 const char *hvn_last_error(void) { return g_err; }
 

@@ -4,7 +4,8 @@ torch is used for exactly three things here: allocating device memory, naming th
 current HIP stream, and wrapping the outputs as tensors.  Weights are uploaded once
 (one flat fp32 slab, 256-byte aligned sub-arrays); activations live in one arena of
 `max_batch x arena_per_sample` floats that is re-used by every call (sized for HBM,
-not for reuse in cache: 160 MB/tile -> 5.1 GB at batch 32).
+not for reuse in cache: 555 MB/tile with the Winograd transform-domain tensors -> 17.8 GB at batch 32).
+`dtype="bf16"` binds the same plan to the bf16 kernels (bf16 arena and conv weights, fp32 logits).
 """
 import ctypes
 
