@@ -82,6 +82,14 @@ class HoVerNet(nn.Module):
         # accumulation; no reference bf16 exists, the declared tolerance is on the fp32 logits, tests/test_gpu_bf16.py)
         self.compute_dtype = os.environ.get("HVN_DTYPE", "fp32")
 
+    def _apply(self, fn, *a, **k):
+        # .to() / .cuda() / .float() replace the parameter storage: the bound plans (and the training engine's slabs
+        # the parameters were re-pointed at) are rebuilt on next use
+        self._engine, self._engine_key = None, None
+        if getattr(self, "_train_engine", None) is not None:
+            self._train_engine = None
+        return super()._apply(fn, *a, **k)
+
     # -- plan lifetime ---------------------------------------------------------------------
     def _weights_version(self):
         # the HIP training kernels update weights / running stats behind torch's version counters: the training

@@ -81,7 +81,8 @@ def train_step(batch_data, run_info):
     if dist is None:
         eng.loss_and_backward()
     else:
-        eng.loss_and_backward(world=dist.get_world_size(), all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        eng.loss_and_backward(world=dist.get_world_size(),
+                              all_reduce=lambda t, async_op=False: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op))
     optimizer.step()
     result = {"EMA": dict(eng.loss_terms())}
     # two random samples for the visualisation protocol (run_desc.py:90-107)

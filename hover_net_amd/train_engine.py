@@ -87,7 +87,14 @@ class TrainEngine:
         self._alloc_wino_scratch()
         self._nbt = [self._buffers[k + ".num_batches_tracked"] for k in P.bns]
         self.fwd_ops = self._lower([self._pack_ops()] + [self._lower_fwd(op) for op in P.fwd])
-        self.bwd_ops = self._lower([self._lower_bwd(op) for op in P.bwd])
+        bwd_groups = [self._lower_bwd(op) for op in P.bwd]
+        self.bwd_ops = self._lower(bwd_groups)
+        # gradient buckets for data-parallel training: the backward list finishes the decoder branches first and their
+        # parameters are the tail of the slab, so their all-reduce can run under the encoder's backward pass
+        first_enc = next((i for i, op in enumerate(P.bwd) if not op.name.startswith("decoder.")), len(P.bwd))
+        self._bwd_split = sum(len(g) for g in bwd_groups[:first_enc])
+        dec_keys = [k for k in self._poff if k.startswith("decoder.")]
+        self._dec_off = min(self._poff[k] for k in dec_keys)
         self._loss = self._loss_desc()
         self.last_terms = None
 
@@ -407,28 +414,44 @@ class TrainEngine:
             raise L.HvnError("hvn_loss_forward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
         return self.sums
 
-    def backward(self, world=1):
-        """Loss stage 2 (logit gradients from the -- possibly all-reduced -- sums) and the backward plan."""
+    def backward(self, world=1, all_reduce=None):
+        """Loss stage 2 (logit gradients from the -- possibly all-reduced -- sums) and the backward plan.  With
+        `all_reduce(tensor, async_op)` (data-parallel training) the gradient slab is reduced in two buckets: the
+        decoder's (the tail of the slab, complete once the decoder branches' backward ops have run) is launched
+        asynchronously and overlaps the encoder's backward pass, the encoder's follows at the end."""
         lib = L.lib()
         s = self._stream()
         self._loss.total_pixels = float(world * self.n * self._loss.h * self._loss.w)
         rc = lib.hvn_loss_backward(ctypes.byref(self._loss), s)
         if rc:
             raise L.HvnError("hvn_loss_backward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
-        rc = lib.hvn_run_train_plan(self.bwd_ops, len(self.bwd_ops), self.n, s)
-        if rc:
-            raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        base, osz, n = ctypes.addressof(self.bwd_ops), ctypes.sizeof(L.hvn_top), len(self.bwd_ops)
+        split = self._bwd_split if (all_reduce is not None and 0 < self._bwd_split < n) else n
+        pending = []
+        for lo, hi in ((0, split), (split, n)):
+            if hi > lo:
+                rc = lib.hvn_run_train_plan(base + lo * osz, hi - lo, self.n, s)
+                if rc:
+                    raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+            if all_reduce is not None:
+                bucket = self.gslab[self._dec_off:] if (lo == 0 and split < n) else (self.gslab[:self._dec_off] if split < n else self.gslab)
+                if lo == 0 or split < n:
+                    pending.append(all_reduce(bucket, True))
+            if split == n:
+                break
+        for w in pending:
+            if w is not None and hasattr(w, "wait"):
+                w.wait()
         return self.gslab
 
     def loss_and_backward(self, world=1, all_reduce=None):
-        """loss stage 1 -> (SUM all-reduce of the partial sums) -> backward -> (SUM all-reduce of the gradient slab).
-        With `all_reduce` = torch.distributed's (RCCL) this is the reference's DataParallel step, one process per GPU."""
+        """loss stage 1 -> (SUM all-reduce of the partial sums) -> backward with the bucketed gradient all-reduce.
+        `all_reduce(tensor, async_op)`: torch.distributed's SUM all-reduce (RCCL), returning a work handle when
+        async_op is True.  This is the reference's DataParallel step, one process per GPU."""
         self.loss_forward()
         if all_reduce is not None:
-            all_reduce(self.sums)
-        self.backward(world)
-        if all_reduce is not None:
-            all_reduce(self.gslab)
+            all_reduce(self.sums, False)
+        self.backward(world, all_reduce)
         return self.sums
 
     def loss_terms(self, sums=None):

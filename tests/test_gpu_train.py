@@ -498,9 +498,20 @@ def test_two_rank_step_equals_dataparallel_semantics():
         eng.forward()
         engs.append(eng)
     sums = sum(e.loss_forward().clone() for e in engs)
+    calls = []
+
+    def fake_all_reduce(t, async_op=False):     # records the buckets the engine hands to the collective
+        calls.append((t.data_ptr(), t.numel(), async_op))
+        return None
     for e in engs:
         e.sums.copy_(sums)
-        e.backward(world=2)
+        e.backward(world=2, all_reduce=fake_all_reduce)
+    # two buckets per engine: decoder tail first (asynchronous, under the encoder's backward), then the head; together the slab
+    e0 = engs[0]
+    assert len(calls) == 4 and all(c[2] for c in calls)
+    assert calls[0][0] == e0.gslab.data_ptr() + 4 * e0._dec_off and calls[0][1] == e0.gslab.numel() - e0._dec_off
+    assert calls[1][0] == e0.gslab.data_ptr() and calls[1][1] == e0._dec_off
+    assert 0 < e0._bwd_split < len(e0.bwd_ops)
     total = engs[0].gslab + engs[1].gslab
     torch.cuda.synchronize()
     # oracle: replicas forward separately (own batch statistics), loss on the concatenation, one backward

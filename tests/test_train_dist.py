@@ -27,10 +27,12 @@ class _StubEngine:
 
     def loss_and_backward(self, world=1, all_reduce=None):
         self.sums[:] = float(self.rank + 1)
-        all_reduce(self.sums)
+        all_reduce(self.sums, False)
         self.world_seen = world
         self.gslab[:] = float(10 * (self.rank + 1))
-        all_reduce(self.gslab)
+        works = [all_reduce(self.gslab[600:], True), all_reduce(self.gslab[:600], True)]      # two buckets, async like the engine
+        for w in works:
+            w.wait()
 
     def loss_terms(self):
         return {"overall_loss": float(self.sums[0])}
