@@ -8,6 +8,7 @@
 //   head     net_desc.py:62-68 u0.conv : 64 -> {2..} logits + bias, written NCHW
 //   predmap  run_desc.py:185-194 : softmax(np)[1], argmax(softmax(tp)), concat
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "hvn_kernels.h"
@@ -75,9 +76,92 @@ __global__ __launch_bounds__(256) void hvn_conv0(const Conv0Args p)
     }
 }
 
+// conv0 on the matrix cores: 16x16 output pixels x 64 channels per workgroup, K = 7*7*3 = 147 (+1 zero) walked as 74
+// v_mfma_f32_32x32x2_f32 steps per block.  The A operand is gathered straight out of the staged image patch (lane = pixel,
+// k -> (tap row, tap col * 3 + ch) is a compile-time offset), B out of the [148][64] taps in LDS; 1.5 LDS reads per MFMA.
+// Replaces the VALU kernel above (1.46 ms -> see profiles; HVN_CONV0_VALU=1 keeps the old one for A/B runs).
+#define C0_PITCH (C0_P * 3 + 2)
+template <typename T>
+__global__ __launch_bounds__(256) void hvn_conv0_mfma(const Conv0Args p)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ float patch[C0_P + 1][C0_PITCH];   // + one zero row: k = 147 (the padding of the odd K) reads row py + 7
+    __shared__ float wl[148][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * C0_T, ox0 = blockIdx.x * C0_T;
+    const T *img = (const T *)p.img + (long)n * p.isn;
+    for (int i = tid; i < (C0_P + 1) * C0_P * 3; i += 256) {
+        const int py = i / (C0_P * 3), pr = i - py * (C0_P * 3);
+        const int px = pr / 3, ch = pr - px * 3;
+        const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+        float v = 0.f;
+        if (py < C0_P && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = (float)img[(long)iy * p.isy + (long)ix * p.isx + (long)ch * p.isc];
+        patch[py][pr] = v;
+    }
+    for (int i = tid; i < 148 * 16; i += 256) {
+        const int k = i >> 4, c4 = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < 147) v = *(const float4 *)(p.w + k * 64 + c4 * 4);
+        *(float4 *)&wl[k][c4 * 4] = v;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // wave w: tile rows 4w .. 4w+3; M-block i: rows 4w + 2i + {0, 1}; lane pixel p = l31 -> (row p >> 4, col p & 15)
+    const float *abase = &patch[4 * wave + (l31 >> 4)][(l31 & 15) * 3];
+    const float *bbase = &wl[lh][l31];
+#pragma unroll
+    for (int t = 0; t < 74; ++t) {
+        const int k0 = 2 * t, k1 = 2 * t + 1;
+        const int o0 = (k0 / 21) * C0_PITCH + (k0 % 21), o1 = (k1 / 21) * C0_PITCH + (k1 % 21);   // compile-time
+        const int off = lh ? o1 : o0;
+        const float a0 = abase[off], a1 = abase[off + 2 * C0_PITCH];
+        const float b0 = bbase[k0 * 64], b1 = bbase[k0 * 64 + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = 32 * j + l31;
+        const float bias = p.bias[ch];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = oy0 + 4 * wave + 2 * i + (m >> 4), ox = ox0 + (m & 15);
+                if (oy < p.Ho && ox < p.Wo) {
+                    const float v = fmaxf(acc[i][j][r] + bias, lo);
+                    const long yoff = (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + ch;
+                    if (p.out_bf16) ((__bf16 *)p.y)[yoff] = (__bf16)v;
+                    else p.y[yoff] = v;
+                }
+            }
+    }
+}
+
 int hvn_launch_conv0(const Conv0Args &a, hipStream_t stream)
 {
     dim3 grid((a.Wo + C0_T - 1) / C0_T, (a.Ho + C0_T - 1) / C0_T, a.N);
+    static int valu = -1;
+    if (valu < 0) valu = getenv("HVN_CONV0_VALU") ? 1 : 0;
+    if (!valu) {
+        if (a.is_f32)
+            hipLaunchKernelGGL(hvn_conv0_mfma<float>, grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL(hvn_conv0_mfma<uint8_t>, grid, dim3(256), 0, stream, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (a.is_f32)
         hipLaunchKernelGGL(hvn_conv0<float>, grid, dim3(256), 0, stream, a);
     else
