@@ -42,3 +42,31 @@ def test_freeze_scoping_counts():
     # the reference's golden run: 262 of 407 parameters receive a gradient in phase 0 (freeze), all in phase 1
     assert len(TrainPlan("original", 5, True).trainable) == 262
     assert len(TrainPlan("original", 5, False).trainable) == 407
+
+
+def test_plan_structure_invariants():
+    """Dilated gradient buffers exist exactly behind stride-2 conv outputs; all running sums of a residual block share one
+    gradient buffer; every gradient buffer is referenced by some backward op; layouts are disjoint and aligned."""
+    from hover_net_amd import train_plan as TP
+    P = TP.TrainPlan("original", 5, False)
+    by_name = {b.name: b for b in P.bufs}
+    for blk in ("d0", "d1", "d2", "d3"):
+        sums = [b for b in P.bufs if b.name.startswith(blk + ".") and (b.name.endswith(".sum") or b.name == blk + ".shortcut")]
+        assert len({id(b.g) for b in sums}) == 1 and len(sums) >= 4
+        assert sums[0].gstep == (1 if blk == "d0" else 2)
+    assert by_name["d1.units.0.z2"].gstep == 2 and by_name["d1.units.1.z2"].gstep == 1 and by_name["d0.units.0.z2"].gstep == 1
+    used = set()
+    for op in P.bwd:
+        for v in (getattr(op, k, None) for k in ("dx", "dy", "dz", "da", "dlo", "dskip")):
+            if v is not None:
+                used.add(id(v.buf))
+    assert used == {id(g) for g in P.gbufs}
+    d, g = P.layout(3)
+    offs = sorted((b.off, b.size(3)) for b in P.bufs)
+    assert all(o % 64 == 0 for o, _ in offs) and all(o1 + s1 <= o2 for (o1, s1), (o2, _) in zip(offs, offs[1:])) and offs[-1][0] + offs[-1][1] <= d
+    goffs = sorted((b.off, b.size(3)) for b in P.gbufs)
+    assert all(o1 + s1 <= o2 for (o1, s1), (o2, _) in zip(goffs, goffs[1:])) and goffs[-1][0] + goffs[-1][1] <= g
+    # phase 0: no encoder unit carries a gradient, d0's shortcut path does
+    F = TP.TrainPlan("original", 5, True)
+    fb = {b.name: b for b in F.bufs}
+    assert fb["d0.units.1.z1"].g is None and fb["d1.out"].g is None and fb["d0.shortcut"].g is not None and fb["conv0.z"].g is not None
