@@ -120,25 +120,26 @@ def trace_contours(inst_host, rec_host):
 def records_to_dict(rec_host, nr_types, inst_host=None):
     """One tile's records (numpy structured array) -> the reference's inst_info_dict.  With `inst_host`
     the contours are traced too and, like the reference (post_proc.py:140-143), instances whose contour
-    has fewer than 3 points are left out of the dict (they stay in the instance map)."""
-    out = {}
+    has fewer than 3 points are left out of the dict (they stay in the instance map).  The per-instance fields are
+    computed for the whole tile at once; only the dict assembly is a python loop (a WSI has ~10^5 instances)."""
+    r = rec_host[rec_host["area"] > 0]
     contours = trace_contours(inst_host, rec_host) if inst_host is not None else None
-    for r in rec_host[rec_host["area"] > 0]:
+    area = r["area"].astype(np.float64)
+    bbox = np.stack([np.stack([r["rmin"], r["cmin"]], -1), np.stack([r["rmax"], r["cmax"]], -1)], 1).astype(np.int64)   # [n,2,2]
+    # m10/m00 on the crop, then + offset (post_proc.py:145-152)
+    cent = np.stack([r["sum_x"] / area + r["cmin"], r["sum_y"] / area + r["rmin"]], -1)
+    labels = r["label"].tolist()
+    types = r["type"].tolist() if nr_types is not None else None
+    tprob = (r["type_count"] / (area + 1.0e-6)).tolist() if nr_types is not None else None
+    out = {}
+    for i, lab in enumerate(labels):
         contour = None
         if contours is not None:
-            contour = contours[int(r["label"])]
+            contour = contours[lab]
             if contour.shape[0] < 3:
                 continue
-        bbox = np.array([[r["rmin"], r["cmin"]], [r["rmax"], r["cmax"]]])
-        cx = r["sum_x"] / float(r["area"]) + r["cmin"]   # m10/m00 on the crop, then + offset (post_proc.py:145-152)
-        cy = r["sum_y"] / float(r["area"]) + r["rmin"]
-        out[int(r["label"])] = {
-            "bbox": bbox,
-            "centroid": np.array([cx, cy]),
-            "contour": contour,
-            "type_prob": None if nr_types is None else float(r["type_count"] / (r["area"] + 1.0e-6)),
-            "type": None if nr_types is None else int(r["type"]),
-        }
+        out[lab] = {"bbox": bbox[i], "centroid": cent[i], "contour": contour,
+                    "type_prob": None if tprob is None else tprob[i], "type": None if types is None else types[i]}
     return out
 
 

@@ -6,7 +6,6 @@ field.  Used (a) on CPU to prove the lowering (BN folding, concat-by-offset, cro
 block-diagonal grouped convs, arena packing) against oracle/net_torch.py, and (b) on
 the GPU box as the per-op reference for the HIP kernels.
 """
-import numpy as np
 import torch
 import torch.nn.functional as F
 
