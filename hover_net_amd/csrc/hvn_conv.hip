@@ -402,21 +402,36 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     const float post_lo = has_post ? 0.f : -__builtin_inff();
     constexpr int NIT = BM / RPP;         // rows per thread: 16 / 8 / 4
     const float *resp = has_res ? p.res : p.w;  // valid address either way; value unused without a residual
+    // this thread's rows are m0 + erow0 + k*RPP: decode the first with divisions, walk the rest (n, oy, ox) incrementally
+    // (32 integer divisions per thread and tile were ~10 % of a short-K tile's instruction stream)
+    unsigned e_n, e_oy, e_ox;
+    {
+        const unsigned m = m0 + erow0;
+        e_n = m / HoWo;
+        const unsigned rem = m - e_n * HoWo;
+        e_oy = rem / (unsigned)p.Wo;
+        e_ox = rem - e_oy * (unsigned)p.Wo;
+    }
     for (int it0 = 0; it0 < NIT; it0 += 4) {
         long yoff[4], roff[4];
         bool ok[4];
         f32x4 rv[4];
-        // decode 4 rows, then issue their residual loads together, then do the math / stores
+        // locate 4 rows, then issue their residual loads together, then do the math / stores
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned m = m0 + erow0 + (it0 + u) * RPP;
             ok[u] = m < M && cok;
-            const unsigned mm = ok[u] ? m : 0u;
-            const unsigned n = mm / HoWo;
-            const unsigned rem = mm - n * HoWo;
-            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
-            yoff[u] = (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co;
-            roff[u] = (ok[u] && has_res) ? (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co : 0;
+            yoff[u] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+            roff[u] = (ok[u] && has_res) ? (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co : 0;
+            e_ox += RPP;
+            while (e_ox >= (unsigned)p.Wo) {
+                e_ox -= (unsigned)p.Wo;
+                ++e_oy;
+            }
+            while (e_oy >= (unsigned)p.Ho) {
+                e_oy -= (unsigned)p.Ho;
+                ++e_n;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) rv[u] = *(const f32x4 *)(resp + roff[u]);

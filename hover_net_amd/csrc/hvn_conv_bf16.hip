@@ -264,13 +264,27 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
     uint16_t *py = (uint16_t *)p.y;
     const uint16_t *pres = (const uint16_t *)p.res;
     if (erow0 < BM) {
-        for (int it = 0; it < (BM + RPP - 1) / RPP; ++it) {
+        // rows m0 + erow0 + it*RPP: the first located with divisions, the rest walked incrementally
+        unsigned n, oy, ox;
+        {
+            const unsigned m = m0 + erow0;
+            n = m / HoWo;
+            const unsigned rem = m - n * HoWo;
+            oy = rem / (unsigned)p.Wo;
+            ox = rem - oy * (unsigned)p.Wo;
+        }
+        for (int it = 0; it < (BM + RPP - 1) / RPP; ++it, ox += RPP) {
+            while (ox >= (unsigned)p.Wo) {
+                ox -= (unsigned)p.Wo;
+                ++oy;
+            }
+            while (oy >= (unsigned)p.Ho) {
+                oy -= (unsigned)p.Ho;
+                ++n;
+            }
             const int rr = erow0 + it * RPP;
             const unsigned m = m0 + rr;
             if (rr >= BM || !(m < M && cok)) continue;
-            const unsigned n = m / HoWo;
-            const unsigned rem = m - n * HoWo;
-            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
             u32x4 r4 = {0u, 0u, 0u, 0u};
             if (has_res) r4 = *(const u32x4 *)(pres + (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co);
             u32x4 o;
