@@ -474,6 +474,8 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+int hvn_launch_dense_grouped(const ConvArgs &a, hipStream_t stream);
+
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
 {
     if (a.Cin % BK != 0 || a.Cin <= 0 || a.Cout % 4 != 0) return -1;
@@ -510,10 +512,137 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
             return padded ? launch_conv<128, 64, 4, 1, true, 0, false, false>(a, stream) : launch_conv<128, 64, 4, 1, false, 0, false, false>(a, stream);
         return padded ? launch_conv<128, 64, 4, 1, true>(a, stream) : launch_conv<128, 64, 4, 1, false>(a, stream);
     case 32:
+        // dense-unit conv2: patch-staged kernel (no per-tap restaging); HVN_NO_DENSE_KERNEL=1 falls back to the generic grouped path
+        if (a.groups == 4 && a.Cin == 128 && a.Cout == 32 && a.stride == 1 && !padded && !a.pre_s && !a.res && !a.post_s && a.nbatch <= 1 &&
+            a.KH == a.KW && (a.KH == 5 || a.KH == 3) && !getenv("HVN_NO_DENSE_KERNEL"))
+            return hvn_launch_dense_grouped(a, stream);
         if (a.groups == 4 && a.Cin == 128 && a.Cout == 32 && !getenv("HVN_NO_GROUPED"))
             return padded ? launch_conv<128, 32, 4, 1, true, 0, true>(a, stream) : launch_conv<128, 32, 4, 1, false, 0, true>(a, stream);
         if (a.groups != 1 && !(a.groups == 4 && a.Cin == 128 && a.Cout == 32)) return -1;
         return padded ? launch_conv<128, 32, 4, 1, true>(a, stream) : launch_conv<128, 32, 4, 1, false>(a, stream);
     default: return -1;
     }
+}
+
+// =========================================================================================
+// Dense-unit conv2 (net_utils.py:114-125): k x k (5 or 3), stride 1, valid, 128 -> 32 channels in 4 groups (32 -> 8).
+// The generic kernel re-stages its 128-pixel A tile for each of the 4 x 25 (slab, tap) k-steps and does only 16 small
+// MFMAs per step; here a workgroup stages the (8+k-1) x (16+k-1) input patch of TWO groups once (64 channels, 65 KB,
+// pixel pitch 68 floats: conflict-free ds_read_b128 for 16 consecutive pixels) and walks all taps out of LDS with no
+// further barrier.  Wave = (group, half of the 8 x 16 pixel tile); per tap 4 pixel rows x 8 v_mfma_f32_16x16x4_f32
+// (K = 32 channels; the k-labelling is permuted so that a lane reads its 8 channels with two ds_read_b128), the
+// 8 x 32 weights of the tap come straight from the packed block-diagonal weights ([32][4][taps][32]) as two 16-byte
+// loads per lane, prefetched one tap ahead.  Half of each MFMA's 16 output columns are padding (8 channels per group).
+// =========================================================================================
+#define DG_TH 8
+#define DG_TW 16
+#define DG_PP 68   // pixel pitch in floats (64 channels + 4)
+template <int KS>
+__global__ __launch_bounds__(256, 2) void hvn_dense_grouped_f32(const ConvArgs p, int tiles_x, int tiles_y)
+{
+    constexpr int PH = DG_TH + KS - 1, PW = DG_TW + KS - 1;
+    extern __shared__ __attribute__((aligned(16))) float dg_patch[];   // [PH][PW][DG_PP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    const int gp = bid & 1;            // group pair: groups 2gp, 2gp+1
+    bid >>= 1;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oy0 = ty * DG_TH, ox0 = tx * DG_TW;
+    // ---- stage the patch of this group pair (64 channels) -------------------------------------------
+    const float *xin = p.x + (long)n * p.xsn + gp * 64;
+    for (int i = tid; i < PH * PW * 16; i += 256) {
+        const int c4 = i & 15, pix = i >> 4;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = oy0 + py, ix = ox0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy < p.H && ix < p.W) v = *(const f32x4 *)(xin + (long)iy * p.xsy + (long)ix * p.xsx + c4 * 4);
+        *(f32x4 *)(dg_patch + pix * DG_PP + c4 * 4) = v;
+    }
+    const int gl = wave & 1, half = wave >> 1;   // group inside the pair, tile rows 4*half .. 4*half+3
+    const int g = 2 * gp + gl;
+    // B: lane (n = l15, q): weights of output channel 8g + n (n < 8), input channels 8q .. 8q+7 of the group's slab
+    const bool bvalid = l15 < 8;
+    const int taps = KS * KS;
+    const float *wrow = p.w + ((long)(8 * g + (bvalid ? l15 : 0)) * 4 + g) * taps * 32 + 8 * q;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, nb0 = b0, nb1 = b0;
+    if (bvalid) {
+        b0 = *(const f32x4 *)(wrow);
+        b1 = *(const f32x4 *)(wrow + 4);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    // A: lane (pixel column l15 of tile row 4*half + m, q): channels 32*gl + 8q .. +7 at the tap-shifted pixel
+    const float *abase = dg_patch + ((4 * half) * PW + l15) * DG_PP + 32 * gl + 8 * q;
+#pragma unroll 1
+    for (int r = 0; r < KS; ++r) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const int tap = r * KS + s2;
+            if (bvalid && tap + 1 < taps) {   // next tap's weights, in flight under this tap's MFMAs
+                nb0 = *(const f32x4 *)(wrow + (tap + 1) * 32);
+                nb1 = *(const f32x4 *)(wrow + (tap + 1) * 32 + 4);
+            }
+            const float *a = abase + (r * PW + s2) * DG_PP;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 a0 = *(const f32x4 *)(a + m * PW * DG_PP);
+                const f32x4 a1 = *(const f32x4 *)(a + m * PW * DG_PP + 4);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[m], 0, 0, 0);
+            }
+            b0 = nb0;
+            b1 = nb1;
+        }
+    }
+    // D[m][n]: lane holds n = l15 (output channel 8g + n, n < 8), pixel columns 4q + i (i = 0..3) of tile row 4*half + m
+    if (bvalid) {
+        const int co = 8 * g + l15;
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        const float lo = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int oy = oy0 + 4 * half + m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + 4 * q + i;
+                if (oy < p.Ho && ox < p.Wo) p.y[(long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co] = fmaxf(acc[m][i] + bias, lo);
+            }
+        }
+    }
+}
+
+template <int KS>
+static int launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
+{
+    const int tiles_x = (a.Wo + DG_TW - 1) / DG_TW, tiles_y = (a.Ho + DG_TH - 1) / DG_TH;
+    const size_t lds = (size_t)(DG_TH + KS - 1) * (DG_TW + KS - 1) * DG_PP * sizeof(float);
+    static bool attr_done = false;
+    auto kern = hvn_dense_grouped_f32<KS>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    const long grid = 2L * tiles_x * tiles_y * a.N;
+    if (grid <= 0 || grid > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, tiles_x, tiles_y);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hvn_launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
+{
+    if (a.KH == 5) return launch_dense_grouped<5>(a, stream);
+    if (a.KH == 3) return launch_dense_grouped<3>(a, stream);
+    return -1;
 }
