@@ -566,12 +566,19 @@ __global__ __launch_bounds__(256, 2) void hvn_dense_grouped_f32(const ConvArgs p
     const int g = 2 * gp + gl;
     // B: lane (n = l15, q): weights of output channel 8g + n (n < 8), input channels 8q .. 8q+7 of the group's slab
     const bool bvalid = l15 < 8;
-    const int taps = KS * KS;
-    const float *wrow = p.w + ((long)(8 * g + (bvalid ? l15 : 0)) * 4 + g) * taps * 32 + 8 * q;
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, nb0 = b0, nb1 = b0;
+    const float *wrow = p.w + ((long)(8 * g + (bvalid ? l15 : 0)) * 4 + g) * (KS * KS) * 32 + 8 * q;
+    // weights of a tap = 8 floats per lane; a tap is only ~1000 matrix cycles, less than an L2 round trip, so the loads run
+    // three taps ahead through a ring of four register slots (the tap loop is fully unrolled: static slot indices)
+    constexpr int TAPS = KS * KS;
+    f32x4 wb[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wb[t][0] = wb[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (bvalid) {
-        b0 = *(const f32x4 *)(wrow);
-        b1 = *(const f32x4 *)(wrow + 4);
+#pragma unroll
+        for (int t = 0; t < 3 && t < TAPS; ++t) {
+            wb[t][0] = *(const f32x4 *)(wrow + t * 32);
+            wb[t][1] = *(const f32x4 *)(wrow + t * 32 + 4);
+        }
     }
     f32x4 acc[4];
 #pragma unroll
@@ -579,32 +586,30 @@ __global__ __launch_bounds__(256, 2) void hvn_dense_grouped_f32(const ConvArgs p
     __syncthreads();
     // A: lane (pixel column l15 of tile row 4*half + m, q): channels 32*gl + 8q .. +7 at the tap-shifted pixel
     const float *abase = dg_patch + ((4 * half) * PW + l15) * DG_PP + 32 * gl + 8 * q;
-#pragma unroll 1
-    for (int r = 0; r < KS; ++r) {
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) {
-            const int tap = r * KS + s2;
-            if (bvalid && tap + 1 < taps) {   // next tap's weights, in flight under this tap's MFMAs
-                nb0 = *(const f32x4 *)(wrow + (tap + 1) * 32);
-                nb1 = *(const f32x4 *)(wrow + (tap + 1) * 32 + 4);
-            }
-            const float *a = abase + (r * PW + s2) * DG_PP;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 a0 = *(const f32x4 *)(a + m * PW * DG_PP);
-                const f32x4 a1 = *(const f32x4 *)(a + m * PW * DG_PP + 4);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[m], 0, 0, 0);
-            }
-            b0 = nb0;
-            b1 = nb1;
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int r = tap / KS, s2 = tap % KS;
+        if (bvalid && tap + 3 < TAPS) {
+            wb[(tap + 3) & 3][0] = *(const f32x4 *)(wrow + (tap + 3) * 32);
+            wb[(tap + 3) & 3][1] = *(const f32x4 *)(wrow + (tap + 3) * 32 + 4);
         }
+        const float *a = abase + (r * PW + s2) * DG_PP;
+        f32x4 a0[4], a1[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a0[m] = *(const f32x4 *)(a + m * PW * DG_PP);
+            a1[m] = *(const f32x4 *)(a + m * PW * DG_PP + 4);
+        }
+        const f32x4 b0 = wb[tap & 3][0], b1 = wb[tap & 3][1];
+        // channel step outermost: the four pixel rows' accumulators alternate, no MFMA waits on the previous one
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][e], b0[e], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][e], b1[e], acc[m], 0, 0, 0);
     }
     // D[m][n]: lane holds n = l15 (output channel 8g + n, n < 8), pixel columns 4q + i (i = 0..3) of tile row 4*half + m
     if (bvalid) {

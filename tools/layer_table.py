@@ -14,7 +14,7 @@ from hover_net_amd.synth import synth_state_dict  # noqa: E402
 db, batch = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 32
 P = build_plan(synth_state_dict("original", 5, seed=0), "original", 5)
 c = sqlite3.connect(db)
-pat = ("igemm", "hvn_conv0", "hvn_upadd", "hvn_head", "hvn_predmap", "hvn_wino")
+pat = ("igemm", "hvn_dense_grouped", "hvn_conv0", "hvn_upadd", "hvn_head", "hvn_predmap", "hvn_wino")
 rows = [r for r in c.execute("select name,duration from kernels order by start") if any(p in r[0] for p in pat)]
 last = rows[-len(P.ops):]
 tot, agg = 0, {}
