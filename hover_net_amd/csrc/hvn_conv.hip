@@ -645,8 +645,128 @@ static int launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+
+// Second form of the dense-unit conv2: the 16 MFMA output columns hold 8 channels x 2 horizontally adjacent output
+// pixels (dx = 0, 1) instead of 8 channels + 8 columns of padding.  A row of the GEMM is a BASE pixel at an even column;
+// the reduction runs over KS x (KS+1) shifted input taps with the weights W'[(ty, tx', ch)][(co, dx)] = w[ty][tx' - dx][ch][co]
+// (zero where tx' - dx falls outside the filter): KS(KS+1) tap steps produce two pixels, 5/6 (3/4 for 3x3) of the MFMA
+// work is useful instead of 1/2.  Tile = 4 rows x 32 columns; wave = (group, two of the rows); lane l15 = base pixel
+// column (stride 2 pixels = 8 LDS banks at 16 bytes per lane: conflict-free).
+#define DG2_TH 4
+#define DG2_TW 32
+template <int KS>
+__global__ __launch_bounds__(256, 2) void hvn_dense_grouped2_f32(const ConvArgs p, int tiles_x, int tiles_y)
+{
+    constexpr int PH = DG2_TH + KS - 1, PW = DG2_TW + KS - 1;
+    constexpr int TAPS2 = KS * (KS + 1);
+    extern __shared__ __attribute__((aligned(16))) float dg_patch[];   // [PH][PW][DG_PP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    const int gp = bid & 1;
+    bid >>= 1;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oy0 = ty * DG2_TH, ox0 = tx * DG2_TW;
+    const float *xin = p.x + (long)n * p.xsn + gp * 64;
+    for (int i = tid; i < PH * PW * 16; i += 256) {
+        const int c4 = i & 15, pix = i >> 4;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = oy0 + py, ix = ox0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy < p.H && ix < p.W) v = *(const f32x4 *)(xin + (long)iy * p.xsy + (long)ix * p.xsx + c4 * 4);
+        *(f32x4 *)(dg_patch + pix * DG_PP + c4 * 4) = v;
+    }
+    const int gl = wave & 1, half = wave >> 1;   // group inside the pair; tile rows 2*half, 2*half + 1
+    const int g = 2 * gp + gl;
+    const int co = l15 & 7, dx = l15 >> 3;       // this lane's output column: channel 8g + co of the pixel at base + dx
+    const float *wrow = p.w + ((long)(8 * g + co) * 4 + g) * (KS * KS) * 32 + 8 * q;
+    // weights of shifted tap t' = (tr, tc'), tc' in [0, KS]: filter tap (tr, tc' - dx) or zero
+    auto load_w = [&](int t2, f32x4 &w0, f32x4 &w1) {
+        const int tr = t2 / (KS + 1), tc = t2 - tr * (KS + 1) - dx;
+        w0 = w1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tc >= 0 && tc < KS) {
+            w0 = *(const f32x4 *)(wrow + (tr * KS + tc) * 32);
+            w1 = *(const f32x4 *)(wrow + (tr * KS + tc) * 32 + 4);
+        }
+    };
+    f32x4 wb[4][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) load_w(t, wb[t][0], wb[t][1]);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    __syncthreads();
+    // A: lane (base pixel column 2*l15 of tile row 2*half + m, q): channels 32*gl + 8q .. +7 at the shifted pixel
+    const float *abase = dg_patch + ((2 * half) * PW + 2 * l15) * DG_PP + 32 * gl + 8 * q;
+#pragma unroll
+    for (int t2 = 0; t2 < TAPS2; ++t2) {
+        const int tr = t2 / (KS + 1), tc = t2 % (KS + 1);
+        if (t2 + 3 < TAPS2) load_w(t2 + 3, wb[(t2 + 3) & 3][0], wb[(t2 + 3) & 3][1]);
+        const float *a = abase + (tr * PW + tc) * DG_PP;
+        f32x4 a0[2], a1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a0[m] = *(const f32x4 *)(a + m * PW * DG_PP);
+            a1[m] = *(const f32x4 *)(a + m * PW * DG_PP + 4);
+        }
+        const f32x4 b0 = wb[t2 & 3][0], b1 = wb[t2 & 3][1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][e], b0[e], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][e], b1[e], acc[m], 0, 0, 0);
+    }
+    // D[m][n]: lane holds column n = l15 = (co, dx); rows = base pixels 4q + i (i = 0..3) of tile row 2*half + m
+    const int ch = 8 * g + co;
+    const float bias = p.bias ? p.bias[ch] : 0.f;
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int oy = oy0 + 2 * half + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ox = ox0 + 2 * (4 * q + i) + dx;
+            if (oy < p.Ho && ox < p.Wo) p.y[(long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + ch] = fmaxf(acc[m][i] + bias, lo);
+        }
+    }
+}
+
+template <int KS>
+static int launch_dense_grouped2(const ConvArgs &a, hipStream_t stream)
+{
+    const int tiles_x = (a.Wo + DG2_TW - 1) / DG2_TW, tiles_y = (a.Ho + DG2_TH - 1) / DG2_TH;
+    const size_t lds = (size_t)(DG2_TH + KS - 1) * (DG2_TW + KS - 1) * DG_PP * sizeof(float);
+    static bool attr_done = false;
+    auto kern = hvn_dense_grouped2_f32<KS>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    const long grid = 2L * tiles_x * tiles_y * a.N;
+    if (grid <= 0 || grid > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, tiles_x, tiles_y);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int hvn_launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
 {
+    static int forced = -1;   // HVN_DENSE_FORM=1 | 2 forces a form (A/B runs); default: by the column-tile waste
+    if (forced < 0) {
+        const char *e = getenv("HVN_DENSE_FORM");
+        forced = e ? atoi(e) : 0;
+    }
+    // form 2 (two pixels per column block, 4 x 32 tiles) does 40 % fewer MFMAs but pads the width to a multiple of 32:
+    // measured faster up to ~1.55x padding (widths 58..42 and 30 of the u3 / u2 dense blocks), slower beyond (38, 34)
+    const int form = forced ? forced : (((a.Wo + 31) / 32 * 32) * 100 <= a.Wo * 155 ? 2 : 1);
+    if (form == 2) {
+        if (a.KH == 5) return launch_dense_grouped2<5>(a, stream);
+        if (a.KH == 3) return launch_dense_grouped2<3>(a, stream);
+        return -1;
+    }
     if (a.KH == 5) return launch_dense_grouped<5>(a, stream);
     if (a.KH == 3) return launch_dense_grouped<3>(a, stream);
     return -1;
