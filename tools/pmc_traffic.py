@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM traffic of the conv kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of
 `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline` (HVN_SPLIT=1 HVN_LANES=0).
-Sums the counters over the hvn_conv_igemm_f32 dispatches of the LAST plan execution.
+Sums the counters over the conv dispatches (hvn_conv_igemm_f32 + hvn_dense_grouped*_f32) of the LAST plan execution.
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x.
 usage: python tools/pmc_traffic.py <fetch.db> <write.db> <out.json>"""
 import json
@@ -17,7 +17,7 @@ from hover_net_amd.synth import synth_state_dict  # noqa: E402
 def total(db, counter, n_last):
     c = sqlite3.connect(db)
     rows = list(c.execute("select dispatch_id, sum(value), min(start) from counters_collection "
-                          "where kernel_name like '%igemm%' and counter_name=? group by dispatch_id order by min(start)", (counter,)))
+                          "where (kernel_name like '%igemm%' or kernel_name like '%dense_grouped%') and counter_name=? group by dispatch_id order by min(start)", (counter,)))
     rows = rows[-n_last:]
     return sum(r[1] for r in rows), len(rows)
 
