@@ -15,6 +15,7 @@
 // the gradient arena once per step), see hover_net_amd/train_plan.py.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hvn_kernels.h"
 
@@ -854,10 +855,117 @@ __global__ __launch_bounds__(256) void hvn_conv0_wgrad(const Conv0WgradArgs p, i
     }
 }
 
+// conv0 weight gradient on the matrix cores: D[co][kidx] = sum_px dz[px][co] * P[px][kidx] with P gathered from the staged
+// image patch (kidx -> (tap row, tap col*3 + ch) is a per-lane constant offset), M = 64 channels (2 blocks), N = 147 (+13)
+// taps (5 blocks), K = pixels.  A wave reduces 32 pixels of each 8-row half tile (16 k-steps x 10 MFMAs) and keeps its
+// 64 x 160 partial in registers across all the tiles of the workgroup; the four waves' partials are summed through LDS and
+// leave with one atomic per weight.  ~10x the VALU kernel above (HVN_CONV0_WGRAD_VALU=1 keeps that one).
+#define W0M_PITCH (W0_P * 3 + 2)
+__global__ __launch_bounds__(256) void hvn_conv0_wgrad_mfma(const Conv0WgradArgs p, int tiles_x, int tiles_y, long tiles_total)
+{
+    typedef float f32x16v __attribute__((ext_vector_type(16)));
+    extern __shared__ __attribute__((aligned(16))) float w0m_lds[];
+    float *patch = w0m_lds;                              // [W0_P][W0M_PITCH]
+    float *dzs = w0m_lds + W0_P * W0M_PITCH;             // [128][64]; later the [64][160] reduction buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16v acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int boff[5];
+    float bmask[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int kidx = 32 * j + l31;
+        const bool ok = kidx < 147;
+        boff[j] = ok ? (kidx / 21) * W0M_PITCH + (kidx % 21) : 0;
+        bmask[j] = ok ? 1.f : 0.f;
+    }
+    for (long tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x);
+        const long t2 = tile / tiles_x;
+        const int ty = (int)(t2 % tiles_y);
+        const int n = (int)(t2 / tiles_y);
+        const int oy0 = ty * W0_T, ox0 = tx * W0_T;
+        __syncthreads();
+        const uint8_t *img = p.img + (long)n * p.isn;
+        for (int i = tid; i < W0_P * W0_P * 3; i += 256) {
+            const int py = i / (W0_P * 3), pr = i - py * (W0_P * 3);
+            const int px = pr / 3, ch = pr - px * 3;
+            const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = (float)img[(long)iy * p.isy + (long)ix * p.isx + ch];
+            patch[py * W0M_PITCH + pr] = v * (1.0f / 255.0f);
+        }
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            for (int i = tid; i < 128 * 16; i += 256) {
+                const int pix = i >> 4, c4 = i & 15;
+                const int oy = oy0 + half * 8 + (pix >> 4), ox = ox0 + (pix & 15);
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (oy < p.Ho && ox < p.Wo) v = *(const f32x4 *)(p.dy + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + c4 * 4);
+                *(f32x4 *)(dzs + pix * 64 + c4 * 4) = v;
+            }
+            __syncthreads();
+            // this wave: rows 2*wave, 2*wave+1 of the half tile = pixels 32*wave .. 32*wave+31; k-step t: pixel 2t + lh
+            const float *abase = dzs + (32 * wave + lh) * 64 + l31;
+            const float *pbase = patch + (half * 8 + 2 * wave) * W0M_PITCH + lh * 3;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int prow = t >> 3, pcol = 2 * (t & 7);             // pixel 2t: row, column (lh adds one column)
+                const float a0 = abase[2 * t * 64], a1 = abase[2 * t * 64 + 32];
+                const float *pb = pbase + prow * W0M_PITCH + pcol * 3;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const float b = pb[boff[j]] * bmask[j];
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // sum the four waves' partials in LDS ([64 co][160 taps]), then one atomic per weight
+    __syncthreads();
+    float *red = dzs;
+    for (int i = tid; i < 64 * 160; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                atomicAdd(red + co * 160 + 32 * j + l31, acc[i][j][r]);
+            }
+    __syncthreads();
+    for (int i = tid; i < 64 * 147; i += 256) {
+        const int co = i / 147, k = i - co * 147;
+        unsafeAtomicAdd(p.dw + i, red[co * 160 + k]);
+    }
+}
+
 int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream)
 {
     const int tx = (a.Wo + W0_T - 1) / W0_T, ty = (a.Ho + W0_T - 1) / W0_T;
     const long total = (long)tx * ty * a.N;
+    static int valu = -1;
+    if (valu < 0) valu = getenv("HVN_CONV0_WGRAD_VALU") ? 1 : 0;
+    if (!valu) {
+        const size_t lds = (size_t)(W0_P * W0M_PITCH + 64 * 160) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(hvn_conv0_wgrad_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        long blocks = total < 512 ? total : 512;
+        hipLaunchKernelGGL(hvn_conv0_wgrad_mfma, dim3((unsigned)blocks), dim3(256), lds, stream, a, tx, ty, total);
+        return launch_ok();
+    }
     long blocks = total < 1024 ? total : 1024;
     hipLaunchKernelGGL(hvn_conv0_wgrad, dim3((unsigned)blocks), dim3(256), 0, stream, a, tx, ty, total);
     return launch_ok();
