@@ -426,20 +426,27 @@ class TrainEngine:
         if rc:
             raise L.HvnError("hvn_loss_backward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
         base, osz, n = ctypes.addressof(self.bwd_ops), ctypes.sizeof(L.hvn_top), len(self.bwd_ops)
-        split = self._bwd_split if (all_reduce is not None and 0 < self._bwd_split < n) else n
-        pending = []
-        for lo, hi in ((0, split), (split, n)):
+
+        def run(lo, hi):
             if hi > lo:
                 rc = lib.hvn_run_train_plan(base + lo * osz, hi - lo, self.n, s)
                 if rc:
                     raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
-            if all_reduce is not None:
-                bucket = self.gslab[self._dec_off:] if (lo == 0 and split < n) else (self.gslab[:self._dec_off] if split < n else self.gslab)
-                if lo == 0 or split < n:
-                    pending.append(all_reduce(bucket, True))
-            if split == n:
-                break
-        for w in pending:
+
+        split = self._bwd_split
+        if all_reduce is None:
+            run(0, n)
+        elif 0 < split < n:
+            run(0, split)                                              # decoder branches
+            pending = [all_reduce(self.gslab[self._dec_off:], True)]   # their bucket travels under ...
+            run(split, n)                                              # ... conv_bot and the encoder
+            pending.append(all_reduce(self.gslab[:self._dec_off], True))
+            for w in pending:
+                if w is not None and hasattr(w, "wait"):
+                    w.wait()
+        else:
+            run(0, n)
+            w = all_reduce(self.gslab, True)
             if w is not None and hasattr(w, "wait"):
                 w.wait()
         return self.gslab
