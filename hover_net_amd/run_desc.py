@@ -114,3 +114,31 @@ def valid_step(batch_data, run_info):
         result["raw"]["true_tp"] = torch.squeeze(batch_data["tp_map"]).type(torch.int64).numpy()
         result["raw"]["pred_tp"] = pred[..., 0].numpy().copy()
     return result
+
+
+def proc_valid_step_output(raw_data, nr_types=None):
+    """Scalar half of run_desc.py:262-333: validation statistics over the accumulated `valid_step` outputs
+    (`raw_data[name]` = list of per-patch arrays or one stacked array): nucleus-pixel accuracy and Dice at p > 0.5,
+    per-type Dice, HV mean squared error per pixel.  Host numpy, computed over the whole set at once instead of patch
+    by patch; the "image" half (the reference's matplotlib / cv2 visualisation) is not rebuilt and stays empty."""
+    import numpy as np
+
+    track = {"scalar": {}, "image": {}}
+    prob_np = np.asarray(raw_data["prob_np"])
+    true_np = np.asarray(raw_data["true_np"])
+    pred_np = (prob_np > 0.5).astype(np.int32)
+
+    def dice(true, pred, label):
+        t, p = (true == label), (pred == label)
+        return 2.0 * np.logical_and(t, p).sum() / (t.sum() + p.sum() + 1.0e-8)
+
+    nr_pixels = true_np.size
+    track["scalar"]["np_acc"] = (pred_np == true_np).sum() / nr_pixels
+    track["scalar"]["np_dice"] = dice(true_np, pred_np, 1)
+    if nr_types is not None:
+        pred_tp, true_tp = np.asarray(raw_data["pred_tp"]), np.asarray(raw_data["true_tp"])
+        for type_id in range(nr_types):
+            track["scalar"]["tp_dice_%d" % type_id] = dice(true_tp, pred_tp, type_id)
+    err = np.asarray(raw_data["pred_hv"], np.float64) - np.asarray(raw_data["true_hv"], np.float64)
+    track["scalar"]["hv_mse"] = (err * err).sum() / nr_pixels
+    return track
