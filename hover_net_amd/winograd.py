@@ -57,5 +57,7 @@ def transform_weights(wt, m):
     """[cout, cin, r, r] float64 -> U [n^2, cout, cin] float64 with U[a*n+b] = (G g G^T)[a][b], n = m + r - 1."""
     r = wt.shape[2]
     g = mats(m, r)[1]
-    u = np.einsum("ar,ocrs,bs->aboc", g, wt, g)
-    return u.reshape((m + r - 1) ** 2, wt.shape[0], wt.shape[1])
+    # one GEMM: U[(a,b), (o,c)] = sum_{r,s} G[a,r] G[b,s] g[o,c,r,s] = kron(G, G) @ W2^T
+    n = m + r - 1
+    u = np.kron(g, g) @ np.ascontiguousarray(wt.reshape(wt.shape[0] * wt.shape[1], r * r).T)   # [n*n, o*c] float64
+    return u.reshape(n * n, wt.shape[0], wt.shape[1])
