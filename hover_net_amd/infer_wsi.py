@@ -109,6 +109,10 @@ class ArraySlide:
         w, h = int(size[0]), int(size[1])
         return np.asarray(self.array[y:y + h, x:x + w, :3])
 
+    def thumbnail(self, scale=32):
+        """Sub-sampled view (40x -> 1.25x for scale 32), the input of the tissue-mask heuristic."""
+        return np.asarray(self.array[::scale, ::scale, :3])
+
 
 def remove_inst(inst_map, ids):
     if len(ids):
@@ -244,9 +248,14 @@ class WsiInference:
         return [mine[i] for i in range(tiles.shape[0])]
 
     def run(self, slide, mask=None):
-        """slide: object with .shape / .read_region; mask: uint8 tissue mask at any scale (None = all tissue).
+        """slide: object with .shape / .read_region; mask: uint8 tissue mask at any scale, None = all tissue, "auto" = the
+        reference's 1.25x thresholding heuristic (wsi.py:486-500) on `slide.thumbnail(32)`.
         Returns (inst_map int32 [H,W] numpy, inst_info dict) like `wsi_inst_map` / `wsi_inst_info`."""
         shape = np.array(slide.shape[:2])
+        if isinstance(mask, str) and mask == "auto":
+            from . import tissue_mask
+
+            mask = tissue_mask.simple_get_mask(slide.thumbnail(32))
         if mask is None:
             mask = np.ones((max(1, int(shape[0]) // 32), max(1, int(shape[1]) // 32)), np.uint8)
         pred_map = self.raw_prediction(slide, mask)
