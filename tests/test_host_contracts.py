@@ -101,3 +101,16 @@ def test_proc_valid_step_output_matches_the_reference_formulas():
         assert abs(got["tp_dice_%d" % t] - 2 * inter / (total + 1e-8)) < 1e-12
     mse = sum(((raw["pred_hv"][i] - raw["true_hv"][i]) ** 2).sum() for i in range(n)) / npx
     assert abs(got["hv_mse"] - mse) < 1e-5 * mse
+
+
+def test_save_json_protocol(tmp_path):
+    import json
+    from hover_net_amd import io_utils
+    info = {7: {"bbox": np.array([[1, 2], [5, 9]]), "centroid": np.array([4.5, 3.25]), "contour": np.array([[2, 1], [8, 1], [8, 4]], np.int32),
+                "type_prob": 0.75, "type": 3}, 9: {"bbox": np.array([[0, 0], [2, 2]]), "centroid": np.array([1.0, 1.0]), "contour": None,
+                                                    "type_prob": None, "type": None}}
+    p = tmp_path / "x.json"
+    io_utils.save_json(str(p), info, mag=40)
+    d = json.load(open(p))
+    assert d["mag"] == 40 and sorted(d["nuc"]) == ["7", "9"]
+    assert d["nuc"]["7"] == {"bbox": [[1, 2], [5, 9]], "centroid": [4.5, 3.25], "contour": [[2, 1], [8, 1], [8, 4]], "type_prob": 0.75, "type": 3}
