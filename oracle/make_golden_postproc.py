@@ -58,6 +58,21 @@ cases["noise80"] = f.astype(np.float32)
 q = synth_pred_maps(4, 80, 80, None, seed=22, noise=0.0)[0]
 q[..., 1:] = np.round(q[..., 1:] * 4) / 4
 cases["quant80"] = q
+# large connected blobs (components far beyond one nucleus: clumps), many noise markers inside: map 0 is one tile-filling
+# blob, map 1 a ~21k-pixel blob next to ordinary nuclei -- the floods whose heap / label window outgrow on-chip memory
+rb = np.random.Generator(np.random.PCG64(31))
+fb = np.stack([_smooth(rb.normal(0, 1, (2, 200, 200)).transpose(1, 2, 0), it=4).transpose(2, 0, 1) for _ in range(3)], -1)
+fb = fb / fb.std()
+pb = np.zeros((2, 200, 200), np.float32)
+pb[0, 4:196, 4:196] = 0.9
+pb[1, 30:170, 25:175] = 0.9
+small = synth_pred_maps(1, 200, 200, None, seed=32)[0][0]
+keep = np.ones((200, 200), bool)
+keep[24:176, 19:181] = False
+pb[1][keep] = small[..., 0][keep]
+fb[..., 0] = pb
+fb[1, ..., 1:][keep] = small[..., 1:][keep]
+cases["blob200"] = fb.astype(np.float32)
 # degenerate: empty, full, constant h/v
 e = np.zeros((3, 40, 40, 3), np.float32)
 e[1, ..., 0] = 1.0
