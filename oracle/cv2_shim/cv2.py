@@ -5,7 +5,9 @@ models/hovernet/post_proc.py (under /opt/conda/bin/python3.9, which has real sci
 and scikit-image) this module supplies the cv2 entry points that file touches
 (post_proc.py:49-54,56-57,59-68,76,83-84), implemented by the C restatement in
 oracle/hvn_oracle.c.  The scipy / skimage / numpy parts of the golden vectors are
-therefore the real thing; the cv2 parts are the restatement (parity unpinned).
+therefore the real thing; the cv2 image filters are the C restatement, cross-checked by a second,
+scipy-based stand-in (oracle/cv2_shim_scipy/cv2.py, tests/test_oracle_cv2_independent.py);
+moments / findContours (post_proc.py:131-135) are python (_suzuki.py).
 """
 import os
 import sys
@@ -13,6 +15,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import postproc as _o  # noqa: E402  (oracle/postproc.py)
 
 NORM_MINMAX = 32
@@ -54,3 +57,19 @@ def morphologyEx(src, op, kernel):
     assert op == MORPH_OPEN and src.dtype == np.uint8
     assert np.array_equal(kernel, getStructuringElement(MORPH_ELLIPSE, (5, 5)))
     return _o.morph_open5(src)
+
+
+# --- post_proc.py:131-135 (the per-instance loop of `process`): independent python restatement, NOT the C oracle and
+# --- not the product's tracer (see _suzuki.py)
+from _suzuki import find_contours_tree as _find_contours_tree, moments as _moments  # noqa: E402
+
+
+def moments(array, binaryImage=False):
+    assert not binaryImage
+    return _moments(array)
+
+
+def findContours(image, mode, method):
+    """OpenCV >= 4 protocol: (contours, hierarchy)."""
+    assert mode == RETR_TREE and method == CHAIN_APPROX_SIMPLE and image.dtype == np.uint8
+    return _find_contours_tree(image)

@@ -21,16 +21,25 @@
  *     produced by the reference's own, unmodified post_proc.py running under
  *     /opt/conda/bin/python3.9 with real scipy 1.7.1 + scikit-image 0.18.3
  *     (oracle/make_golden_postproc.py); this file must reproduce them bit for bit.
- *   - OpenCV parts: PARITY UNPINNED.  OpenCV is not installed anywhere on the
- *     build box, so the cv2 arithmetic below follows the OpenCV 4.3 sources from
- *     memory (file names cited at each function).  The golden files were made with
- *     oracle/cv2_shim/cv2.py, which calls *this* library for those seven cv2
- *     functions, so they cannot detect a mis-remembered OpenCV rounding order.
+ *   - OpenCV parts: pinned to a SECOND, independently written restatement, not to OpenCV itself.
+ *     OpenCV is not installed anywhere on the build box, so the cv2 arithmetic below follows the
+ *     OpenCV 4.3 sources from memory (file names cited at each function), and the golden files were
+ *     made with oracle/cv2_shim/cv2.py, which calls *this* library for normalize / Sobel /
+ *     GaussianBlur / morphologyEx.  What guards against a mis-remembered kernel, border mode or
+ *     structuring element: oracle/cv2_shim_scipy/cv2.py restates the same calls with scipy.ndimage in
+ *     float64 without this file's operation order; tests/test_oracle_cv2_independent.py holds the two
+ *     together (integer results bit-equal, floating point within a few ulp = summation order only) and
+ *     oracle/check_alt_shim.py shows that the reference's own __proc_np_hv over the second shim
+ *     reproduces all 56 committed golden instance maps exactly (reference PQ == 1).  What stays
+ *     unverifiable without OpenCV: the last-bit rounding ORDER of its SIMD paths.
  *     Assumed build: the AVX2/FMA3 dispatch units (what an opencv-python wheel
  *     runs on any x86 host since Haswell), i.e. `s += f*x` contracts to one fma.
  *     Where the products are exact (integer taps x float32 data, power-of-two
  *     taps) this makes no difference; it matters in the Sobel column pass and
  *     in convertTo.
+ *   - process()'s per-instance loop (post_proc.py:119-181; cv2.moments / findContours): restated in
+ *     python (oracle/process_np.py + oracle/cv2_shim/_suzuki.py), pinned by tests/golden/proc_*.npz,
+ *     which the reference's own process() made (oracle/make_golden_process.py).
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (see oracle/Makefile).
  * -ffp-contract=off so that the only fused operations are the explicit fma()/

@@ -107,6 +107,35 @@ def test_process_contract_and_instance_table():
     assert info2 is None
 
 
+PROC_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "proc_*.npz")))
+
+
+@pytest.mark.parametrize("path", PROC_CASES, ids=[os.path.basename(p)[5:-4] for p in PROC_CASES])
+def test_process_matches_reference_golden(path):
+    """`process()` end to end (instance separation + hvn_instance_table on the GPU, contours + dict on the host) against
+    the fixtures made by the reference's own unmodified process() (oracle/make_golden_process.py): instance map, dict key
+    set and order, bbox, centroid, contour point order, type and type_prob -- all compared with ==."""
+    from golden_util import assert_same_info, golden_dicts
+    from hover_net_amd import post_proc
+
+    z = np.load(path)
+    nt = None if int(z["nr_types"]) < 0 else int(z["nr_types"])
+    for i, want in enumerate(golden_dicts(z)):
+        inst, info = post_proc.process(z["pred"][i], nr_types=nt, return_centroids=True)
+        np.testing.assert_array_equal(inst, z["inst"][i])
+        assert inst.dtype == np.int32
+        assert_same_info(info, want)
+    # the batched device path gives the same records for all maps of the case at once
+    pred = torch.from_numpy(z["pred"]).to("cuda")
+    inst_b, rec, counts = post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True)
+    np.testing.assert_array_equal(inst_b.cpu().numpy(), z["inst"])
+    rec_h = rec.cpu().numpy()
+    for i, want in enumerate(golden_dicts(z)):
+        got = post_proc.records_to_dict(rec_h[i].view(post_proc._REC_DTYPE).reshape(-1), nt, z["inst"][i])
+        assert_same_info(got, want)
+        assert int(counts[i]) == len(np.unique(z["inst"][i])) - 1
+
+
 def test_empty_and_full_maps():
     e = np.zeros((3, 40, 40, 3), np.float32)
     e[1, ..., 0] = 1.0
