@@ -1,19 +1,32 @@
 #!/usr/bin/env python
-"""bench.py -- tiles/sec of the HoVer-Net hot path on MI355X (BASELINE.json metric).
+"""bench.py -- tiles/sec of the HoVer-Net hot path on MI355X (BASELINE.json metric, cfg 2).
 
-One *step* = one pass of the whole hot path over one batch of synthetic input already resident
-in HBM: 32 uint8 270x270 tiles -> HIP network (original mode, 5 types, fp32) -> infer_step
-epilogue -> on-GPU instance separation (Sobel/threshold/CC/watershed) + per-instance table, the
-latter on a side stream so that it overlaps the next step's network (hover_net_amd/pipeline.py).
-No host round trip inside the step.  N > 1: one process per GPU (torch.distributed / RCCL for
-the barrier and the max-over-ranks clock only); tiles are independent units, so every rank
-processes its own batches and there is no data-path collective ("weak" scaling).
+One *step* = one pass of the whole hot path over one batch of synthetic tiles resident in HBM:
+32 uint8 270x270 tiles -> HIP network (original mode, 5 types, fp32) -> infer_step epilogue -> on-GPU
+instance separation (Sobel / threshold / CC / watershed) + per-instance table -> [N > 1: RCCL gather of
+instance maps + record tables to rank 0] -> D2H of instance maps, records and counts into pinned host
+memory.  The post-processing of step i runs on a side stream under the network of step i+1
+(hover_net_amd/pipeline.py); nothing inside a step waits on the host.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fp32-MFMA
-implicit-GEMM conv): algorithmic conv FLOPs of one step / summed duration of that step's conv
-launches, measured with HIP events on the launch stream in an extra, untimed step.
-`cpu_baseline` (N=1 only) times the CPU oracle (torch fp32 restatement + C post-proc port) on
-a bounded sample of the same workload on this box's host cores.
+`value` = tiles/s over exactly --steps steps, inputs resident in HBM, results on the host.  Two more rates
+are measured in separate, untimed-by-the-driver legs and reported under `variants` (SURVEY 8d defines the
+metric from pinned host memory to host results): `host_to_host` (tiles start in pinned host memory, H2D
+inside) and `with_dict` (additionally the contour tracing + inst_info_dict assembly of the structured maps on
+the host, i.e. everything `post_proc.process` returns).  `sustained` repeats the timed step for >= 8 s.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Tiles are independent units: every rank
+runs the network + instance separation on its own batch (weak scaling, global batch = 32 N) and the results
+are gathered to rank 0 INSIDE the timed step (`infer_tile.gather_to_rank0`, the collective north_star names).
+`--scaling strong` keeps a fixed set of --strong-tiles tiles and splits it over the ranks instead.
+
+`roofline` is for the dominant kernel (`hvn_conv_igemm_f32`, fp32 MFMA): achieved = MFMA FLOPs the conv
+launches of one step EXECUTE (after the Winograd transforms: that is what the matrix pipe issues) / summed
+HIP-event duration of those launches, measured in the same single-stream execution mode as the timed steps.
+`algorithmic_speedup` = direct-convolution FLOPs / executed FLOPs (what Winograd removes) is reported
+beside it, never folded into `frac`.  `cpu_baseline` (N = 1 only) times the CPU oracle -- torch fp32
+restatement of the network + the C / python restatement of `process()` -- on a bounded sample of the same
+tiles on this box's host cores.  The reference itself is python under /root/reference and cannot travel to
+the GPU box, so kind = "port"; profiles/ holds the reference's own timing taken in the build container.
 """
 import argparse
 import json
@@ -31,18 +44,21 @@ PEAK_BF16_MATRIX_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16 (cfg 3 o
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--mode", default="original")
     ap.add_argument("--nr-types", type=int, default=5)
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--strong-tiles", type=int, default=1024, help="size of the fixed tile set of --scaling strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the host_to_host / with_dict / sustained legs")
+    ap.add_argument("--sustain-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--quiet-net-output", action="store_true",
                     help="bias the NP head of the random-init checkpoint towards background, so that the network's own output "
-                         "holds no nuclei and the instance-separation load of the step comes from the structured maps only "
-                         "(the 'fast'-mode random init otherwise emits tile-filling blobs, the flood's worst case)")
+                         "holds no nuclei and the instance-separation load of the step comes from the structured maps only")
     ap.add_argument("--dtype", default="fp32", choices=("fp32", "bf16"),
                     help="fp32 = the headline configuration (BASELINE cfg 2); bf16 = cfg 3 (use with --mode fast --nr-types 6 --batch 64)")
     args = ap.parse_args()
@@ -59,10 +75,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
+    from hover_net_amd import infer_tile, post_proc, run_desc
     from hover_net_amd import lib as L
-    from hover_net_amd import net_desc, post_proc, run_desc
+    from hover_net_amd import net_desc
+    from hover_net_amd.pipeline import TilePipeline
     from hover_net_amd.synth import synth_pred_maps, synth_state_dict, synth_tiles
 
     nt = args.nr_types if args.nr_types > 0 else None
@@ -75,23 +94,34 @@ def main():
     net.max_batch = args.batch
     net.compute_dtype = args.dtype
     net = net.to(dev).eval()
-    tiles = torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank)).to(dev)  # resident in HBM
-    # A random-init network emits maps without nuclei (0 instances -> the watershed has nothing to
-    # flood).  So that the step carries a realistic instance-separation load it ALSO post-processes a
-    # resident batch of structured synthetic maps (painted, partly touching elliptical nuclei,
-    # hover_net_amd.synth.synth_pred_maps): post-proc runs twice per step, which over-counts its cost.
-    # Density: CoNSeP has 24 319 nuclei in 41 images of 1000x1000 px = 3.8 per 80x80 output tile; the
-    # structured maps carry 2..8 (mean 5) per 80x80, scaled by area for other output sizes.
+    # the work of one step on this rank: `sub` batches of `args.batch` tiles
+    if args.scaling == "strong":
+        lo, hi = infer_tile.shard_range(args.strong_tiles, rank, world)
+        sub = max(1, -(-(hi - lo) // args.batch))
+        tiles_per_step_global = args.strong_tiles
+    else:
+        sub = 1
+        tiles_per_step_global = world * args.batch
+    tiles_host = [torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank + 1000 * j)).pin_memory() for j in range(sub)]
+    tiles = [t.to(dev) for t in tiles_host]                       # resident in HBM
+    # A random-init network emits maps without nuclei (0 instances -> the watershed has nothing to flood).  So that the
+    # step carries a realistic instance-separation load it ALSO post-processes a resident batch of structured synthetic
+    # maps (painted, partly touching elliptical nuclei, hover_net_amd.synth.synth_pred_maps): post-proc runs twice per
+    # batch, which over-counts its cost.  Density: CoNSeP has 24 319 nuclei in 41 images of 1000x1000 px = 3.8 per 80x80
+    # output tile; the structured maps carry 2..8 (mean 5) per 80x80, scaled by area for other output sizes.
     out_hw = net.engine(args.batch).plan.geo["out"]
-    structured = torch.from_numpy(synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank, k_lo=2, k_hi=8)[0]).to(dev)
+    structured_np = synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank, k_lo=2, k_hi=8)[0]
+    structured = torch.from_numpy(structured_np).to(dev)
 
-    from hover_net_amd.pipeline import TilePipeline
-
-    # network of step i+1 (main stream) overlaps the post-processing of step i (side stream)
+    # network of batch i+1 (main stream) overlaps the post-processing of batch i (side stream)
     pipe = TilePipeline(net, nr_types=nt, return_centroids=True)
+    gather = infer_tile.gather_to_rank0 if world > 1 else None
 
-    def step():
-        return pipe.submit(tiles, extra_maps=structured)
+    def step(src=tiles):
+        out = None
+        for t in src:
+            out = pipe.submit(t, extra_maps=structured, gather=gather, to_host=True)
+        return out
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -99,88 +129,158 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    n_inst = int(out[2].sum().item())
+    dt, out = timed(step, args.steps)
+    n_inst = int(out[2].sum().item()) if (rank == 0 and out is not None) else 0
+    if rank == 0 and world > 1:
+        assert out[0].shape[0] == world * args.batch, "rank 0 must hold every rank's instance maps after the gather"
 
+    ms_per_step = 1e3 * dt / args.steps
     result = {
         "metric": "tiles/sec (%dx%d, batch %d) end-to-end incl. watershed" % (size, size, args.batch),
-        "value": world * args.batch * args.steps / dt,
+        "value": tiles_per_step_global * args.steps / dt,
         "unit": "tiles/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 tiles per GPU, "
-                               "random-init checkpoint (seeded%s), network + infer_step epilogue + on-GPU watershed post-proc "
-                               "(of the network output AND of a resident batch of structured synthetic maps, see bench.py)"
-                               % (args.mode, nt, args.batch, size, size, ", NP head biased to background" if args.quiet_net_output else ""),
-                   "global_batch": world * args.batch, "instances_last_step": n_inst, "parallelism": "tile-sharded x%d" % world},
+        "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 tiles per GPU resident in HBM, "
+                               "random-init checkpoint (seeded%s): network + infer_step epilogue + on-GPU instance separation and "
+                               "instance table (of the network output AND of a resident batch of structured synthetic maps), %s"
+                               "D2H of instance maps + records to pinned host memory"
+                               % (args.mode, nt, args.batch, size, size, ", NP head biased to background" if args.quiet_net_output else "",
+                                  "RCCL gather to rank 0, " if world > 1 else ""),
+                   "global_batch": tiles_per_step_global, "world_size": world, "batches_per_step_per_rank": sub,
+                   "instances_last_step": n_inst,
+                   "parallelism": "tile-sharded x%d, %s" % (world, "gather to rank 0 per batch" if world > 1 else "single GPU"),
+                   "execution": "network on one HIP stream (decoder branches batched per launch), post-processing + D2H on a side stream"},
     }
 
+    # ---- per-stage split of one batch (rank 0, untimed extra passes, torch events on the launch stream) -------------
     if rank == 0:
-        # split of one step (untimed extra passes, torch events on the launch stream)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        pred = run_desc.infer_step_device(tiles, net)
-        ev[1].record()
-        post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True)
-        ev[2].record()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         torch.cuda.synchronize(dev)
-        result["config"]["network_ms"] = ev[0].elapsed_time(ev[1])
-        result["config"]["postproc_structured_ms"] = ev[1].elapsed_time(ev[2])
+        ev[0].record()
+        pred = run_desc.infer_step_device(tiles[0], net)
+        ev[1].record()
+        inst, rec, counts = post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True)
+        ev[2].record()
+        host = [t.cpu() for t in (inst, rec, counts)]
+        ev[3].record()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        rec_h, inst_h = host[1].numpy(), host[0].numpy()
+        dicts = [post_proc.records_to_dict(rec_h[i].view(post_proc._REC_DTYPE).reshape(-1), nt, inst_h[i]) for i in range(inst_h.shape[0])]
+        dict_ms = 1e3 * (time.perf_counter() - t1)
+        result["config"]["stage_ms"] = {"network": ev[0].elapsed_time(ev[1]), "postproc_structured": ev[1].elapsed_time(ev[2]),
+                                        "d2h_results": ev[2].elapsed_time(ev[3]), "host_contours_and_dict": dict_ms,
+                                        "instances_in_dicts": sum(len(d) for d in dicts)}
 
+    # ---- variants (untimed by the driver; same K steps each) ---------------------------------------------------------
+    if not args.no_variants:
+        variants = {}
+        dt_h, _ = timed(lambda: step(tiles_host), args.steps)
+        variants["host_to_host"] = {"value": tiles_per_step_global * args.steps / dt_h, "unit": "tiles/s",
+                                    "what": "tiles start in pinned host memory (H2D inside the step), results end in pinned host memory"}
+        if world == 1:
+            prev = [None]
+
+            def step_dict():
+                o = step(tiles_host)
+                done = prev[0]
+                prev[0] = (o, torch.cuda.Event())
+                prev[0][1].record(pipe.side)
+                if done is not None:                # host half of process() for the PREVIOUS step, under this step's GPU work
+                    done[1].synchronize()
+                    ih, rh = done[0][0].numpy(), done[0][1].numpy()
+                    for i in range(ih.shape[0]):
+                        post_proc.records_to_dict(rh[i].view(post_proc._REC_DTYPE).reshape(-1), nt, ih[i])
+                return o
+
+            dt_d, _ = timed(step_dict, args.steps)
+            variants["with_dict"] = {"value": tiles_per_step_global * args.steps / dt_d, "unit": "tiles/s",
+                                     "what": "host_to_host + contour tracing and inst_info_dict assembly on the host (one thread), "
+                                             "overlapped with the next step's GPU work"}
+        reps, t_end = 0, time.perf_counter() + args.sustain_seconds
+        fence()
+        t0 = time.perf_counter()
+        while True:
+            for _ in range(args.steps):
+                step()
+            reps += args.steps
+            flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=dev)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 0.0:
+                break
+        fence()
+        dt_s = time.perf_counter() - t0
+        variants["sustained"] = {"value": tiles_per_step_global * reps / dt_s, "unit": "tiles/s", "steps": reps, "seconds": dt_s,
+                                 "what": "the timed step repeated for >= %.0f s (same mode)" % args.sustain_seconds}
+        result["variants"] = variants
+
+    # ---- roofline of the dominant kernel (rank 0) ---------------------------------------------------------------------
     if rank == 0 and not args.no_roofline:
         eng = net.engine(args.batch)
-        conv_flops = sum(o.flops() for o in eng.plan.ops if o.kind == 2) * args.batch
-        # single launch stream for this pass (HIP events bracket each conv launch on that stream)
-        saved = (eng.n_split, eng.n_lane_streams)
-        eng.n_split, eng.n_lane_streams = 1, 0
-        torch.cuda.synchronize(dev)
-        L.lib().hvn_profile_enable(1)
-        run_desc.infer_step_device(tiles, net)
-        ms = L.lib().hvn_profile_conv_ms()
-        launches = L.lib().hvn_profile_conv_launches()
-        L.lib().hvn_profile_enable(0)
-        eng.n_split, eng.n_lane_streams = saved
-        achieved = conv_flops / (ms * 1e-3) / 1e12
-        # MFMA FLOPs actually issued: the 5x5 decoder convs run as Winograd F(4x4,5x5) (4 instead of 25 multiplies per
-        # output), so the algorithmic rate can exceed the matrix-pipe peak; the executed rate cannot
+        assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: HVN_SPLIT=1 HVN_LANES=0"
+        n_prof = 5
+        algo_flops = sum(o.flops() for o in eng.plan.ops if o.kind == 2) * args.batch
         exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in eng.plan.ops if o.kind == 2) * args.batch
-        executed = exec_flops / (ms * 1e-3) / 1e12
-        # HBM bytes of the same 140 launches from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        # (tools/pmc_traffic.py, gfx950 x2 correction on FETCH_SIZE); cannot be collected live
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5 and args.dtype == "fp32":
-            traffic = json.load(open(tpath))["hbm_bytes_per_step"]
+        torch.cuda.synchronize(dev)
+        ms_list, launches = [], 0
+        for _ in range(n_prof):
+            L.lib().hvn_profile_enable(1)
+            run_desc.infer_step_device(tiles[0], net)           # same engine, same single launch stream as the timed steps
+            ms_list.append(L.lib().hvn_profile_conv_ms())
+            launches = L.lib().hvn_profile_conv_launches()
+            L.lib().hvn_profile_enable(0)
+        ms = sorted(ms_list)[len(ms_list) // 2]
+        n_conv = sum(1 for o in eng.plan.ops if o.kind == 2)
         peak = PEAK_FP32_MATRIX_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
-        result["roofline"] = {"bound": "mfma", "kernel": "hvn_conv_igemm_f32" if args.dtype == "fp32" else "hvn_conv_igemm_bf16",
-                              "achieved": achieved, "peak": peak,
-                              "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                              "traffic_unit": "HBM bytes per step (all conv launches; rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
-                              "launches_per_step": launches, "conv_ms_per_step": ms, "conv_gflop_per_step": conv_flops / 1e9,
-                              "executed": {"achieved": executed, "frac": executed / peak, "gflop_per_step": exec_flops / 1e9,
-                                           "note": "MFMA FLOPs issued after Winograd F(4x4,5x5) on the 5x5 convs; `achieved` above is "
-                                                   "direct-convolution (algorithmic) FLOPs over the same time, transforms included"}}
+        achieved = exec_flops / (ms * 1e-3) / 1e12
+        traffic, tsrc = None, None
+        for name in ("r02_pmc_traffic.json",):
+            tpath = os.path.join(REPO, "profiles", name)
+            if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5 and args.dtype == "fp32":
+                traffic, tsrc = json.load(open(tpath))["hbm_bytes_per_step"] / max(1, n_conv), name
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "hvn_conv_igemm_f32" if args.dtype == "fp32" else "hvn_conv_igemm_bf16",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per conv launch, mean over the step's launches (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                            "separate passes; profiles/%s)" % tsrc if traffic is not None else None,
+            "flops_per_launch": exec_flops / max(1, n_conv), "avg_launch_ms": ms / max(1, launches),
+            "timed_launches_per_step": launches, "conv_launches_per_step": n_conv,
+            "conv_ms_per_step": ms, "executed_gflop_per_step": exec_flops / 1e9,
+            "algorithmic_gflop_per_step": algo_flops / 1e9, "algorithmic_speedup": algo_flops / exec_flops,
+            "note": "achieved = MFMA FLOPs executed by the conv launches of one step (Winograd-domain GEMMs counted as issued; "
+                    "SURVEY 8d's 392.17 GFLOP/tile direct-convolution figure is `algorithmic_gflop_per_step` / batch) / summed "
+                    "HIP-event time of those launches incl. the Winograd transform launches, median of %d passes, single stream" % n_prof}
+        result["config"]["network_share_of_step"] = result["config"]["stage_ms"]["network"] / ms_per_step if sub == 1 else None
 
+    # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same tiles ------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import net_torch
+        from oracle import net_torch, process_np
         from oracle import postproc as O
 
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -197,23 +297,25 @@ def main():
             best = min(best, (time.perf_counter() - t1, th))
         cores = best[1]
         torch.set_num_threads(cores)
-        cpu_tiles = tiles.cpu()
+        cpu_tiles = tiles_host[0]
 
         def cpu_pass(k):
+            t1 = time.perf_counter()
             x = cpu_tiles[:k].permute(0, 3, 1, 2).float()
             pm = net_torch.infer_epilogue(net_torch.forward(sd, x, args.mode)).numpy()
-            return O.proc_batch(pm)
+            t2 = time.perf_counter()
+            for m in list(pm) + list(structured_np[:k]):       # what the GPU step post-processes: net output + structured maps
+                process_np.process(m, nt, True)
+            return t2 - t1, time.perf_counter() - t2
 
-        t1 = time.perf_counter()
-        cpu_pass(1)
-        one = time.perf_counter() - t1
+        one = sum(cpu_pass(1))
         k = int(max(1, min(args.batch, round(args.cpu_seconds / max(one, 1e-3)))))
-        t1 = time.perf_counter()
-        cpu_pass(k)
-        cdt = time.perf_counter() - t1
-        result["cpu_baseline"] = {"value": k / cdt, "unit": "tiles/s", "cores": cores, "kind": "port",
-                                  "sample": "%d of the same %d tiles: oracle/net_torch.py (torch-CPU fp32, %d threads) + "
-                                            "oracle/hvn_oracle.c post-proc (1 thread)" % (k, args.batch, cores)}
+        net_s, pp_s = cpu_pass(k)
+        result["cpu_baseline"] = {"value": k / (net_s + pp_s), "unit": "tiles/s", "cores": cores, "kind": "port",
+                                  "sample": "%d of the same %d tiles: oracle/net_torch.py (torch-CPU fp32, %d threads) %.2f s + "
+                                            "oracle process() restatement (hvn_oracle.c + process_np.py, 1 thread) on the %d network maps and "
+                                            "%d structured maps %.2f s" % (k, args.batch, cores, net_s, k, k, pp_s),
+                                  "network_s_per_tile": net_s / k, "postproc_s_per_tile": pp_s / k}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

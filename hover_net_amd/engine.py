@@ -60,8 +60,8 @@ class Engine:
         # independent sub-batches on their own HIP streams lets the tail of one chain be filled by
         # the other's workgroups.
         import os
-        self.n_split = int(os.environ.get("HVN_SPLIT", "2")) if n_split is None else int(n_split)
-        self.n_lane_streams = int(os.environ.get("HVN_LANES", "2"))  # extra streams for the decoder branches
+        self.n_split = int(os.environ.get("HVN_SPLIT", "1")) if n_split is None else int(n_split)
+        self.n_lane_streams = int(os.environ.get("HVN_LANES", "0"))  # extra streams for the decoder branches (0: one launch stream)
         self.split_decoder = os.environ.get("HVN_SPLIT_DECODER", "0") != "0"
         self._streams = None
         self._upload_params()

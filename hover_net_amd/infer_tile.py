@@ -141,6 +141,30 @@ def gather_shards(local, n_items):
     return torch.cat(parts, 0)
 
 
+def gather_to_rank0(tensors, dst=0):
+    """Fan-in of per-rank results to rank `dst`: `tensors` is a tuple of tensors (None entries pass through) whose
+    shapes are the same on every rank; returns, on rank `dst`, the tuple of [world * n, ...] concatenations in rank
+    order and None elsewhere.  One `dist.gather` per tensor (RCCL: point-to-point sends over xGMI into rank `dst`'s
+    buffer; gloo in the CPU tests) -- the instance maps and the fixed-size record tables travel as tensors, nothing
+    is pickled.  world == 1: returns `tensors` unchanged."""
+    dist, rank, world = _dist()
+    if world == 1:
+        return tensors
+    out = []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        t = t.contiguous()
+        if rank == dst:
+            full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.gather(t, list(full.chunk(world, 0)), dst=dst)
+            out.append(full)
+        else:
+            dist.gather(t, None, dst=dst)
+    return tuple(out) if rank == dst else None
+
+
 def run_sharded(items, step_fn, batch_size):
     """Apply `step_fn(batch) -> tensor [b, ...]` to this rank's contiguous share of `items`
     ([P, ...] tensor) in batches and return the result for ALL items on every rank."""

@@ -27,11 +27,16 @@ class TilePipeline:
         self._n = 0
         self._last = None
 
-    def submit(self, tiles_u8, extra_maps=None):
+    def submit(self, tiles_u8, extra_maps=None, gather=None, to_host=False):
         """Network on the current stream, post-processing on the side stream.  Returns
-        (inst, records, counts) device tensors that are valid after `wait()` (or after the side
+        (inst, records, counts) tensors that are valid after `wait()` (or after the side
         stream is otherwise synchronised).  `extra_maps`: optional additional [N,h,w,C] maps to
-        post-process in the same side-stream slot (bench.py's structured workload)."""
+        post-process in the same side-stream slot (bench.py's structured workload).
+        `gather`: optional callable applied to the result tuple on the side stream (the multi-GPU
+        path hands `infer_tile.gather_to_rank0` here, so the RCCL gather overlaps the next network
+        pass too).  `to_host=True`: the results are copied to pinned host memory on the side stream
+        (the reference's contract ends on the host: infer/tile.py:308-316); the returned tensors are
+        then the pinned buffers of this slot, overwritten two submits later."""
         main = torch.cuda.current_stream(self.device)
         k = self._n & 1
         self._n += 1
@@ -48,6 +53,10 @@ class TilePipeline:
             out = self._run_pp(self._buf[k])
             if extra_maps is not None:
                 out = self._run_pp(extra_maps)
+            if gather is not None:
+                out = gather(out)
+            if to_host and out is not None:
+                out = self._to_host(out, k)
             self._free[k] = torch.cuda.Event()
             self._free[k].record(self.side)
         self._last = out
@@ -59,6 +68,20 @@ class TilePipeline:
             rec, counts = self._pp.table(inst, maps, self.nr_types)
             return inst, rec, counts
         return inst, None, None
+
+    def _to_host(self, out, k):
+        """D2H of (inst, records, counts) into this slot's pinned buffers, asynchronous on the side stream."""
+        if not hasattr(self, "_pin"):
+            self._pin = [None, None]
+        bufs = self._pin[k]
+        if bufs is None or any((b is None) != (t is None) or (t is not None and (b.shape != t.shape or b.dtype != t.dtype))
+                               for b, t in zip(bufs, out)):
+            bufs = tuple(None if t is None else torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
+            self._pin[k] = bufs
+        for b, t in zip(bufs, out):
+            if t is not None:
+                b.copy_(t, non_blocking=True)
+        return bufs
 
     def wait(self):
         self.side.synchronize()
