@@ -186,6 +186,7 @@ struct LossArgs {
     float *gws;                        // [N][H][W][2] focus-weighted Sobel differences
     int N, H, W, T;
     double m_total;
+    float wt[6];                       // np bce, np dice, hv mse, hv msge, tp bce, tp dice
 };
 int hvn_launch_loss(const LossArgs &a, int stage, hipStream_t stream);
 int hvn_launch_adam(float *w, const float *g, float *m, float *v, long n, float b1, float b2, float eps, float step_size,

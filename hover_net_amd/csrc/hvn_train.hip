@@ -972,7 +972,7 @@ int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream)
 }
 
 // =========================================================================================
-// losses (utils.py:54-172 as composed by run_desc.py:40-82; all weights 1)
+// losses (utils.py:54-172 as composed by run_desc.py:40-82 with the weight table of opt.py:47-51: wt[] scales the gradients)
 //   sums[0] bce_np  [1] bce_tp  [2] mse  [3] msge numerator  [4] focus sum (both channels)
 //   sums[8 + c]  dice np: inse[c], [10 + c] l[c], [12 + c] r[c]   (c < 2)
 //   sums[16 + c] dice tp: inse[c], [32 + c] l[c], [48 + c] r[c]   (c < T <= 16)
@@ -1101,7 +1101,8 @@ __global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long tota
         }
         float *d = p.d_np + (long)n * 2 * plane + pix;
         for (int c = 0; c < 2; ++c)
-            d[c * plane] = (float)((double)gate * ((double)pr[c] - (c == tc ? 1.0 : 0.0)) / M + (double)pr[c] * (D[c] - dot));
+            d[c * plane] = (float)((double)p.wt[0] * ((double)gate * ((double)pr[c] - (c == tc ? 1.0 : 0.0)) / M) +
+                                   (double)p.wt[1] * ((double)pr[c] * (D[c] - dot)));
     }
     if (p.T > 0) {
         const float *l = p.l_tp + (long)n * p.T * plane + pix;
@@ -1130,7 +1131,8 @@ __global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long tota
         }
         float *d = p.d_tp + (long)n * p.T * plane + pix;
         for (int c = 0; c < p.T; ++c)
-            d[c * plane] = (float)((double)gate * ((double)pr[c] - (c == tc ? 1.0 : 0.0)) / M + (double)pr[c] * (D[c] - dot));
+            d[c * plane] = (float)((double)p.wt[4] * ((double)gate * ((double)pr[c] - (c == tc ? 1.0 : 0.0)) / M) +
+                                   (double)p.wt[5] * ((double)pr[c] * (D[c] - dot)));
     }
     {
         const float *l = p.l_hv + (long)n * 2 * plane;
@@ -1150,8 +1152,8 @@ __global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long tota
             }
         const float kf = (float)(2.0 / (p.sums[4] + 1.0e-8));
         float *d = p.d_hv + (long)n * 2 * plane + pix;
-        d[0] = d0 / (float)M + kf * a0;        // mse: mean over M*2 elements of e^2 -> e / M
-        d[plane] = d1 / (float)M + kf * a1;
+        d[0] = p.wt[2] * (d0 / (float)M) + p.wt[3] * (kf * a0);        // mse: mean over M*2 elements of e^2 -> e / M
+        d[plane] = p.wt[2] * (d1 / (float)M) + p.wt[3] * (kf * a1);
     }
 }
 

@@ -168,6 +168,10 @@ static int loss_common(const hvn_loss *l, LossArgs &a)
     a.sums = l->sums; a.gws = l->sobel_ws;
     a.N = l->n; a.H = l->h; a.W = l->w; a.T = l->nr_types;
     a.m_total = l->total_pixels;
+    for (int i = 0; i < 6; ++i) {
+        if (!(l->weight[i] >= 0.f)) return HVN_E_ARG;   // also rejects NaN
+        a.wt[i] = l->weight[i];
+    }
     return 0;
 }
 

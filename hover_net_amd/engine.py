@@ -27,6 +27,27 @@ def _view_struct(v, base_ptr, sn, itemsize=4):
     return s
 
 
+WG_SLOTS = 512          # conv workgroups resident at once: 2 per CU (LDS) x 256 CUs
+NARROW_TILE_COST = 0.54  # a 128x64 tile's time relative to a 128x128 tile (half the MFMAs, A tile re-read, measured ~8 % less efficient)
+
+
+def pick_tile_n(op, batch):
+    """Column tile (128 or 64) of a CONV launch by its wave quantisation: a launch of W workgroups runs in ceil(W / 512)
+    rounds, so 1092 workgroups of 128x128 tiles (2.13 rounds -> 3) lose 29 % to the last round, while 2184 workgroups of
+    128x64 tiles need 5 half-length rounds.  The packed weights are the same for both (cout is padded to 128).  Only plain
+    launches with cout >= 128 are re-tiled; HVN_TILE_SELECT=0 keeps the static choice of plan._tile_n."""
+    import math
+    import os
+
+    if op.tile_n != 128 or os.environ.get("HVN_TILE_SELECT", "1") == "0":
+        return op.tile_n
+    m_tiles = math.ceil(batch * op.y.h * op.y.w / 128.0)
+    nb = int(op.extra.get("nbatch", 1))
+    wide = math.ceil(m_tiles * math.ceil(op.cout / 128.0) * nb / WG_SLOTS)
+    narrow = math.ceil(m_tiles * math.ceil(op.cout / 64.0) * nb / WG_SLOTS) * NARROW_TILE_COST
+    return 64 if narrow < wide else 128
+
+
 def to_bf16_bits(a):
     """float32 array -> bfloat16 bit patterns (uint16), round to nearest even."""
     u = np.ascontiguousarray(a, np.float32).view(np.uint32)
@@ -132,6 +153,8 @@ class Engine:
             o.act_dtype = 1 if self.dtype == "bf16" else 0
             o.kind, o.kh, o.kw, o.stride = op.kind, op.kh, op.kw, op.stride
             o.pad_t, o.pad_l, o.relu, o.cout, o.tile_n, o.x_dtype = op.pad_t, op.pad_l, op.relu, op.cout, op.tile_n, 0
+            if op.kind == PL.OP_CONV and self.dtype == "fp32":
+                o.tile_n = pick_tile_n(op, self.max_batch)
             o.groups = int(op.extra.get("groups", 1))
             o._rsv = int(op.extra.get("stride2", 1))
             o.nbatch = int(op.extra.get("nbatch", 1))

@@ -36,7 +36,7 @@ class hvn_top(ctypes.Structure):
 class hvn_loss(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("logits_np", "logits_hv", "logits_tp", "true_np", "true_tp", "true_hv",
                                                "grad_np", "grad_hv", "grad_tp", "sums", "sobel_ws")] + \
-               [(k, ctypes.c_int32) for k in ("n", "h", "w", "nr_types")] + [("total_pixels", ctypes.c_double)]
+               [(k, ctypes.c_int32) for k in ("n", "h", "w", "nr_types")] + [("total_pixels", ctypes.c_double), ("weight", ctypes.c_float * 6)]
 
 
 class hvn_inst_rec(ctypes.Structure):

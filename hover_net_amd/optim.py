@@ -15,6 +15,18 @@ import torch
 from . import lib as L
 
 
+def _check(rc):
+    if rc != 0:   # the training entry points report through hvn_train_last_error
+        raise L.HvnError("hvn_adam_step failed (%d): %s" % (rc, L.lib().hvn_train_last_error().decode()))
+
+
+def _bump(params):
+    """The kernel writes the weights through raw pointers, behind torch's version counters; bump them so that anything keyed
+    on `p._version` (HoVerNet._weights_version -> the cached inference plan) sees the update."""
+    for p in params:
+        torch._C._increment_version(p)
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -59,8 +71,9 @@ class FusedAdam(torch.optim.Optimizer):
                     st["v"] = torch.zeros(n + 4, dtype=torch.float32, device=dev)
                 rc = lib.hvn_adam_step(ws + 4 * lo, gs + 4 * lo, st["m"].data_ptr(), st["v"].data_ptr(), n, group["lr"], b1, b2,
                                        group["eps"], st["step"], stream)
-                L.check(rc, "hvn_adam_step")
+                _check(rc)
                 self.fused_launches += 1
+                _bump(group["params"])
                 continue
             for p in group["params"]:
                 if p.grad is None:
@@ -72,6 +85,7 @@ class FusedAdam(torch.optim.Optimizer):
                     ps["m"], ps["v"] = torch.zeros_like(p.data), torch.zeros_like(p.data)
                 rc = lib.hvn_adam_step(p.data_ptr(), p.grad.data_ptr(), ps["m"].data_ptr(), ps["v"].data_ptr(), p.numel(), group["lr"], b1, b2,
                                        group["eps"], st["step"], stream)
-                L.check(rc, "hvn_adam_step")
+                _check(rc)
                 self.fallback_launches += 1
+                _bump([p])
         return loss

@@ -54,7 +54,7 @@ def train_step(batch_data, run_info):
     `{"EMA": {loss_<branch>_<term>, overall_loss}, "raw": {img, np: (true, pred), hv: (true, pred)}}`.
 
     What runs: forward in train() mode (batch-statistics BatchNorm, running stats updated), the reference's loss
-    set (opt.py:47-51: np bce+dice, hv mse+msge, tp bce+dice, weights 1 -- other weightings are rejected), backward
+    set (np bce+dice, hv mse+msge, tp bce+dice) with the weights of `extra_info["loss"]` (opt.py:47-51), backward
     and `optimizer.step()`, all on the HIP path (hover_net_amd.train_engine).  Multi-GPU is one process per GPU:
     when torch.distributed is initialised the loss partial sums and the flat gradient slab are SUM-all-reduced
     (RCCL), which reproduces the reference's single-process DataParallel step over the concatenated batch
@@ -66,15 +66,12 @@ def train_step(batch_data, run_info):
     optimizer = run_info["net"]["optimizer"]
     net = _unwrap(model)
     loss_opts = run_info["net"].get("extra_info", {}).get("loss")
-    want = {"np": {"bce": 1, "dice": 1}, "hv": {"mse": 1, "msge": 1}}
-    if net.nr_types is not None:
-        want["tp"] = {"bce": 1, "dice": 1}
-    if loss_opts is not None and {k: dict(v) for k, v in loss_opts.items() if k in want} != want:
-        raise NotImplementedError("hover_net_amd: the fused loss kernel implements the reference configuration "
-                                  "(opt.py:47-51, all weights 1); got %r" % (loss_opts,))
+    if loss_opts is not None:       # the branches the network does not have are ignored, like run_desc.py:66 (`for branch_name in pred_dict`)
+        loss_opts = {k: dict(v) for k, v in loss_opts.items() if k in ("np", "hv") or (k == "tp" and net.nr_types is not None)}
     imgs = batch_data["img"]
     eng = train_engine.engine_for(net, imgs.shape[0])
     net.train()
+    eng.set_loss_weights(loss_opts)
     eng.load_batch(batch_data)
     eng.forward()
     dist = _dist()

@@ -10,9 +10,12 @@ Deliberately not rebuilt (host glue that never touches the GPU path)
 callbacks, visualisation, the file-list dataset and its imgaug augmentation pipeline -- any iterable of the
 reference loader's batch dicts is accepted instead (`SyntheticLoader` provides seeded synthetic ones).
 
-Multi-GPU: one process per GPU (`torchrun --nproc-per-node N`); `run_desc.train_step` all-reduces the loss sums
-and the flat gradient slab over RCCL, every rank steps its own optimizer on identical gradients, so the weights
-stay bit-identical across ranks without a broadcast.  Each rank reads its own shard of the loader.
+Multi-GPU: one process per GPU (`torchrun --nproc-per-node N`, device = LOCAL_RANK); at the start of every phase rank 0's
+parameters and buffers are BROADCAST to all ranks (each process draws its own random init, and the reference runs one
+process), `run_desc.train_step` then all-reduces the loss sums and the flat gradient slab over RCCL and every rank steps
+its own optimizer on identical gradients, so the weights stay bit-identical across ranks.  Each rank reads its own shard
+of the loader; every rank must see the same number of equally sized batches per epoch (checked; ragged last batches are
+dropped when world > 1, the all-reduce would otherwise dead-lock or mis-scale the loss normalisation).
 """
 import os
 
@@ -25,8 +28,11 @@ from .synth import synth_train_batch
 LOSS_TABLE = {"np": {"bce": 1, "dice": 1}, "hv": {"mse": 1, "msge": 1}, "tp": {"bce": 1, "dice": 1}}   # opt.py:47-51
 
 
-def get_config(nr_type, mode):
-    """Same shape as opt.py:get_config's `phase_list` (the part the data path reads)."""
+def get_config(nr_type, mode, pretrained=None):
+    """Same shape as opt.py:get_config's `phase_list` (the part the data path reads).  `pretrained`: path of the encoder
+    checkpoint phase 0 starts from (opt.py:53 hard-codes "../pretrained/ImageNet-ResNet50-Preact_pytorch.tar"; there is no
+    network here to fetch it, so it is an argument).  Phase 0 freezes the encoder: without a pretrained encoder the decoder
+    would train on a frozen RANDOM encoder, which `run_phases` refuses unless `allow_random_frozen_encoder=True`."""
     def phase(freeze, train_bs, valid_bs, pretrained):
         return {
             "run_info": {"net": {
@@ -39,7 +45,7 @@ def get_config(nr_type, mode):
             "batch_size": {"train": train_bs, "valid": valid_bs},
             "nr_epochs": 50,
         }
-    return {"phase_list": [phase(True, 16, 16, None), phase(False, 4, 8, -1)],
+    return {"phase_list": [phase(True, 16, 16, pretrained), phase(False, 4, 8, -1)],
             "run_engine": {"train": {"run_step": run_desc.train_step}, "valid": {"run_step": run_desc.valid_step}}}
 
 
@@ -67,10 +73,53 @@ def _dist_info():
     return 0, 1
 
 
-def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device="cuda", on_epoch=None):
+def convert_checkpoint_keys(sd):
+    """run_utils/utils.py:convert_pytorch_checkpoint: a checkpoint saved from nn.DataParallel carries 'module.' on every
+    key; strip it (only when ALL keys have it, like the reference)."""
+    keys = list(sd.keys())
+    if keys and all(k.startswith("module.") for k in keys):
+        return {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
+def broadcast_module_state(net, src=0):
+    """Make every rank start a phase from rank `src`'s parameters and buffers (one flat broadcast per dtype)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [p.data for p in net.parameters()] + [b.data for b in net.buffers()]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].reshape(t.shape))
+            off += t.numel()
+
+
+def _same_on_all_ranks(value, what):
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value), -float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if t[0].item() != -t[1].item():
+        raise ValueError("%s differs between ranks (max %g, min %g): every rank must run the same number of equally sized steps"
+                         % (what, t[0].item(), -t[1].item()))
+
+
+def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device=None, on_epoch=None, allow_random_frozen_encoder=False):
     """config: get_config(...); make_loaders(phase_idx, batch_size_dict) -> {"train": iterable, "valid": iterable|None}.
     Returns the per-epoch history [{phase, epoch, lr, train: {EMA means}, valid_steps}] and the final net."""
-    rank, _world = _dist_info()
+    rank, world = _dist_info()
+    if device is None:                      # one process per GPU: the launcher's LOCAL_RANK names it
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cuda"
     history, prev_state, net = [], None, None
     for pi, phase in enumerate(config["phase_list"]):
         info = phase["run_info"]["net"]
@@ -82,20 +131,29 @@ def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device="cuda"
             net.load_state_dict(prev_state, strict=True)
         elif pre is not None:
             sd = torch.load(pre, map_location="cpu")
-            sd = sd["desc"] if "desc" in sd else sd
+            sd = convert_checkpoint_keys(sd["desc"] if "desc" in sd else sd)
             missing, unexpected = net.load_state_dict(sd, strict=False)    # ImageNet encoder: decoder keys are missing
             if unexpected:
                 raise KeyError("unexpected keys in %s: %s" % (pre, unexpected[:4]))
+        elif getattr(net, "freeze", False) and not allow_random_frozen_encoder:
+            raise ValueError("phase %d freezes the encoder but has no pretrained checkpoint (get_config(..., pretrained=PATH)): "
+                             "it would train the decoder on a frozen random encoder; pass allow_random_frozen_encoder=True "
+                             "to do that on purpose (synthetic benchmarks)" % pi)
         net = net.to(device)
+        broadcast_module_state(net)         # before the TrainEngine re-points the parameters at its slab
         opt_cls, opt_args = info["optimizer"]
         optimizer = opt_cls(net.parameters(), **opt_args)
         scheduler = info["lr_scheduler"](optimizer)
         run_info = [{"net": {"desc": net, "optimizer": optimizer, "lr_scheduler": scheduler, "extra_info": info["extra_info"]}},
                     {"epoch": 0, "step": 0}]
         loaders = make_loaders(pi, phase["batch_size"])
+        if hasattr(loaders["train"], "__len__"):
+            _same_on_all_ranks(len(loaders["train"]), "phase %d: number of training batches per epoch" % pi)
         for epoch in range(nr_epochs if nr_epochs is not None else phase["nr_epochs"]):
             ema, steps = {}, 0
             for batch in loaders["train"]:
+                if world > 1 and int(batch["img"].shape[0]) != int(phase["batch_size"]["train"]):
+                    continue                                         # drop_last: a ragged batch would mis-scale the all-reduced loss
                 out = run_desc.train_step(batch, run_info)
                 for k, v in out["EMA"].items():                     # ScalarMovingAverage(alpha=0.95), run_utils/callbacks/base.py
                     ema[k] = v if k not in ema else 0.95 * ema[k] + 0.05 * v
@@ -114,7 +172,9 @@ def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device="cuda"
             if log_dir is not None and rank == 0:                    # PeriodicSaver: {"desc": state_dict}
                 os.makedirs(os.path.join(log_dir, "%02d" % pi), exist_ok=True)
                 sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
-                torch.save({"desc": sd, "epoch": epoch}, os.path.join(log_dir, "%02d" % pi, "net_epoch=%d.tar" % (epoch + 1)))
+                # run_utils/callbacks/base.py:PeriodicSaver: {"desc", "optimizer", "lr_scheduler"} state_dicts per net
+                torch.save({"desc": sd, "optimizer": optimizer.state_dict(), "lr_scheduler": scheduler.state_dict(), "epoch": epoch},
+                           os.path.join(log_dir, "%02d" % pi, "net_epoch=%d.tar" % (epoch + 1)))
             if on_epoch is not None:
                 on_epoch(rec)
         prev_state = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}

@@ -376,7 +376,24 @@ class TrainEngine:
         d.sums, d.sobel_ws = self.sums.data_ptr(), self.sobel_ws.data_ptr()
         d.n, d.h, d.w = self.n, self.true_np.shape[1], self.true_np.shape[2]
         d.nr_types = self.net.nr_types or 0
+        for i in range(6):
+            d.weight[i] = 1.0
         return d
+
+    _WEIGHT_SLOT = {("np", "bce"): 0, ("np", "dice"): 1, ("hv", "mse"): 2, ("hv", "msge"): 3, ("tp", "bce"): 4, ("tp", "dice"): 5}
+
+    def set_loss_weights(self, loss_opts):
+        """loss_opts: the `extra_info["loss"]` table of the reference's config (opt.py:47-51), {branch: {term: weight}}; a
+        term that is absent has weight 0 (run_desc.py:66-82 only visits the listed terms).  None = all ones."""
+        w = [1.0] * 6 if loss_opts is None else [0.0] * 6
+        for br, terms in (loss_opts or {}).items():
+            for term, val in terms.items():
+                if (br, term) not in self._WEIGHT_SLOT:
+                    raise KeyError("unknown loss term %s/%s (the reference's loss_func_dict has bce, dice, mse, msge)" % (br, term))
+                w[self._WEIGHT_SLOT[(br, term)]] = float(val)
+        for i in range(6):
+            self._loss.weight[i] = w[i]
+        self._weights = w
 
     # -- one step ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -477,7 +494,14 @@ class TrainEngine:
         t["loss_np_dice"] = dice(8, 10, 12, 2)
         t["loss_hv_mse"] = float(s[2] / (2.0 * m))
         t["loss_hv_msge"] = float(s[3] / (s[4] + 1.0e-8))
-        t["overall_loss"] = float(sum(t.values()))
+        # run_desc.py:80-82: the tracked terms are unweighted, the overall loss is their weighted sum
+        w = getattr(self, "_weights", [1.0] * 6)
+        names = ("loss_np_bce", "loss_np_dice", "loss_hv_mse", "loss_hv_msge", "loss_tp_bce", "loss_tp_dice")
+        overall = sum(w[i] * t[k] for i, k in enumerate(names) if k in t)
+        for i, k in enumerate(names):
+            if k in t and w[i] == 0.0:
+                del t[k]                 # a term that is not in the table is neither computed nor tracked by the reference
+        t["overall_loss"] = float(overall)
         return t
 
 

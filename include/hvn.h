@@ -200,6 +200,10 @@ typedef struct hvn_loss {
     float *sobel_ws;
     int32_t n, h, w, nr_types;   /* nr_types = 0: no tp branch */
     double total_pixels;
+    /* loss weights of run_desc.py:66-82 (`loss += loss_weight * term_loss`, table opt.py:47-51): np bce, np dice, hv mse,
+     * hv msge, tp bce, tp dice; 0 = term absent from the table.  They scale the logit gradients (hvn_loss_backward); the
+     * partial sums of hvn_loss_forward are the unweighted terms, which is what the reference tracks per term. */
+    float weight[6];
 } hvn_loss;
 HVN_API int hvn_loss_forward(const hvn_loss *l, void *stream);
 HVN_API int hvn_loss_backward(const hvn_loss *l, void *stream);

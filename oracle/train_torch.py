@@ -131,10 +131,11 @@ def msge_loss(true, pred, focus):
 LOSS_OPTS = {"np": ("bce", "dice"), "hv": ("mse", "msge"), "tp": ("bce", "dice")}       # opt.py:47-51, weights 1
 
 
-def loss_terms(logits, batch, nr_types, dtype=torch.float32):
+def loss_terms(logits, batch, nr_types, dtype=torch.float32, loss_opts=None):
     """logits: dict of NCHW tensors; batch: dict of tensors (np_map int64, hv_map float32, tp_map int64).
     -> (total loss, dict of named terms) exactly as run_desc.py:40-82 composes them.  dtype=float64 gives the
-    high-precision reference used to measure the fp32 noise floor of the gradients."""
+    high-precision reference used to measure the fp32 noise floor of the gradients.  loss_opts: the config's
+    {branch: {term: weight}} table (opt.py:47-51), default all ones: `loss += weight * term`, terms tracked unweighted."""
     true_np = batch["np_map"].type(torch.int64)
     onehot_np = F.one_hot(true_np, 2).type(dtype)
     true = {"np": onehot_np, "hv": batch["hv_map"].type(dtype)}
@@ -147,11 +148,12 @@ def loss_terms(logits, batch, nr_types, dtype=torch.float32):
     fn = {"bce": xentropy_loss, "dice": dice_loss, "mse": mse_loss, "msge": msge_loss}
     total, terms = 0, {}
     for b in pred:
-        for name in LOSS_OPTS[b]:
+        table = {name: 1 for name in LOSS_OPTS[b]} if loss_opts is None else loss_opts[b]
+        for name, weight in table.items():
             args = [true[b], pred[b]] + ([onehot_np[..., 1]] if name == "msge" else [])
             t = fn[name](*args)
             terms["loss_%s_%s" % (b, name)] = t
-            total = total + t
+            total = total + weight * t
     return total, terms
 
 

@@ -297,8 +297,11 @@ def test_upadd_head_conv0_backward():
         close(zb, F.conv2d(xp, w0).permute(0, 2, 3, 1), 1e-4, "conv0 forward (no relu)")
 
 
-@pytest.mark.parametrize("nt", [None, 5])
-def test_losses_and_logit_gradients(nt):
+_WEIGHTED = {"np": {"bce": 2.0, "dice": 0.5}, "hv": {"mse": 1.5, "msge": 0.25}, "tp": {"dice": 3.0}}     # tp bce absent = weight 0
+
+
+@pytest.mark.parametrize("nt,loss_opts", [(None, None), (5, None), (5, _WEIGHTED), (None, {"np": {"bce": 0.3}, "hv": {"msge": 2.0}})])
+def test_losses_and_logit_gradients(nt, loss_opts):
     from hover_net_amd import lib as L
     from hover_net_amd.synth import synth_train_batch
     from oracle import train_torch
@@ -310,7 +313,8 @@ def test_losses_and_logit_gradients(nt):
         logits = {"tp": torch.randn(n, nt, h, h, generator=g) * 2, **logits}
     logits["np"][0, :, :4, :4] = torch.tensor([40.0, -40.0]).view(2, 1, 1)    # saturated pixels: the clamp gates the bce gradient
     lg = {k: v.clone().requires_grad_(True) for k, v in logits.items()}
-    total, terms = train_torch.loss_terms(lg, {k: torch.as_tensor(v) for k, v in batch.items()}, nt)
+    opts = None if loss_opts is None else {k: v for k, v in loss_opts.items() if k != "tp" or nt}
+    total, terms = train_torch.loss_terms(lg, {k: torch.as_tensor(v) for k, v in batch.items()}, nt, loss_opts=opts)
     total.backward()
     dev = {k: v.cuda() for k, v in logits.items()}
     grads = {k: torch.zeros_like(v) for k, v in dev.items()}
@@ -326,6 +330,9 @@ def test_losses_and_logit_gradients(nt):
     d.true_np, d.true_hv, d.sums, d.sobel_ws = t_np.data_ptr(), t_hv.data_ptr(), sums.data_ptr(), ws.data_ptr()
     d.n, d.h, d.w, d.nr_types = n, h, h, nt or 0
     d.total_pixels = float(n * h * h)
+    slot = {("np", "bce"): 0, ("np", "dice"): 1, ("hv", "mse"): 2, ("hv", "msge"): 3, ("tp", "bce"): 4, ("tp", "dice"): 5}
+    for (br, term), i in slot.items():       # hvn.h: weight[6] = the table of opt.py:47-51, 0 = term absent
+        d.weight[i] = 1.0 if opts is None else float(opts.get(br, {}).get(term, 0.0))
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert L.lib().hvn_loss_forward(ctypes.byref(d), s) == 0, L.lib().hvn_train_last_error()
     assert L.lib().hvn_loss_backward(ctypes.byref(d), s) == 0, L.lib().hvn_train_last_error()
@@ -337,10 +344,12 @@ def test_losses_and_logit_gradients(nt):
     if nt:
         got["loss_tp_bce"] = sm[1] / m
         got["loss_tp_dice"] = sum(1 - (2 * sm[16 + c] + 1e-3) / (sm[32 + c] + sm[48 + c] + 1e-3) for c in range(nt))
-    for k, v in got.items():
-        assert abs(v - float(terms[k])) <= 2e-5 * max(1.0, abs(float(terms[k]))), (k, v, float(terms[k]))
+    for k, v in got.items():          # the sums are the unweighted terms; the oracle only lists the terms of the table
+        if k in terms:
+            assert abs(v - float(terms[k])) <= 2e-5 * max(1.0, abs(float(terms[k]))), (k, v, float(terms[k]))
     for k in logits:
-        close(grads[k], lg[k].grad, 2e-4, "dlogits " + k)
+        want = lg[k].grad if lg[k].grad is not None else torch.zeros_like(lg[k])
+        close(grads[k], want, 2e-4, "dlogits " + k)
 
 
 def test_adam_matches_torch():
