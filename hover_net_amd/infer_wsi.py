@@ -21,6 +21,8 @@ Different by design:
   * the slide backend is any object with `.shape` and `.read_region((x, y), (w, h))`
     (`ArraySlide` wraps a numpy array / memmap; OpenSlide is not required).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -112,6 +114,27 @@ class ArraySlide:
     def thumbnail(self, scale=32):
         """Sub-sampled view (40x -> 1.25x for scale 32), the input of the tissue-mask heuristic."""
         return np.asarray(self.array[::scale, ::scale, :3])
+
+
+class TiledSlide:
+    """Synthetic slide: one uint8 [h,w,3] texture repeated over a virtual H x W extent; `read_region` composes the request
+    from the texture by modular indexing, so a 40 000^2 slide (4.8 GB as an array) costs nothing until it is read."""
+
+    def __init__(self, tile, shape):
+        self.tile = np.ascontiguousarray(tile[..., :3])
+        self.shape = (int(shape[0]), int(shape[1]), 3)
+
+    def read_region(self, coords, size):
+        x, y = int(coords[0]), int(coords[1])
+        w, h = int(size[0]), int(size[1])
+        th, tw = self.tile.shape[:2]
+        rows = (np.arange(y, min(y + h, self.shape[0])) % th)
+        cols = (np.arange(x, min(x + w, self.shape[1])) % tw)
+        return self.tile[rows][:, cols]
+
+    def thumbnail(self, scale=32):
+        th, tw = self.tile.shape[:2]
+        return self.tile[(np.arange(0, self.shape[0], scale) % th)][:, (np.arange(0, self.shape[1], scale) % tw)]
 
 
 def remove_inst(inst_map, ids):
@@ -234,10 +257,22 @@ class WsiInference:
             if i % world != rank:
                 continue
             tl, br = tiles[i][0], tiles[i][1]
+            tm = getattr(self, "timing", None)
+            t0 = time.perf_counter()
             tile = pred_map[tl[0]:br[0], tl[1]:br[1]].contiguous().unsqueeze(0)
             inst, rec, _ = post_proc.process_batch_device(tile, self.nr_types, True)
+            if tm is not None:
+                torch.cuda.synchronize(self.device)
+                t1 = time.perf_counter()
             inst_h = inst[0].cpu().numpy()
-            info = post_proc.records_to_dict(rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1), self.nr_types, inst_h)
+            rec_h = rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1)
+            t2 = time.perf_counter()
+            info = post_proc.records_to_dict(rec_h, self.nr_types, inst_h)
+            if tm is not None:
+                t3 = time.perf_counter()
+                tm["gpu_postproc_s"] = tm.get("gpu_postproc_s", 0.0) + (t1 - t0)
+                tm["d2h_s"] = tm.get("d2h_s", 0.0) + (t2 - t1)
+                tm["contours_dict_s"] = tm.get("contours_dict_s", 0.0) + (t3 - t2)
             mine[i] = (inst_h, info)
         if world > 1:
             import torch.distributed as dist
@@ -271,6 +306,10 @@ class WsiInference:
         for phase, tiles in enumerate((grid, boundary, cross)):
             tiles = select_valid(tiles, mask, shape, has_output_info=False)
             cb = merger.normal if phase == 0 else merger.fixing
-            for (inst_h, info), t in zip(self._tile_results(pred_map, tiles), tiles):
+            results = self._tile_results(pred_map, tiles)
+            t0 = time.perf_counter()
+            for (inst_h, info), t in zip(results, tiles):
                 cb(inst_h, info, t[0], t[1])
+            if getattr(self, "timing", None) is not None:
+                self.timing["merge_s"] = self.timing.get("merge_s", 0.0) + (time.perf_counter() - t0)
         return merger.inst_map, merger.inst_info

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--nr-types", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--skip-stage1", action="store_true")
     args = ap.parse_args()
     nt = args.nr_types if args.nr_types > 0 else None
     S = args.size
@@ -40,24 +41,36 @@ def main():
     net = net.to("cuda").eval()
     rng = np.random.default_rng(0)
     tile = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
-    slide = infer_wsi.ArraySlide(np.tile(tile, (S // 512 + 1, S // 512 + 1, 1))[:S, :S])
+    slide = infer_wsi.TiledSlide(tile, (S, S))
     wsi = infer_wsi.WsiInference(net, nr_types=nt, batch_size=args.batch)
     mask = np.ones((S // 32, S // 32), np.uint8)
-    wsi.raw_prediction(infer_wsi.ArraySlide(slide.array[:1024, :1024]), np.ones((32, 32), np.uint8))   # warm-up (plan, arena)
+    wsi.raw_prediction(infer_wsi.TiledSlide(tile, (1024, 1024)), np.ones((32, 32), np.uint8))   # warm-up (plan, arena)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pm = wsi.raw_prediction(slide, mask)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter() - t0
+    t1 = float("nan")
+    if not args.skip_stage1:
+        torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        pm = wsi.raw_prediction(slide, mask)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t0
+        del pm
     _c, pinfo = infer_wsi.get_chunk_patch_info(np.array([S, S]), wsi.chunk_shape, wsi.pin, wsi.pout)
     n_patch = int(pinfo.shape[0])
-    del pm
+    peak1 = torch.cuda.max_memory_allocated() / 2 ** 30
     # stage 2 on a structured map: 512^2 painted blocks tiled over the slide (nuclei at CoNSeP density: 3.8 per 80^2)
-    blk = synth_pred_maps(4, 512, 512, nt, seed=3, k_lo=2, k_hi=6)[0]
+    # (assembled on the device: the 40 000^2 map is 25.6 GB)
+    blk = torch.from_numpy(synth_pred_maps(4, 512, 512, nt, seed=3, k_lo=2, k_hi=6)[0]).to("cuda")
     reps = S // 512 + 1
-    rows = [np.concatenate([blk[(r + c) % 4] for c in range(reps)], 1) for r in range(reps)]
-    full = torch.from_numpy(np.ascontiguousarray(np.concatenate(rows, 0)[:S, :S])).to("cuda")
+    full = torch.empty((S, S, blk.shape[-1]), dtype=torch.float32, device="cuda")
+    for r in range(reps):
+        for c in range(reps):
+            y0, x0 = r * 512, c * 512
+            h, w = min(512, S - y0), min(512, S - x0)
+            if h > 0 and w > 0:
+                full[y0:y0 + h, x0:x0 + w] = blk[(r + c) % 4][:h, :w]
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    wsi.timing = {}
     t0 = time.perf_counter()
     inst_map, info = wsi.stitch_instances(full, mask)
     torch.cuda.synchronize()
@@ -65,7 +78,8 @@ def main():
     grid, boundary, cross = infer_wsi.get_tile_info(np.array([S, S]), wsi.tile_shape, wsi.ambiguous_size)
     print(json.dumps({"slide": [S, S], "mode": args.mode, "dtype": args.dtype, "patches": n_patch, "stage1_s": t1, "patches_per_s": n_patch / t1,
                       "stage2_s": t2, "tiles": [int(grid.shape[0]), int(boundary.shape[0]), int(cross.shape[0])], "instances": len(info),
-                      "mpix_per_s_stage2": S * S / 1e6 / t2}))
+                      "mpix_per_s_stage2": S * S / 1e6 / t2, "stage2_breakdown_s": wsi.timing, "peak_hbm_gib_stage1": peak1,
+                      "peak_hbm_gib_stage2": torch.cuda.max_memory_allocated() / 2 ** 30}))
 
 
 if __name__ == "__main__":
