@@ -13,11 +13,12 @@ Different by design:
   * `pred_map` ([H,W,3|4] float32, 25.6 GB for a 40k x 40k slide) lives in HBM (288 GB per GPU)
     instead of a disk memmap written by a helper process (wsi.py:520-534, 235-258); patch outputs
     are scattered into it with one indexed write per chunk;
-  * patches of a chunk are sharded over the ranks (one process per GPU, `infer_tile.run_sharded`,
-    one all_gather per chunk) instead of `nn.DataParallel`;
+  * chunks are sharded over the ranks (one process per GPU: a chunk is read, cut into patches and predicted by ONE rank;
+    one RCCL all-reduce of the HBM-resident map at the end of stage 1) instead of `nn.DataParallel`;
   * a tile (2048 x 2048 + margins) is post-processed on the GPU (`post_proc.process_batch_device`:
     per-component parallel watershed) instead of a 16-process CPU pool; tiles are dealt round-robin
-    to the ranks, results are exchanged, and every rank applies the merge callbacks in tile order;
+    to the ranks, instance maps / record tables / contours travel to rank 0 as tensors, and rank 0 applies the merge
+    callbacks in tile order;
   * the slide backend is any object with `.shape` and `.read_region((x, y), (w, h))`
     (`ArraySlide` wraps a numpy array / memmap; OpenSlide is not required).
 """
@@ -215,19 +216,30 @@ class WsiInference:
 
     # -- stage 1: raw prediction into the HBM-resident map ----------------------------------------
     def raw_prediction(self, slide, mask):
+        """Chunks are the unit of rank sharding: rank r reads and predicts chunks r, r + world, ... (every patch belongs to the
+        FIRST chunk that selects it, so no patch is computed twice and no chunk is read by two ranks); each rank scatters
+        its patch outputs into its own HBM-resident map and ONE all-reduce (SUM; every pixel is written by exactly one rank,
+        the others contribute 0.0) over RCCL makes the map complete on every rank for stage 2."""
         shape = np.array(slide.shape[:2])
         pred_map = torch.zeros((int(shape[0]), int(shape[1]), self.out_ch), dtype=torch.float32, device=self.device)
         chunk_info, patch_info = get_chunk_patch_info(shape, self.chunk_shape, self.pin, self.pout)
         between = lambda x, a, b: (a <= x) & (x <= b)  # noqa: E731
         h = int(self.pout[0])
         ar = torch.arange(h, device=self.device)
+        dist, rank, world = infer_tile._dist()
+        taken = np.zeros(patch_info.shape[0], bool)
+        self.stage1_patches = 0
         for ci in range(chunk_info.shape[0]):
             chunk = chunk_info[ci]
             start, end = chunk[0, 0], chunk[0, 1] - self.pin
-            sel = between(patch_info[:, 0, 0, 0], start[0], end[0]) & between(patch_info[:, 0, 0, 1], start[1], end[1])
+            sel = between(patch_info[:, 0, 0, 0], start[0], end[0]) & between(patch_info[:, 0, 0, 1], start[1], end[1]) & ~taken
+            taken |= sel
+            if ci % world != rank:
+                continue
             plist = select_valid(np.array(patch_info[sel]), mask, shape)
             if plist.shape[0] == 0:
                 continue
+            self.stage1_patches += int(plist.shape[0])
             region = slide.read_region(chunk[0][0][::-1], (chunk[0][1] - chunk[0][0])[::-1])
             rel = plist[:, 0, 0] - chunk[0, 0]                    # patch input top-left inside the chunk
             win = int(self.pin[0])
@@ -239,53 +251,132 @@ class WsiInference:
                 del region_dev
             else:
                 patches = torch.from_numpy(np.ascontiguousarray(np.stack([region[y:y + win, x:x + win] for y, x in rel])))
-            out = infer_tile.run_sharded(patches, lambda b: run_desc.infer_step_device(b.to(self.device), self.model), self.batch_size)
+            outs = [self._step(patches[b0:b0 + self.batch_size]).clone() for b0 in range(0, patches.shape[0], self.batch_size)]
+            out = torch.cat(outs, 0)
             # output top-left in the slide = input top-left + diff // 2 (the placement rule of _assemble_and_flush,
             # wsi.py:235-258; patch_info[:, 1] is offset by the FULL diff in the reference and only feeds the mask test)
             otl = torch.from_numpy((plist[:, 0, 0] + (self.pin - self.pout) // 2).astype(np.int64)).to(self.device)
             rows = (otl[:, 0, None] + ar)[:, :, None].expand(-1, h, h)
             cols = (otl[:, 1, None] + ar)[:, None, :].expand(-1, h, h)
-            pred_map[rows, cols] = out                            # one scatter per chunk
+            pred_map[rows, cols] = out.to(pred_map.device)        # one scatter per chunk
+        if world > 1:
+            dist.all_reduce(pred_map, op=dist.ReduceOp.SUM)
         return pred_map
 
-    # -- stage 2: three-phase post-processing ------------------------------------------------------
-    def _tile_results(self, pred_map, tiles):
-        """(pred_inst numpy, inst_info dict) per tile; tiles dealt round-robin to the ranks."""
-        _, rank, world = infer_tile._dist()
-        mine = {}
-        for i in range(tiles.shape[0]):
-            if i % world != rank:
-                continue
-            tl, br = tiles[i][0], tiles[i][1]
-            tm = getattr(self, "timing", None)
-            t0 = time.perf_counter()
-            tile = pred_map[tl[0]:br[0], tl[1]:br[1]].contiguous().unsqueeze(0)
-            inst, rec, _ = post_proc.process_batch_device(tile, self.nr_types, True)
-            if tm is not None:
-                torch.cuda.synchronize(self.device)
-                t1 = time.perf_counter()
-            inst_h = inst[0].cpu().numpy()
-            rec_h = rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1)
-            t2 = time.perf_counter()
-            info = post_proc.records_to_dict(rec_h, self.nr_types, inst_h)
-            if tm is not None:
-                t3 = time.perf_counter()
-                tm["gpu_postproc_s"] = tm.get("gpu_postproc_s", 0.0) + (t1 - t0)
-                tm["d2h_s"] = tm.get("d2h_s", 0.0) + (t2 - t1)
-                tm["contours_dict_s"] = tm.get("contours_dict_s", 0.0) + (t3 - t2)
-            mine[i] = (inst_h, info)
-        if world > 1:
-            import torch.distributed as dist
+    def _step(self, batch):
+        return run_desc.infer_step_device(batch.to(self.device), self.model)
 
-            parts = [None] * world
-            dist.all_gather_object(parts, mine)
-            mine = {k: v for p in parts for k, v in p.items()}
-        return [mine[i] for i in range(tiles.shape[0])]
+    # -- stage 2: three-phase post-processing ------------------------------------------------------
+    def _results_in_order(self, pred_map, tiles):
+        """Yields (tile index, pred_inst numpy, inst_info dict) in tile order on rank 0 (nothing on the other ranks).
+
+        Three overlapped stages per rank: (a) the GPU instance separation + instance table of tile i+1 and its D2H into pinned
+        memory are in flight (`_launch_tile`) while (b) a worker thread traces the contours of tile i on the host cores
+        (C++, multi-threaded, no GIL) and (c) the caller merges tile i-1.  One rank: results are yielded as they complete, so
+        the sequential merge runs under the GPU work of later tiles.  Several ranks: tiles are dealt round-robin, every rank
+        runs the same pipeline over its share, then instance maps / record tables / contour arrays travel to rank 0 as
+        tensors (`infer_tile.gather_items_to_rank0`) and rank 0 assembles the dicts."""
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+
+        _, rank, world = infer_tile._dist()
+        idxs = [i for i in range(tiles.shape[0]) if i % world == rank]
+        tm = getattr(self, "timing", None)
+
+        def host_half(inst_h, rec_h, release):
+            t0 = time.perf_counter()
+            arrs = infer_tile.result_to_arrays(inst_h, rec_h, self.nr_types)
+            t1 = time.perf_counter()
+            out = infer_tile.arrays_to_result(arrs, self.nr_types) if world == 1 else [np.array(a) for a in arrs]
+            release()
+            if tm is not None:
+                tm["contours_s"] = tm.get("contours_s", 0.0) + (t1 - t0)
+                tm["dict_s"] = tm.get("dict_s", 0.0) + (time.perf_counter() - t1)
+            return out
+
+        inflight, futs, mine = collections.deque(), collections.deque(), {}
+        with ThreadPoolExecutor(1) as pool:
+            def drain(block):
+                while futs and (block or futs[0][1].done()):
+                    i, f = futs.popleft()
+                    if world == 1:
+                        yield (i,) + f.result()
+                    else:
+                        mine[i] = f.result()
+
+            def finish():
+                i, wait = inflight.popleft()
+                inst_h, rec_h, release = wait()
+                futs.append((i, pool.submit(host_half, inst_h, rec_h, release)))
+
+            for i in idxs:
+                tl, br = tiles[i][0], tiles[i][1]
+                inflight.append((i, self._launch_tile(pred_map[tl[0]:br[0], tl[1]:br[1]])))
+                if len(inflight) >= 2:
+                    finish()
+                yield from drain(False)
+            while inflight:
+                finish()
+            yield from drain(True)
+        if world > 1:
+            every = infer_tile.gather_items_to_rank0(mine)
+            if every is not None:
+                for i in range(tiles.shape[0]):
+                    yield (i,) + infer_tile.arrays_to_result(every[i], self.nr_types)
+
+    def _launch_tile(self, tile_map):
+        """Start the GPU half of one tile; returns wait() -> (int32 instance map, record table, release) on the host.  CUDA:
+        kernels + D2H into a pinned slot are enqueued and wait() blocks on the slot's event; `release()` frees the slot once
+        the host half is done with the arrays (they alias pinned memory)."""
+        if self.device.type != "cuda":
+            inst_h, rec_h = self._postproc_tile(tile_map)
+            return lambda: (inst_h, rec_h, lambda: None)
+        t0 = time.perf_counter()
+        inst, rec, _ = post_proc.process_batch_device(tile_map.contiguous().unsqueeze(0), self.nr_types, True)
+        slot = self._pinned_slot(inst[0].shape, rec[0].shape)
+        slot["inst"].copy_(inst[0], non_blocking=True)
+        slot["rec"].copy_(rec[0], non_blocking=True)
+        slot["event"].record(torch.cuda.current_stream(self.device))
+        tm = getattr(self, "timing", None)
+
+        def wait():
+            slot["event"].synchronize()
+            if tm is not None:
+                tm["gpu_launch_to_ready_s"] = tm.get("gpu_launch_to_ready_s", 0.0) + (time.perf_counter() - t0)
+            return slot["inst"].numpy(), slot["rec"].numpy().view(post_proc._REC_DTYPE).reshape(-1), slot["free"].set
+
+        return wait
+
+    def _pinned_slot(self, inst_shape, rec_shape):
+        """A free pinned (instance map, record table) pair for this tile shape; four per shape, waiting for the oldest when
+        all are in use (hipHostMalloc is slow, so the slots are kept)."""
+        import threading
+
+        pools = self.__dict__.setdefault("_slots", {})
+        key = (tuple(inst_shape), tuple(rec_shape))
+        ring = pools.setdefault(key, {"slots": [], "next": 0})
+        if len(ring["slots"]) < 4:
+            slot = {"inst": torch.empty(inst_shape, dtype=torch.int32, pin_memory=True),
+                    "rec": torch.empty(rec_shape, dtype=torch.uint8, pin_memory=True),
+                    "event": torch.cuda.Event(), "free": threading.Event()}
+            ring["slots"].append(slot)
+        else:
+            slot = ring["slots"][ring["next"] % 4]
+            ring["next"] += 1
+            slot["free"].wait()
+        slot["free"].clear()
+        return slot
+
+    def _postproc_tile(self, tile_map):
+        """One tile of the prediction map -> (int32 instance map, record table) on the host, synchronously."""
+        inst, rec, _ = post_proc.process_batch_device(tile_map.contiguous().unsqueeze(0), self.nr_types, True)
+        return inst[0].cpu().numpy(), rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1)
 
     def run(self, slide, mask=None):
         """slide: object with .shape / .read_region; mask: uint8 tissue mask at any scale, None = all tissue, "auto" = the
         reference's 1.25x thresholding heuristic (wsi.py:486-500) on `slide.thumbnail(32)`.
-        Returns (inst_map int32 [H,W] numpy, inst_info dict) like `wsi_inst_map` / `wsi_inst_info`."""
+        Returns (inst_map int32 [H,W] numpy, inst_info dict) like `wsi_inst_map` / `wsi_inst_info` on rank 0, (None, None) on
+        the other ranks of a multi-GPU run."""
         shape = np.array(slide.shape[:2])
         if isinstance(mask, str) and mask == "auto":
             from . import tissue_mask
@@ -306,10 +397,12 @@ class WsiInference:
         for phase, tiles in enumerate((grid, boundary, cross)):
             tiles = select_valid(tiles, mask, shape, has_output_info=False)
             cb = merger.normal if phase == 0 else merger.fixing
-            results = self._tile_results(pred_map, tiles)
-            t0 = time.perf_counter()
-            for (inst_h, info), t in zip(results, tiles):
-                cb(inst_h, info, t[0], t[1])
-            if getattr(self, "timing", None) is not None:
-                self.timing["merge_s"] = self.timing.get("merge_s", 0.0) + (time.perf_counter() - t0)
+            # the merge is sequential by definition (wsi.py:569-677) and runs on rank 0, under the GPU work of later tiles
+            for i, inst_h, info in self._results_in_order(pred_map, tiles):
+                t0 = time.perf_counter()
+                cb(inst_h, info, tiles[i][0], tiles[i][1])
+                if getattr(self, "timing", None) is not None:
+                    self.timing["merge_s"] = self.timing.get("merge_s", 0.0) + (time.perf_counter() - t0)
+        if infer_tile._dist()[1] != 0:
+            return None, None
         return merger.inst_map, merger.inst_info

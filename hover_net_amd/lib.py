@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("hvn_conv.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
            "hvn_train_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fvisibility=hidden", "-Wno-unused-value")
+               "-fvisibility=hidden", "-Wno-unused-value", "-pthread")
 
 
 class hvn_view(ctypes.Structure):

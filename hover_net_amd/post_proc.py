@@ -101,29 +101,43 @@ def process_batch_device(pred_dev, nr_types=None, return_centroids=False):
     return inst, None, None
 
 
-def trace_contours(inst_host, rec_host):
-    """Host: outer-border contour of every present label (cv2.findContours ... [0][0] semantics, see
-    csrc/hvn_contour.cpp).  -> dict label -> int32 [K,2] array of (x, y)."""
+def trace_contours_flat(inst_host, rec_host):
+    """Host: contours[0] of every record (cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] semantics, see
+    csrc/hvn_contour.cpp) as flat arrays: (pts int32 [P,2] of (x, y), offs int64 [n_rec + 1]); record i owns
+    pts[offs[i]:offs[i+1]] (empty for absent labels).  The flat form is what travels between ranks."""
     inst_host = np.ascontiguousarray(inst_host, np.int32)
     rec_host = np.ascontiguousarray(rec_host)
     h, w = inst_host.shape
     n = rec_host.shape[0]
-    max_pts = 4 * int((inst_host > 0).sum()) + 8 * n + 16
+    # a border pixel is visited at most 4 times (once per 4-neighbour side that faces the background)
+    max_pts = 4 * int(rec_host["area"].sum()) + 8 * n + 16
     pts = np.empty((max_pts, 2), np.int32)
     offs = np.empty(n + 1, np.int64)
     tot = L.lib().hvn_trace_contours(inst_host.ctypes.data, h, w, rec_host.ctypes.data, n, pts.ctypes.data, max_pts, offs.ctypes.data)
     if tot < 0:
         raise L.HvnError("hvn_trace_contours failed (%d)" % tot)
-    return {int(rec_host["label"][i]): pts[offs[i]:offs[i + 1]].copy() for i in range(n) if rec_host["area"][i] > 0}
+    return pts[:tot].copy(), offs
 
 
-def records_to_dict(rec_host, nr_types, inst_host=None):
+def trace_contours(inst_host, rec_host):
+    """-> dict label -> int32 [K,2] array of (x, y) (see trace_contours_flat)."""
+    rec_host = np.ascontiguousarray(rec_host)
+    pts, offs = trace_contours_flat(inst_host, rec_host)
+    return {int(rec_host["label"][i]): pts[offs[i]:offs[i + 1]].copy() for i in range(rec_host.shape[0]) if rec_host["area"][i] > 0}
+
+
+def records_to_dict(rec_host, nr_types, inst_host=None, contours_flat=None):
     """One tile's records (numpy structured array) -> the reference's inst_info_dict.  With `inst_host`
-    the contours are traced too and, like the reference (post_proc.py:140-143), instances whose contour
+    the contours are traced too (or taken from `contours_flat` = trace_contours_flat's result, e.g. traced on another
+    rank) and, like the reference (post_proc.py:140-143), instances whose contour
     has fewer than 3 points are left out of the dict (they stay in the instance map).  The per-instance fields are
     computed for the whole tile at once; only the dict assembly is a python loop (a WSI has ~10^5 instances)."""
     r = rec_host[rec_host["area"] > 0]
-    contours = trace_contours(inst_host, rec_host) if inst_host is not None else None
+    if contours_flat is not None:
+        pts, offs = contours_flat
+        contours = {int(rec_host["label"][i]): pts[offs[i]:offs[i + 1]] for i in np.nonzero(rec_host["area"] > 0)[0]}
+    else:
+        contours = trace_contours(inst_host, rec_host) if inst_host is not None else None
     area = r["area"].astype(np.float64)
     bbox = np.stack([np.stack([r["rmin"], r["cmin"]], -1), np.stack([r["rmax"], r["cmax"]], -1)], 1).astype(np.int64)   # [n,2,2]
     # m10/m00 on the crop, then + offset (post_proc.py:145-152)

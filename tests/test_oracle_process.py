@@ -78,3 +78,25 @@ def test_contours0_is_the_last_top_level_component():
     rec = np.array([(5, len(ys), ys.min(), ys.max() + 1, xs.min(), xs.max() + 1, 0., 0., -1, 0)], dtype=PP._REC_DTYPE)
     got = PP.trace_contours(a, rec)[5]
     assert got.tolist() == want.tolist()
+
+
+def test_threaded_tracer_equals_single_thread(monkeypatch):
+    """hvn_trace_contours splits the record table over host threads (>= 256 records): same flat arrays as one thread."""
+    from scipy import ndimage
+
+    from hover_net_amd import post_proc as PP
+
+    rng = np.random.default_rng(11)
+    a = ndimage.gaussian_filter(rng.normal(size=(400, 500)), 2.0) > 0.15
+    lab, n = ndimage.label(a)
+    assert n > 600
+    inst = lab.astype(np.int32)
+    rec = np.zeros(n + 50, PP._REC_DTYPE)                      # trailing empty slots like a real table
+    for i, sl in enumerate(ndimage.find_objects(lab)):
+        rec[i] = (i + 1, int((lab[sl] == i + 1).sum()), sl[0].start, sl[0].stop, sl[1].start, sl[1].stop, 0., 0., -1, 0)
+    monkeypatch.setenv("HVN_HOST_THREADS", "1")
+    p1, o1 = PP.trace_contours_flat(inst, rec)
+    monkeypatch.setenv("HVN_HOST_THREADS", "7")
+    p7, o7 = PP.trace_contours_flat(inst, rec)
+    assert np.array_equal(o1, o7) and np.array_equal(p1, p7) and o1[-1] > 5 * n
+    assert (np.diff(o1)[n:] == 0).all()
