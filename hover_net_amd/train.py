@@ -1,10 +1,11 @@
 """The training schedule on the HIP path: `get_config` mirrors /root/reference/models/hovernet/opt.py:23-142
 (two phases: decoder-only with the encoder frozen at batch 16/GPU, then all layers at batch 4/GPU carrying the
 weights over, Adam lr 1e-4 betas (0.9, 0.999), StepLR(25), 50 epochs each, the loss table of opt.py:47-51) and
-`run_phases` is the data path of `TrainManager.run_once` / `RunEngine.run` (run_train.py:135-271,
-run_utils/engine.py:132-204): build the net, load the previous phase's weights, step the loader through
-`run_desc.train_step`, step the LR scheduler per epoch, run `valid_step` over the validation loader, write the
-reference-format checkpoint `{"desc": state_dict}` per epoch.
+`run_phases` is `TrainManager.run_once` (run_train.py:135-271) on `hover_net_amd.run_engine` (the RunEngine / Events /
+callback protocol of run_utils/engine.py:132-204): build the net, load the previous phase's weights, wire the train and valid
+engines the way opt.py:96-140 does (ScalarMovingAverage, TrackLr, PeriodicSaver, TriggerEngine("valid"), ScheduleLr;
+AccumulateRawOutput, ProcessAccumulatedRawOutput) and run them; checkpoints are `{"desc", "optimizer", "lr_scheduler"}`
+state_dicts per epoch like the reference's PeriodicSaver.
 
 Deliberately not rebuilt (host glue that never touches the GPU path): tensorboard / JSON logging
 callbacks, visualisation, the file-list dataset and its imgaug augmentation pipeline -- any iterable of the
@@ -22,6 +23,7 @@ import os
 import torch
 
 from . import net_desc, run_desc
+from . import run_engine as RE
 from .optim import FusedAdam
 from .synth import synth_train_batch
 
@@ -63,6 +65,19 @@ class SyntheticLoader:
         for i in range(self.steps):
             b = synth_train_batch(self.batch_size, self.mode, self.nr_types, seed=self.seed + 1000 * (i * self.world + self.rank))
             yield {k: torch.from_numpy(v) for k, v in b.items()}
+
+
+class _DropRagged:
+    """drop_last for a multi-rank run: a batch of another size would mis-scale the all-reduced loss normalisation."""
+
+    def __init__(self, loader, batch_size):
+        self.loader, self.batch_size = loader, batch_size
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        return (b for b in self.loader if int(b["img"].shape[0]) == self.batch_size)
 
 
 def _dist_info():
@@ -114,9 +129,12 @@ def _same_on_all_ranks(value, what):
                          % (what, t[0].item(), -t[1].item()))
 
 
-def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device=None, on_epoch=None, allow_random_frozen_encoder=False):
+def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device=None, on_epoch=None, allow_random_frozen_encoder=False,
+               handlers=None):
     """config: get_config(...); make_loaders(phase_idx, batch_size_dict) -> {"train": iterable, "valid": iterable|None}.
-    Returns the per-epoch history [{phase, epoch, lr, train: {EMA means}, valid_steps}] and the final net."""
+    Returns the per-epoch history [{phase, epoch, lr, train: {EMA means}, valid_steps, valid: {scalars}}] and the final net.
+    `handlers`: extra (event, handler) pairs for the train engine -- any object with the reference's `.run(state, event)`
+    protocol (run_utils/callbacks/*), e.g. its logging callbacks."""
     rank, world = _dist_info()
     if device is None:                      # one process per GPU: the launcher's LOCAL_RANK names it
         device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cuda"
@@ -144,38 +162,48 @@ def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device=None, 
         opt_cls, opt_args = info["optimizer"]
         optimizer = opt_cls(net.parameters(), **opt_args)
         scheduler = info["lr_scheduler"](optimizer)
-        run_info = [{"net": {"desc": net, "optimizer": optimizer, "lr_scheduler": scheduler, "extra_info": info["extra_info"]}},
-                    {"epoch": 0, "step": 0}]
+        run_info = {"net": {"desc": net, "optimizer": optimizer, "lr_scheduler": scheduler, "extra_info": info["extra_info"]}}
         loaders = make_loaders(pi, phase["batch_size"])
         if hasattr(loaders["train"], "__len__"):
             _same_on_all_ranks(len(loaders["train"]), "phase %d: number of training batches per epoch" % pi)
-        for epoch in range(nr_epochs if nr_epochs is not None else phase["nr_epochs"]):
-            ema, steps = {}, 0
-            for batch in loaders["train"]:
-                if world > 1 and int(batch["img"].shape[0]) != int(phase["batch_size"]["train"]):
-                    continue                                         # drop_last: a ragged batch would mis-scale the all-reduced loss
-                out = run_desc.train_step(batch, run_info)
-                for k, v in out["EMA"].items():                     # ScalarMovingAverage(alpha=0.95), run_utils/callbacks/base.py
-                    ema[k] = v if k not in ema else 0.95 * ema[k] + 0.05 * v
-                steps += 1
-                run_info[1]["step"] += 1
-            lr = optimizer.param_groups[0]["lr"]
-            nvalid = 0
-            if loaders.get("valid") is not None:
-                for batch in loaders["valid"]:
-                    run_desc.valid_step(batch, run_info)
-                    nvalid += 1
-            scheduler.step()                                         # ScheduleLr on EPOCH_COMPLETED
-            run_info[1]["epoch"] += 1
-            rec = {"phase": pi, "epoch": epoch, "lr": lr, "steps": steps, "train": dict(ema), "valid_steps": nvalid}
-            history.append(rec)
-            if log_dir is not None and rank == 0:                    # PeriodicSaver: {"desc": state_dict}
-                os.makedirs(os.path.join(log_dir, "%02d" % pi), exist_ok=True)
-                sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
-                # run_utils/callbacks/base.py:PeriodicSaver: {"desc", "optimizer", "lr_scheduler"} state_dicts per net
-                torch.save({"desc": sd, "optimizer": optimizer.state_dict(), "lr_scheduler": scheduler.state_dict(), "epoch": epoch},
-                           os.path.join(log_dir, "%02d" % pi, "net_epoch=%d.tar" % (epoch + 1)))
-            if on_epoch is not None:
-                on_epoch(rec)
+        train_bs = int(phase["batch_size"]["train"])
+        train_loader = _DropRagged(loaders["train"], train_bs) if world > 1 else loaders["train"]
+        # ---- the wiring of opt.py:96-140 on run_engine.RunEngine --------------------------------------------------------------
+        step_fns = config.get("run_engine", {})
+        train_eng = RE.RunEngine("train", train_loader, step_fns.get("train", {}).get("run_step", run_desc.train_step), run_info)
+        valid_eng = None
+        train_eng.add_event_handler(RE.Events.STEP_COMPLETED, RE.ScalarMovingAverage())
+        train_eng.add_event_handler(RE.Events.EPOCH_COMPLETED, RE.TrackLr())
+        if log_dir is not None and rank == 0:
+            os.makedirs(os.path.join(log_dir, "%02d" % pi), exist_ok=True)
+            train_eng.state.logging, train_eng.state.log_dir = True, os.path.join(log_dir, "%02d" % pi)
+            train_eng.add_event_handler(RE.Events.EPOCH_COMPLETED, RE.PeriodicSaver())
+        if loaders.get("valid") is not None:
+            valid_eng = RE.RunEngine("valid", loaders["valid"], step_fns.get("valid", {}).get("run_step", run_desc.valid_step), run_info)
+            valid_eng.add_event_handler(RE.Events.STEP_COMPLETED, RE.AccumulateRawOutput())
+            valid_eng.add_event_handler(RE.Events.EPOCH_COMPLETED, RE.ProcessAccumulatedRawOutput(
+                lambda raw: run_desc.proc_valid_step_output(raw, nr_types=net.nr_types)))
+            trig = RE.TriggerEngine("valid")
+            trig.triggered_engine = valid_eng
+            train_eng.add_event_handler(RE.Events.EPOCH_COMPLETED, trig)
+        for extra in (handlers or ()):                      # e.g. the reference's own logging / visualisation callbacks
+            train_eng.add_event_handler(*extra)
+
+        class _Record(RE.BaseCallbacks):                    # history row per epoch, before ScheduleLr changes the rate
+            def run(_self, state, event):
+                nvalid = 0 if valid_eng is None else valid_eng.state.curr_epoch_step
+                if valid_eng is not None:
+                    valid_eng.state.curr_epoch_step = 0
+                rec = {"phase": pi, "epoch": state.curr_epoch - 1, "lr": optimizer.param_groups[0]["lr"], "steps": state.curr_epoch_step,
+                       "train": {k: v for k, v in state.tracked_step_output["scalar"].items() if not k.startswith("lr-")},
+                       "valid_steps": nvalid, "valid": None if valid_eng is None else valid_eng.state.tracked_step_output.get("scalar")}
+                state.curr_epoch_step = 0
+                history.append(rec)
+                if on_epoch is not None:
+                    on_epoch(rec)
+
+        train_eng.add_event_handler(RE.Events.EPOCH_COMPLETED, _Record())
+        train_eng.add_event_handler(RE.Events.EPOCH_COMPLETED, RE.ScheduleLr())
+        train_eng.run(nr_epochs if nr_epochs is not None else phase["nr_epochs"])
         prev_state = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
     return history, net
