@@ -84,19 +84,6 @@ class Engine:
         self.n_split = int(os.environ.get("HVN_SPLIT", "1")) if n_split is None else int(n_split)
         self.n_lane_streams = int(os.environ.get("HVN_LANES", "0"))  # extra streams for the decoder branches (0: one launch stream)
         self.split_decoder = os.environ.get("HVN_SPLIT_DECODER", "0") != "0"
-        # Depth-first head: the first ops of the plan (conv0, d0, d1 -- the layers whose 64..256-channel tensors at 264^2 /
-        # 132^2 are 71 / 36 MB per sample and make them HBM-bound) run sub-batch by sub-batch, so that a tensor written by one
-        # launch is still in the 256 MB Infinity Cache when the next launch reads it; the rest of the plan runs on the whole
-        # batch (large launches, little wave quantisation).  HVN_DF_UPTO = name prefix of the first op that is NOT depth-first
-        # ("" = off), HVN_DF_BATCH = samples per sub-batch.
-        self.df_upto = os.environ.get("HVN_DF_UPTO", "")
-        self.df_batch = int(os.environ.get("HVN_DF_BATCH", "2"))
-        self._df_end = 0
-        if self.df_upto:
-            for i, op in enumerate(plan.ops):
-                if op.name.startswith(self.df_upto):
-                    self._df_end = i
-                    break
         self._streams = None
         self._upload_params()
         self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32 if dtype == "fp32" else torch.int16,
@@ -306,18 +293,7 @@ class Engine:
         lane_pool = self._streams[split - 1:]
         lanes = getattr(self.plan, "lanes", None)
         enc_end = lanes[0][2] if (lanes and lanes[0][0] == "main" and len(lanes) > 1) else 0
-        if split == 1 and self._df_end and upto is None and n > self.df_batch:
-            o0 = self.ops[0]
-            esz = 1 if o0.x_dtype == 0 else 4
-            for first in range(0, n, self.df_batch):
-                cnt = min(self.df_batch, n - first)
-                ops = self._shifted_ops(first)
-                ops[0].x = o0.x
-                ops[0].x_dtype = o0.x_dtype
-                ops[0].x.base = o0.x.base + esz * first * o0.x.sn
-                L.check(L.lib().hvn_run_plan(ctypes.addressof(ops), self._df_end, cnt, ctypes.c_void_p(main.cuda_stream)), "hvn_run_plan")
-            self._launch(self.ops, n_ops, n, main, lane_pool[:n_lane], start=self._df_end)
-        elif split == 1:
+        if split == 1:
             self._launch(self.ops, n_ops, n, main, lane_pool[:n_lane])
         elif not self.split_decoder and enc_end and upto is None:
             # encoder (large launches, tail-quantised) on `split` sub-batch streams; the decoder's small
