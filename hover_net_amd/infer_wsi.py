@@ -151,9 +151,38 @@ class WsiMerger:
     def __init__(self, proc_shape):
         self.inst_map = np.zeros(tuple(proc_shape), np.int32)
         self.inst_info = {}
+        self._flag = np.zeros(1 << 16, np.uint8)       # scratch lookup table over instance ids, all zero between calls
 
     def _max_id(self):
-        return max(self.inst_info.keys()) if self.inst_info else 0
+        # every new key is `local id + current maximum`, i.e. larger than all keys before it: the dict's insertion order is
+        # ascending, so after any removals its LAST key is still the maximum (the reference takes max() over a million keys
+        # per tile, wsi.py:574/621)
+        return next(reversed(self.inst_info)) if self.inst_info else 0
+
+    def _table(self, size):
+        if self._flag.shape[0] < size:
+            self._flag = np.zeros(max(size, 2 * self._flag.shape[0]), np.uint8)
+        return self._flag
+
+    def _present(self, a):
+        """np.unique(a) for a non-negative id array, by table lookup instead of a sort (a boundary strip is 0.5 Mpix and
+        there are ~1100 of them on a 40 000^2 slide)."""
+        lo, hi = int(a.min()), int(a.max())
+        f = self._table(hi + 1)
+        f[a.ravel()] = 1
+        ids = np.flatnonzero(f[lo:hi + 1]) + lo
+        f[ids] = 0
+        return ids
+
+    def _zero_ids(self, a, ids):
+        """remove_inst: a[isin(a, ids)] = 0 by table lookup."""
+        if len(ids):
+            f = self._table(int(a.max()) + 1)
+            ids = ids[ids < f.shape[0]]
+            f[ids] = 1
+            a[f[a] != 0] = 0
+            f[ids] = 0
+        return a
 
     def normal(self, pred_inst, info, tile_tl, tile_br):
         if len(info) == 0:
@@ -176,18 +205,18 @@ class WsiMerger:
         off = self._max_id()                                     # before any removal (wsi.py:621-624)
         roi = self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]].copy()
         edge = np.concatenate([roi[[0, -1], :].ravel(), roi[:, [0, -1]].ravel()])
-        on_edge = np.unique(edge)[1:]                            # "[1:]  # exclude background" (wsi.py:631, as is)
-        inner = np.unique(roi)[1:]
+        on_edge = np.unique(edge)[1:]                            # "[1:]  # exclude background" (wsi.py:631, as is: drops the smallest)
+        inner = self._present(roi)[1:]
         inner = np.setdiff1d(inner, on_edge, assume_unique=True)
-        roi = remove_inst(roi, inner)                            # old nuclei fully inside the strip are replaced
-        self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = roi
-        for i in inner:
+        roi = self._zero_ids(roi, inner)                         # old nuclei fully inside the strip are replaced
+        for i in inner.tolist():
             self.inst_info.pop(i, None)
         pred_inst = pred_inst.copy()
-        touching = np.unique(pred_inst[roi > 0])                 # new nuclei overlapping the kept (split) ones
-        new_inner = np.setdiff1d(np.unique(pred_inst)[1:], touching, assume_unique=True)
-        pred_inst = remove_inst(pred_inst, touching)
-        for i in new_inner:
+        n_local = int(pred_inst.max()) + 1
+        touching = np.flatnonzero(np.bincount(pred_inst[roi > 0], minlength=n_local))    # new nuclei overlapping the kept (split) ones
+        new_inner = np.setdiff1d(np.flatnonzero(np.bincount(pred_inst.ravel(), minlength=n_local))[1:], touching, assume_unique=True)
+        pred_inst = self._zero_ids(pred_inst, touching)
+        for i in new_inner.tolist():
             if i not in info:                                    # contour had < 3 points (wsi.py:655-657)
                 continue
             e = info[i]
