@@ -632,7 +632,8 @@ __global__ __launch_bounds__(PP_T) void ws_list(PPBuf b)
 
 // Replay one window [y0..y0+bh) x [x0..x0+bw) of tile n; root >= 0 restricts the mask to that component,
 // root < 0 takes the whole blob mask (whole-tile replay).  All 64 lanes stage / write back, lane 0 floods.
-__device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned char *lds, int *s_flag)
+__device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned char *lds, int *s_flag,
+                          int lds_bytes = WS_LDS_BYTES)
 {
     typedef unsigned long long u64;
     const long g0 = (long)n * b.P;
@@ -640,8 +641,8 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     double *val;
     int32_t *out;
     u64 *heap;
-    const bool in_lds = A <= WS_AMAX;
-    const bool inline_val = A <= WS_AMAX16;
+    const bool in_lds = (long)20 * A <= lds_bytes;
+    const bool inline_val = (long)28 * A <= lds_bytes;
     HItem *heap_far = nullptr;
     int cap = 0;
     if (in_lds) {
@@ -721,24 +722,30 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     return any;
 }
 
-__global__ __launch_bounds__(64) void ws_component(PPBuf b)
+// Components are replayed in two launches by window size, because the LDS a workgroup declares sets how many of them a CU
+// holds: `small` windows (<= WS_SMALL_A pixels: a single nucleus or a small clump, the bulk of a tile's components) take
+// 28 KB, so five one-wave workgroups share a CU instead of one with the full 152 KB; the `large` launch (cls 1) takes the rest.
+#define WS_SMALL_A 1024
+#define WS_SMALL_LDS (WS_SMALL_A * 28)
+__global__ __launch_bounds__(64) void ws_component(PPBuf b, int cls, int lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
     __shared__ int s_flag;
     const int n = blockIdx.y;
     const long g0 = (long)n * b.P;
     const int ncomp = b.stat[n].n_comp;
-    // a tile dominated by one blob gains nothing from the per-component split: replay it whole, here,
-    // concurrently with the other tiles' components (and exactly, so no tie bookkeeping is needed)
-    if (2L * b.stat[n].max_area > b.P) {
-        if (blockIdx.x == 0 && ncomp > 0) ws_window(b, n, -1, 0, 0, b.H, b.W, ws_lds, &s_flag);
+    // a tile that IS one blob gains nothing from the per-component split: replay it whole (exactly, so no tie bookkeeping)
+    if (ncomp == 1 && 2L * b.stat[n].max_area > b.P) {
+        if (cls == 1 && blockIdx.x == 0) ws_window(b, n, -1, 0, 0, b.H, b.W, ws_lds, &s_flag, lds_bytes);
         return;
     }
     for (int k = blockIdx.x; k < ncomp; k += gridDim.x) {
         const int root = b.par[g0 + k];
         const int y0 = b.par2[g0 + root], y1 = ((const int32_t *)b.hraw)[g0 + root];
         const int x0 = ((const int32_t *)b.vraw)[g0 + root], x1 = b.cnt[g0 + root];
-        if (ws_window(b, n, root, y0, x0, y1 - y0 + 1, x1 - x0 + 1, ws_lds, &s_flag) && threadIdx.x == 0) b.stat[n].tie = 1;
+        const int bh = y1 - y0 + 1, bw = x1 - x0 + 1;
+        if (((long)bh * bw <= WS_SMALL_A ? 0 : 1) != cls) continue;   // uniform per workgroup
+        if (ws_window(b, n, root, y0, x0, bh, bw, ws_lds, &s_flag, lds_bytes) && threadIdx.x == 0) b.stat[n].tie = 1;
     }
 }
 
@@ -858,7 +865,10 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
             return HVN_E_LAUNCH;
         ws_attr = true;
     }
-    if (!ws_mode) hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_LDS_BYTES, s, b);
+    if (!ws_mode) {
+        hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_SMALL_LDS, s, b, 0, WS_SMALL_LDS);
+        hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_LDS_BYTES, s, b, 1, WS_LDS_BYTES);
+    }
     hipLaunchKernelGGL(ws_fallback, dim3(n), dim3(64), WS_LDS_BYTES, s, b, ws_mode);
     const size_t NP = (size_t)n * b.P;
     if (tap_blb) hipMemcpyAsync(tap_blb, b.blb, NP * 4, hipMemcpyDeviceToDevice, s);
