@@ -243,14 +243,14 @@ def result_to_arrays(inst_h, rec_h, nr_types):
     return [np.ascontiguousarray(inst_h, np.int32), rec_h.view(np.uint8).reshape(rec_h.shape[0], rec_h.dtype.itemsize), pts, offs]
 
 
-def arrays_to_result(arrs, nr_types, with_info=True):
+def arrays_to_result(arrs, nr_types, with_info=True, shift_xy=None):
     from . import post_proc
 
     inst_h, rec_b, pts, offs = arrs
     if not with_info:
         return np.array(inst_h), None
     rec_h = np.ascontiguousarray(rec_b).view(post_proc._REC_DTYPE).reshape(-1)
-    return np.array(inst_h), post_proc.records_to_dict(rec_h, nr_types, contours_flat=(np.array(pts), np.array(offs)))
+    return np.array(inst_h), post_proc.records_to_dict(rec_h, nr_types, contours_flat=(np.array(pts), np.array(offs)), shift_xy=shift_xy)
 
 
 def run_sharded(items, step_fn, batch_size):

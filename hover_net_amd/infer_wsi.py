@@ -184,21 +184,23 @@ class WsiMerger:
             f[ids] = 0
         return a
 
-    def normal(self, pred_inst, info, tile_tl, tile_br):
+    def normal(self, pred_inst, info, tile_tl, tile_br, shifted=False):
+        """shifted=True: the entries of `info` already carry the tile origin (post_proc.records_to_dict(shift_xy=...))."""
         if len(info) == 0:
             return
         top_left = np.asarray(tile_tl)[::-1]
         off = self._max_id()
         for i, e in info.items():
-            e["bbox"] = e["bbox"] + top_left        # (sic) the reference adds (x, y) to the (row, col) box
-            e["contour"] = e["contour"] + top_left
-            e["centroid"] = e["centroid"] + top_left
+            if not shifted:
+                e["bbox"] = e["bbox"] + top_left        # (sic) the reference adds (x, y) to the (row, col) box
+                e["contour"] = e["contour"] + top_left
+                e["centroid"] = e["centroid"] + top_left
             self.inst_info[i + off] = e
         pred_inst = pred_inst.copy()
         pred_inst[pred_inst > 0] += off
         self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = pred_inst
 
-    def fixing(self, pred_inst, info, tile_tl, tile_br):
+    def fixing(self, pred_inst, info, tile_tl, tile_br, shifted=False):
         if len(info) == 0:
             return
         top_left = np.asarray(tile_tl)[::-1]
@@ -220,9 +222,10 @@ class WsiMerger:
             if i not in info:                                    # contour had < 3 points (wsi.py:655-657)
                 continue
             e = info[i]
-            e["bbox"] = e["bbox"] + top_left
-            e["contour"] = e["contour"] + top_left
-            e["centroid"] = e["centroid"] + top_left
+            if not shifted:
+                e["bbox"] = e["bbox"] + top_left
+                e["contour"] = e["contour"] + top_left
+                e["centroid"] = e["centroid"] + top_left
             self.inst_info[i + off] = e
         pred_inst[pred_inst > 0] += off
         self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = roi + pred_inst
@@ -297,7 +300,8 @@ class WsiInference:
 
     # -- stage 2: three-phase post-processing ------------------------------------------------------
     def _results_in_order(self, pred_map, tiles):
-        """Yields (tile index, pred_inst numpy, inst_info dict) in tile order on rank 0 (nothing on the other ranks).
+        """Yields (tile index, pred_inst numpy, inst_info dict with the tile origin already added) in tile order on rank 0
+        (nothing on the other ranks).
 
         Three overlapped stages per rank: (a) the GPU instance separation + instance table of tile i+1 and its D2H into pinned
         memory are in flight (`_launch_tile`) while (b) a worker thread traces the contours of tile i on the host cores
@@ -312,11 +316,14 @@ class WsiInference:
         idxs = [i for i in range(tiles.shape[0]) if i % world == rank]
         tm = getattr(self, "timing", None)
 
-        def host_half(inst_h, rec_h, release):
+        def shift_of(i):
+            return (int(tiles[i][0][1]), int(tiles[i][0][0]))      # tile origin as (x, y)
+
+        def host_half(i, inst_h, rec_h, release):
             t0 = time.perf_counter()
             arrs = infer_tile.result_to_arrays(inst_h, rec_h, self.nr_types)
             t1 = time.perf_counter()
-            out = infer_tile.arrays_to_result(arrs, self.nr_types) if world == 1 else [np.array(a) for a in arrs]
+            out = infer_tile.arrays_to_result(arrs, self.nr_types, shift_xy=shift_of(i)) if world == 1 else [np.array(a) for a in arrs]
             release()
             if tm is not None:
                 tm["contours_s"] = tm.get("contours_s", 0.0) + (t1 - t0)
@@ -336,7 +343,7 @@ class WsiInference:
             def finish():
                 i, wait = inflight.popleft()
                 inst_h, rec_h, release = wait()
-                futs.append((i, pool.submit(host_half, inst_h, rec_h, release)))
+                futs.append((i, pool.submit(host_half, i, inst_h, rec_h, release)))
 
             for i in idxs:
                 tl, br = tiles[i][0], tiles[i][1]
@@ -351,7 +358,7 @@ class WsiInference:
             every = infer_tile.gather_items_to_rank0(mine)
             if every is not None:
                 for i in range(tiles.shape[0]):
-                    yield (i,) + infer_tile.arrays_to_result(every[i], self.nr_types)
+                    yield (i,) + infer_tile.arrays_to_result(every[i], self.nr_types, shift_xy=shift_of(i))
 
     def _launch_tile(self, tile_map):
         """Start the GPU half of one tile; returns wait() -> (int32 instance map, record table, release) on the host.  CUDA:
@@ -429,7 +436,7 @@ class WsiInference:
             # the merge is sequential by definition (wsi.py:569-677) and runs on rank 0, under the GPU work of later tiles
             for i, inst_h, info in self._results_in_order(pred_map, tiles):
                 t0 = time.perf_counter()
-                cb(inst_h, info, tiles[i][0], tiles[i][1])
+                cb(inst_h, info, tiles[i][0], tiles[i][1], shifted=True)
                 if getattr(self, "timing", None) is not None:
                     self.timing["merge_s"] = self.timing.get("merge_s", 0.0) + (time.perf_counter() - t0)
         if infer_tile._dist()[1] != 0:

@@ -26,6 +26,11 @@ class TilePipeline:
         self._free = [None, None]                    # event: the side stream is done reading _buf[k]
         self._n = 0
         self._last = None
+        # host batches (the reference contract: infer_step takes a CPU uint8 tensor) go up on their own copy stream into one of
+        # two device slots, so the H2D of batch i+1 runs under the network of batch i
+        self.h2d = torch.cuda.Stream(self.device)
+        self._in = [None, None]
+        self._in_free = [None, None]                 # event: the network is done reading _in[k]
 
     def submit(self, tiles_u8, extra_maps=None, gather=None, to_host=False):
         """Network on the current stream, post-processing on the side stream.  Returns
@@ -40,7 +45,12 @@ class TilePipeline:
         main = torch.cuda.current_stream(self.device)
         k = self._n & 1
         self._n += 1
+        if not tiles_u8.is_cuda:
+            tiles_u8 = self._upload(tiles_u8, k, main)
         pred = run_desc.infer_step_device(tiles_u8, self.model)       # aliases the engine's buffer
+        if self._in[k] is not None and tiles_u8 is self._in[k]:
+            self._in_free[k] = torch.cuda.Event()
+            self._in_free[k].record(main)
         if self._free[k] is not None:
             main.wait_event(self._free[k])                             # ping-pong slot k is free again
         if self._buf[k] is None or self._buf[k].shape != pred.shape:
@@ -61,6 +71,21 @@ class TilePipeline:
             self._free[k].record(self.side)
         self._last = out
         return out
+
+    def _upload(self, tiles_host, k, main):
+        if tiles_host.dtype != torch.uint8:
+            tiles_host = tiles_host.to(torch.uint8)
+        if self._in[k] is None or self._in[k].shape != tiles_host.shape:
+            self._in[k] = torch.empty(tiles_host.shape, dtype=torch.uint8, device=self.device)
+            self._in_free[k] = None
+        with torch.cuda.stream(self.h2d):
+            if self._in_free[k] is not None:
+                self.h2d.wait_event(self._in_free[k])
+            self._in[k].copy_(tiles_host, non_blocking=True)          # asynchronous when the source is pinned
+            up = torch.cuda.Event()
+            up.record(self.h2d)
+        main.wait_event(up)
+        return self._in[k]
 
     def _run_pp(self, maps):
         inst = self._pp.separate(maps)

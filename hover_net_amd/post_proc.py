@@ -126,15 +126,20 @@ def trace_contours(inst_host, rec_host):
     return {int(rec_host["label"][i]): pts[offs[i]:offs[i + 1]].copy() for i in range(rec_host.shape[0]) if rec_host["area"][i] > 0}
 
 
-def records_to_dict(rec_host, nr_types, inst_host=None, contours_flat=None):
+def records_to_dict(rec_host, nr_types, inst_host=None, contours_flat=None, shift_xy=None):
     """One tile's records (numpy structured array) -> the reference's inst_info_dict.  With `inst_host`
     the contours are traced too (or taken from `contours_flat` = trace_contours_flat's result, e.g. traced on another
     rank) and, like the reference (post_proc.py:140-143), instances whose contour
     has fewer than 3 points are left out of the dict (they stay in the instance map).  The per-instance fields are
-    computed for the whole tile at once; only the dict assembly is a python loop (a WSI has ~10^5 instances)."""
+    computed for the whole tile at once; only the dict assembly is a python loop (a WSI has ~10^6 instances).
+    `shift_xy` = (x0, y0): the tile's origin in the slide, added to bbox, centroid and contour the way the WSI merge
+    callbacks do (wsi.py:580-584: `+ top_left` with top_left = (x, y) on all three, i.e. x is added to the bbox ROWS --
+    the reference's quirk, kept) -- vectorised here instead of three small-array additions per instance there."""
     r = rec_host[rec_host["area"] > 0]
     if contours_flat is not None:
         pts, offs = contours_flat
+        if shift_xy is not None:
+            pts = pts + np.asarray(shift_xy, pts.dtype)
         contours = {int(rec_host["label"][i]): pts[offs[i]:offs[i + 1]] for i in np.nonzero(rec_host["area"] > 0)[0]}
     else:
         contours = trace_contours(inst_host, rec_host) if inst_host is not None else None
@@ -142,6 +147,11 @@ def records_to_dict(rec_host, nr_types, inst_host=None, contours_flat=None):
     bbox = np.stack([np.stack([r["rmin"], r["cmin"]], -1), np.stack([r["rmax"], r["cmax"]], -1)], 1).astype(np.int64)   # [n,2,2]
     # m10/m00 on the crop, then + offset (post_proc.py:145-152)
     cent = np.stack([r["sum_x"] / area + r["cmin"], r["sum_y"] / area + r["rmin"]], -1)
+    if shift_xy is not None:
+        if contours_flat is None:
+            raise ValueError("shift_xy needs contours_flat")
+        bbox = bbox + np.asarray(shift_xy, bbox.dtype)
+        cent = cent + np.asarray(shift_xy, cent.dtype)
     labels = r["label"].tolist()
     types = r["type"].tolist() if nr_types is not None else None
     tprob = (r["type_count"] / (area + 1.0e-6)).tolist() if nr_types is not None else None

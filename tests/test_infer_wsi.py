@@ -68,19 +68,50 @@ def test_three_phase_merge_matches_reference_callbacks():
     me = types.SimpleNamespace(wsi_inst_info={}, wsi_inst_map=np.zeros(tuple(shape), np.int32))
     rns = dict(ns, self=me, pbar=types.SimpleNamespace(update=lambda: None), log_info=lambda *a: None)
     exec(compile(textwrap.dedent(body), REF, "exec"), rns)
-    mine = W.WsiMerger(shape)
+    mine, pre = W.WsiMerger(shape), W.WsiMerger(shape)
     for phase, tiles in enumerate((grid, boundary, cross)):
         for idx, t in enumerate(tiles):
             res = _fake_tile_result(truth, t[0], t[1], np.random.default_rng(100 * phase + idx))
             ref_cb = rns["post_proc_normal_tile_callback"] if phase == 0 else rns["post_proc_fixing_tile_callback"]
             ref_cb((copy.deepcopy(res), (idx, t[0].copy(), t[1].copy())))
             (mine.normal if phase == 0 else mine.fixing)(res[0].copy(), copy.deepcopy(res[1]), t[0], t[1])
+            # the pipelined path hands over entries that already carry the tile origin (added in bulk at dict assembly)
+            shifted = copy.deepcopy(res[1])
+            for e in shifted.values():
+                for f in ("bbox", "centroid", "contour"):
+                    e[f] = e[f] + np.asarray(t[0])[::-1]
+            (pre.normal if phase == 0 else pre.fixing)(res[0].copy(), shifted, t[0], t[1], shifted=True)
         np.testing.assert_array_equal(mine.inst_map, me.wsi_inst_map)
-        assert sorted(mine.inst_info) == sorted(me.wsi_inst_info)
+        np.testing.assert_array_equal(pre.inst_map, me.wsi_inst_map)
+        assert list(mine.inst_info) == sorted(me.wsi_inst_info) == list(pre.inst_info)       # insertion order = ascending ids (O(1) running maximum)
     for k, e in me.wsi_inst_info.items():
         for f in ("bbox", "centroid", "contour"):
             np.testing.assert_array_equal(mine.inst_info[k][f], e[f])
+            np.testing.assert_array_equal(pre.inst_info[k][f], e[f])
     assert len(mine.inst_info) > 50
+
+
+def test_records_to_dict_shift_is_the_merge_offset():
+    """post_proc.records_to_dict(shift_xy=(x0, y0)) == the three per-instance `+ top_left` of wsi.py:580-584, x added to the
+    bbox rows included."""
+    from hover_net_amd import post_proc as PP
+
+    inst = np.zeros((30, 40), np.int32)
+    inst[3:9, 5:12] = 1
+    inst[15:25, 20:33] = 2
+    rec = np.zeros(4, PP._REC_DTYPE)
+    for l in (1, 2):
+        ys, xs = np.nonzero(inst == l)
+        rec[l - 1] = (l, len(ys), ys.min(), ys.max() + 1, xs.min(), xs.max() + 1, float((xs - xs.min()).sum()), float((ys - ys.min()).sum()), -1, 0)
+    flat = PP.trace_contours_flat(inst, rec)
+    plain = PP.records_to_dict(rec, None, contours_flat=flat)
+    moved = PP.records_to_dict(rec, None, contours_flat=flat, shift_xy=(700, 90))
+    tl = np.array([700, 90])
+    for k in plain:
+        np.testing.assert_array_equal(moved[k]["bbox"], plain[k]["bbox"] + tl)
+        np.testing.assert_array_equal(moved[k]["centroid"], plain[k]["centroid"] + tl)
+        np.testing.assert_array_equal(moved[k]["contour"], plain[k]["contour"] + tl)
+        assert moved[k]["contour"].dtype == np.int32
 
 
 def test_geometry_invariants():
