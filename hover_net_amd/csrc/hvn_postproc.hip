@@ -89,6 +89,7 @@ struct PPBuf {
     TileStat *stat;
     // watershed scratch
     unsigned long long *heap;  // 2 x u64 per item, n*P items
+    int no_wave;               // HVN_WS_WAVE=0: every component on the one-lane binary heap (A/B and tests)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -580,6 +581,178 @@ __device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, b
     return ties;
 }
 
+// ---- wave-cooperative replay (windows whose state fits the launch's LDS) --------------------------------------------------------
+// skimage pops the heap item with the smallest (value, age).  Ages are unique (one global counter) except for the initial
+// markers (all age 0), so -- marker ties aside -- WHICH priority queue is used cannot change the result: any structure that
+// always extracts the exact minimum replays the same flood.  A binary heap walked by one lane costs ~8 dependent LDS round
+// trips per pop; here the frontier is an UNSORTED array in LDS and all 64 lanes find its minimum together: every lane scans
+// its slots (one 16-byte read for frontiers up to 64 items), the minimum of the sortable 64-bit value keys is reduced across
+// the wave with DPP row shifts / row broadcasts (no LDS traffic), then the minimum age among the lanes holding that value.
+// Push = append; pop = move the last item into the hole.  The four neighbours of the popped pixel are handled by four lanes at
+// once (ages handed out in skimage's neighbour order by a ballot prefix count); the window carries a one-pixel border of
+// "not in the mask" so no coordinate is ever range-checked.  A marker tie (two age-0 items of equal value at the minimum) has no
+// defined order here: the component reports it and the tile is redone by the exact whole-tile binary-heap replay.
+__device__ inline unsigned long long ws_key(double v)
+{
+    v = v + 0.0;                                     // -0.0 -> +0.0: skimage compares doubles, for which they are equal
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);   // order-preserving map of finite doubles onto unsigned integers
+}
+
+template <int CTRL, int RMASK>
+__device__ inline unsigned long long dpp_min_u64(unsigned long long x)
+{
+    const int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, RMASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, RMASK, 0xf, false);
+    const unsigned long long y = ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2;
+    return y < x ? y : x;
+}
+
+template <int CTRL, int RMASK>
+__device__ inline unsigned dpp_min_u32(unsigned x)
+{
+    const unsigned y = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, RMASK, 0xf, false);
+    return y < x ? y : x;
+}
+
+// minimum over the 64 lanes, returned to every lane: row_shr 1/2/4/8 leave each row's minimum in its lane 15,
+// row_bcast:15 / row_bcast:31 carry it to lane 63
+__device__ inline unsigned long long wave_min_u64(unsigned long long x)
+{
+    x = dpp_min_u64<0x111, 0xf>(x);
+    x = dpp_min_u64<0x112, 0xf>(x);
+    x = dpp_min_u64<0x114, 0xf>(x);
+    x = dpp_min_u64<0x118, 0xf>(x);
+    x = dpp_min_u64<0x142, 0xa>(x);
+    x = dpp_min_u64<0x143, 0xc>(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ inline unsigned wave_min_u32(unsigned x)
+{
+    x = dpp_min_u32<0x111, 0xf>(x);
+    x = dpp_min_u32<0x112, 0xf>(x);
+    x = dpp_min_u32<0x114, 0xf>(x);
+    x = dpp_min_u32<0x118, 0xf>(x);
+    x = dpp_min_u32<0x142, 0xa>(x);
+    x = dpp_min_u32<0x143, 0xc>(x);
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// One component (root >= 0) over its bounding box, all 64 lanes.  LDS: 28 bytes per pixel of the bordered window.
+// Returns true when a marker tie was met (the caller flags the tile for the exact whole-tile replay).
+__device__ bool ws_window_wave(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned char *lds)
+{
+    typedef unsigned long long u64;
+    const int lane = threadIdx.x;
+    const long g0 = (long)n * b.P;
+    const int bw2 = bw + 2, A2 = bw2 * (bh + 2);
+    u64 *kv = (u64 *)lds;                    // [A2] sortable key of every pixel's value
+    u64 *fk = kv + A2;                       // frontier: value key ...
+    unsigned *fa = (unsigned *)(fk + A2);    // ... age ...
+    unsigned *fi = fa + A2;                  // ... window index
+    int *out = (int *)(fi + A2);             // labels: -1 outside the component, 0 unlabelled
+    for (int t = lane; t < A2; t += 64) {
+        const int ry = t / bw2;
+        const int yy = ry - 1, xx = t - ry * bw2 - 1;
+        int o = -1;
+        u64 k = 0;
+        if ((unsigned)yy < (unsigned)bh && (unsigned)xx < (unsigned)bw) {
+            const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
+            if (b.broot[gi] == root) {
+                o = b.mk[gi];
+                k = ws_key(b.blur[gi]);
+            }
+        }
+        out[t] = o;
+        kv[t] = k;
+    }
+    __syncthreads();
+    int nf = 0;
+    for (int base = 0; base < A2; base += 64) {   // the markers, in any order: their keys decide
+        const int i = base + lane;
+        const bool m = i < A2 && out[i] > 0;
+        const u64 mask = __ballot(m);
+        if (m) {
+            const int s = nf + __popcll(mask & ((1ull << lane) - 1ull));
+            fk[s] = kv[i];
+            fa[s] = 0u;
+            fi[s] = (unsigned)i;
+        }
+        nf += __popcll(mask);
+    }
+    __syncthreads();
+    unsigned age = 0;
+    bool tie = false;
+    while (nf > 0) {
+        u64 bk = ~0ull;
+        unsigned ba = 0xffffffffu;
+        int bs = 0, cnt = 0;
+        for (int s = lane; s < nf; s += 64) {
+            const u64 k = fk[s];
+            const unsigned a = fa[s];
+            if (k < bk || (k == bk && a < ba)) {
+                bk = k;
+                ba = a;
+                bs = s;
+                cnt = 1;
+            } else if (k == bk && a == ba)
+                ++cnt;
+        }
+        const u64 gk = wave_min_u64(bk);
+        const unsigned ga = wave_min_u32(bk == gk ? ba : 0xffffffffu);
+        const bool mine = bk == gk && ba == ga && cnt > 0;
+        const u64 win = __ballot(mine);
+        if (ga == 0u && (__popcll(win) > 1 || __any(mine && cnt > 1))) {
+            tie = true;
+            break;
+        }
+        const int wl = __ffsll((long long)win) - 1;
+        const int gs = __builtin_amdgcn_readlane(bs, wl);
+        const int idx = (int)fi[gs];
+        const int lab = out[idx];
+        --nf;
+        if (gs != nf && lane == 0) {   // the last item fills the hole
+            fk[gs] = fk[nf];
+            fa[gs] = fa[nf];
+            fi[gs] = fi[nf];
+        }
+        bool unl = false;
+        int q = 0;
+        if (lane < 4) {                // skimage's neighbour order: up, left, right, down
+            q = idx + (lane == 0 ? -bw2 : lane == 1 ? -1 : lane == 2 ? 1 : bw2);
+            unl = out[q] == 0;
+        }
+        const u64 um = __ballot(unl);
+        if (unl) {
+            const int r = __popcll(um & ((1ull << lane) - 1ull));
+            out[q] = lab;              // labelled at push time
+            const int s = nf + r;
+            fk[s] = kv[q];
+            fa[s] = age + 1u + (unsigned)r;
+            fi[s] = (unsigned)q;
+        }
+        const int np = __popcll(um);
+        age += (unsigned)np;
+        nf += np;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (!tie)
+        for (int t = lane; t < A2; t += 64) {
+            const int v = out[t];
+            if (v >= 0) {
+                const int ry = t / bw2;
+                b.inst[g0 + (long)(y0 + ry - 1) * b.W + (x0 + t - ry * bw2 - 1)] = v;
+            }
+        }
+    __syncthreads();
+    return tie;
+}
+
 #define WS_AMAX 7600  // largest window replayed out of LDS (8-byte heap items: 20 B per pixel -> 152 KB)
 #define WS_AMAX16 5400  // ... with the value inline in the heap item (28 B per pixel)
 #define WS_LDS_BYTES (WS_AMAX * 20)
@@ -636,6 +809,9 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
                           int lds_bytes = WS_LDS_BYTES)
 {
     typedef unsigned long long u64;
+    // a component whose bordered window fits the LDS is replayed by the whole wave; whole-tile replays (root < 0) ARE the
+    // reference's tie order and keep the binary heap, as do windows beyond the LDS
+    if (root >= 0 && (long)28 * (bh + 2) * (bw + 2) <= lds_bytes && !b.no_wave) return ws_window_wave(b, n, root, y0, x0, bh, bw, lds);
     const long g0 = (long)n * b.P;
     const int A = bh * bw;
     double *val;
@@ -744,7 +920,7 @@ __global__ __launch_bounds__(64) void ws_component(PPBuf b, int cls, int lds_byt
         const int y0 = b.par2[g0 + root], y1 = ((const int32_t *)b.hraw)[g0 + root];
         const int x0 = ((const int32_t *)b.vraw)[g0 + root], x1 = b.cnt[g0 + root];
         const int bh = y1 - y0 + 1, bw = x1 - x0 + 1;
-        if (((long)bh * bw <= WS_SMALL_A ? 0 : 1) != cls) continue;   // uniform per workgroup
+        if (((long)(bh + 2) * (bw + 2) <= WS_SMALL_A ? 0 : 1) != cls) continue;   // uniform per workgroup
         if (ws_window(b, n, root, y0, x0, bh, bw, ws_lds, &s_flag, lds_bytes) && threadIdx.x == 0) b.stat[n].tie = 1;
     }
 }
@@ -848,11 +1024,14 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
     hipLaunchKernelGGL(pp_marker_labels, grid, blk, 0, s, b);
     // taps first: the watershed stage recycles dead planes
     if (tap_marker) hipMemcpyAsync(tap_marker, b.mk, (size_t)n * b.P * 4, hipMemcpyDeviceToDevice, s);
-    static int ws_mode = -1;  // HVN_WS_GLOBAL=1 forces the whole-tile replay everywhere (tests)
+    static int ws_mode = -1, ws_wave = 1;  // HVN_WS_GLOBAL=1 forces the whole-tile replay everywhere (tests)
     if (ws_mode < 0) {
         const char *e = getenv("HVN_WS_GLOBAL");
         ws_mode = (e && atoi(e)) ? 1 : 0;
+        e = getenv("HVN_WS_WAVE");
+        ws_wave = e ? atoi(e) : 1;
     }
+    b.no_wave = ws_wave ? 0 : 1;
     hipLaunchKernelGGL(ws_init, grid, blk, 0, s, b);
     hipLaunchKernelGGL(ws_bbox, grid, blk, 0, s, b);
     hipLaunchKernelGGL(ws_list, grid, blk, 0, s, b);
