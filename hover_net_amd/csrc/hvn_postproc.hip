@@ -591,7 +591,8 @@ __device__ int ws_flood_window(void *heap_raw, VP val, OP out, int bh, int bw, b
 // Push = append; pop = move the last item into the hole.  The four neighbours of the popped pixel are handled by four lanes at
 // once (ages handed out in skimage's neighbour order by a ballot prefix count); the window carries a one-pixel border of
 // "not in the mask" so no coordinate is ever range-checked.  A marker tie (two age-0 items of equal value at the minimum) has no
-// defined order here: the component reports it and the tile is redone by the exact whole-tile binary-heap replay.
+// defined order here: the component reports it and is redone on the one-lane binary heap (ws_window), which knows how to
+// prove a two-way tie harmless or else hands the tile to the exact whole-tile replay.
 __device__ inline unsigned long long ws_key(double v)
 {
     v = v + 0.0;                                     // -0.0 -> +0.0: skimage compares doubles, for which they are equal
@@ -643,7 +644,7 @@ __device__ inline unsigned wave_min_u32(unsigned x)
 }
 
 // One component (root >= 0) over its bounding box, all 64 lanes.  LDS: 28 bytes per pixel of the bordered window.
-// Returns true when a marker tie was met (the caller flags the tile for the exact whole-tile replay).
+// Returns true when a marker tie was met (the caller then replays this component on the binary heap).
 __device__ bool ws_window_wave(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned char *lds)
 {
     typedef unsigned long long u64;
@@ -811,7 +812,11 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     typedef unsigned long long u64;
     // a component whose bordered window fits the LDS is replayed by the whole wave; whole-tile replays (root < 0) ARE the
     // reference's tie order and keep the binary heap, as do windows beyond the LDS
-    if (root >= 0 && (long)28 * (bh + 2) * (bw + 2) <= lds_bytes && !b.no_wave) return ws_window_wave(b, n, root, y0, x0, bh, bw, lds);
+    // (a marker tie has no defined order in the unsorted frontier: that component alone is redone below on the binary heap,
+    // whose layout the reference's tie order follows, incl. the swap proof of a harmless two-way tie)
+    if (root >= 0 && (long)28 * (bh + 2) * (bw + 2) <= lds_bytes && !b.no_wave) {
+        if (!ws_window_wave(b, n, root, y0, x0, bh, bw, lds)) return false;
+    }
     const long g0 = (long)n * b.P;
     const int A = bh * bw;
     double *val;

@@ -169,6 +169,6 @@ def test_bf16_sized_map_perturbation_keeps_the_segmentation():
     a = pp.separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
     b = pp.separate(torch.from_numpy(noisy).to("cuda")).cpu().numpy()
     scores = [pq(x, y) for x, y in zip(a, b)]
-    assert len(np.unique(a)) > 100
+    assert sum(len(np.unique(x)) - 1 for x in a) > 300
     print("bf16-sized perturbation: PQ mean %.4f min %.4f" % (float(np.mean(scores)), min(scores)))
     assert min(scores) >= 0.85 and float(np.mean(scores)) >= 0.97, (min(scores), float(np.mean(scores)))
