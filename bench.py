@@ -173,7 +173,7 @@ def main():
                    "global_batch": tiles_per_step_global, "world_size": world, "batches_per_step_per_rank": sub,
                    "instances_last_step": n_inst,
                    "parallelism": "tile-sharded x%d, %s" % (world, "gather to rank 0 per batch" if world > 1 else "single GPU"),
-                   "execution": "network on one HIP stream (decoder branches batched per launch), post-processing + D2H on a side stream"},
+                   "execution": "network on one HIP stream, post-processing + gather + D2H on a side stream under the next network pass"},
     }
 
     # ---- per-stage split of one batch (rank 0, untimed extra passes, torch events on the launch stream) -------------
@@ -319,6 +319,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()          # rank 0 ran the single-rank legs (stage split, roofline) after the last collective of the others
         dist.destroy_process_group()
 
 

@@ -147,14 +147,18 @@ extern "C" HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, co
                                            int32_t *pts, long max_pts, int64_t *offs)
 {
     if (!inst || !recs || !pts || !offs || h <= 0 || w <= 0 || n_rec < 0) return HVN_E_ARG;
+    long crop_px = 0;  // crop pixels to scan
     for (int i = 0; i < n_rec; ++i) {
         const hvn_inst_rec &r = recs[i];
-        if (r.area > 0 && (r.rmin < 0 || r.cmin < 0 || r.rmax > h || r.cmax > w || r.rmax <= r.rmin || r.cmax <= r.cmin)) return HVN_E_ARG;
+        if (r.area <= 0) continue;
+        if (r.rmin < 0 || r.cmin < 0 || r.rmax > h || r.cmax > w || r.rmax <= r.rmin || r.cmax <= r.cmin) return HVN_E_ARG;
+        crop_px += (long)(r.rmax - r.rmin) * (r.cmax - r.cmin);
     }
     // Instances are independent: contiguous record ranges go to worker threads (a 2048^2 WSI tile holds ~3000 instances,
     // a 40 000^2 slide ~10^6), each tracing into its own buffer; the offsets are a prefix sum over the per-record counts.
+    // (threads only when there is enough to share: an 80 x 80 tile's handful of nuclei is traced faster than a thread starts)
     int n_thr = 1;
-    if (n_rec >= 256) {
+    if (n_rec >= 256 && crop_px >= 200000) {
         const char *e = getenv("HVN_HOST_THREADS");
         const unsigned hc = std::thread::hardware_concurrency();
         n_thr = e ? atoi(e) : (int)(hc ? (hc < 16 ? hc : 16) : 4);

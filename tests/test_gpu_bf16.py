@@ -131,7 +131,7 @@ def test_bf16_sized_map_perturbation_keeps_the_segmentation():
     prediction maps of structured synthetic tiles are perturbed by the network's measured bf16 error scale -- every channel
     rounded to bf16 (8 mantissa bits: relative 2^-9, i.e. up to 2e-3 on p ~ 0.9 and 4e-3 on |h|, |v| ~ 1) plus smooth noise of
     +-1e-2 on p_nuc / +-3e-2 on h, v (twice the mean logit error measured above) -- and post-processed on the GPU:
-    mean panoptic quality against the unperturbed fp32 result must stay >= 0.97 (no tile below 0.85) (metrics/stats_utils.py:178 get_fast_pq semantics:
+    mean panoptic quality against the unperturbed fp32 result must stay >= 0.985 (no tile below 0.93; measured 0.9906 / 0.9547) (metrics/stats_utils.py:178 get_fast_pq semantics:
     IoU > 0.5 pairing, DQ x SQ), restated here in numpy."""
     from hover_net_amd.post_proc import PostProc
     from hover_net_amd.synth import synth_pred_maps
@@ -171,4 +171,4 @@ def test_bf16_sized_map_perturbation_keeps_the_segmentation():
     scores = [pq(x, y) for x, y in zip(a, b)]
     assert sum(len(np.unique(x)) - 1 for x in a) > 300
     print("bf16-sized perturbation: PQ mean %.4f min %.4f" % (float(np.mean(scores)), min(scores)))
-    assert min(scores) >= 0.85 and float(np.mean(scores)) >= 0.97, (min(scores), float(np.mean(scores)))
+    assert min(scores) >= 0.93 and float(np.mean(scores)) >= 0.985, (min(scores), float(np.mean(scores)))

@@ -87,9 +87,10 @@ def test_threaded_tracer_equals_single_thread(monkeypatch):
     from hover_net_amd import post_proc as PP
 
     rng = np.random.default_rng(11)
-    a = ndimage.gaussian_filter(rng.normal(size=(400, 500)), 2.0) > 0.15
+    a = ndimage.gaussian_filter(rng.normal(size=(1000, 1200)), 2.0) > 0.15
     lab, n = ndimage.label(a)
     assert n > 600
+    assert sum((sl[0].stop - sl[0].start) * (sl[1].stop - sl[1].start) for sl in ndimage.find_objects(lab)) > 250000   # threaded path
     inst = lab.astype(np.int32)
     rec = np.zeros(n + 50, PP._REC_DTYPE)                      # trailing empty slots like a real table
     for i, sl in enumerate(ndimage.find_objects(lab)):
