@@ -643,19 +643,36 @@ __device__ inline unsigned wave_min_u32(unsigned x)
     return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-// One component (root >= 0) over its bounding box, all 64 lanes.  LDS: 28 bytes per pixel of the bordered window.
-// Returns true when a marker tie was met (the caller then replays this component on the binary heap).
-__device__ bool ws_window_wave(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned char *lds)
+// One component (root >= 0) over its bounding box, all 64 lanes.  `kv` / `out` hold the bordered window (A2 = (bh+2)(bw+2)
+// entries: LDS for windows that fit, HBM scratch -- L2-resident -- for larger ones), `fk` / `fa` / `fi` the frontier (`cap`
+// slots, always LDS).  Returns true when the component must be redone on the binary heap: a marker tie was met, or the
+// frontier outgrew its slots.
+template <bool BIG>
+__device__ __forceinline__ bool ws_window_wave(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned long long *kv_far, int *out_far,
+                                               int cap)
 {
     typedef unsigned long long u64;
+    // the launch's dynamic LDS, named here so that the compiler sees LDS addresses (ds_read / ds_write, not flat accesses)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds_w[];
     const int lane = threadIdx.x;
     const long g0 = (long)n * b.P;
     const int bw2 = bw + 2, A2 = bw2 * (bh + 2);
-    u64 *kv = (u64 *)lds;                    // [A2] sortable key of every pixel's value
-    u64 *fk = kv + A2;                       // frontier: value key ...
-    unsigned *fa = (unsigned *)(fk + A2);    // ... age ...
-    unsigned *fi = fa + A2;                  // ... window index
-    int *out = (int *)(fi + A2);             // labels: -1 outside the component, 0 unlabelled
+    u64 *kv, *fk;
+    unsigned *fa, *fi;
+    int *out;
+    if constexpr (BIG) {
+        kv = kv_far;
+        out = out_far;
+        fk = (u64 *)ws_lds_w;
+        fa = (unsigned *)(fk + cap);
+        fi = fa + cap;
+    } else {
+        kv = (u64 *)ws_lds_w;
+        fk = kv + A2;
+        fa = (unsigned *)(fk + A2);
+        fi = fa + A2;
+        out = (int *)(fi + A2);
+    }
     for (int t = lane; t < A2; t += 64) {
         const int ry = t / bw2;
         const int yy = ry - 1, xx = t - ry * bw2 - 1;
@@ -677,6 +694,7 @@ __device__ bool ws_window_wave(PPBuf &b, int n, int root, int y0, int x0, int bh
         const int i = base + lane;
         const bool m = i < A2 && out[i] > 0;
         const u64 mask = __ballot(m);
+        if (nf + __popcll(mask) > cap) return true;   // (uniform) no room for the markers: binary-heap path
         if (m) {
             const int s = nf + __popcll(mask & ((1ull << lane) - 1ull));
             fk[s] = kv[i];
@@ -689,6 +707,10 @@ __device__ bool ws_window_wave(PPBuf &b, int n, int root, int y0, int x0, int bh
     unsigned age = 0;
     bool tie = false;
     while (nf > 0) {
+        if (nf + 4 > cap) {                       // the frontier outgrew its LDS slots
+            tie = true;
+            break;
+        }
         u64 bk = ~0ull;
         unsigned ba = 0xffffffffu;
         int bs = 0, cnt = 0;
@@ -814,8 +836,23 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     // reference's tie order and keep the binary heap, as do windows beyond the LDS
     // (a marker tie has no defined order in the unsorted frontier: that component alone is redone below on the binary heap,
     // whose layout the reference's tie order follows, incl. the swap proof of a harmless two-way tie)
-    if (root >= 0 && (long)28 * (bh + 2) * (bw + 2) <= lds_bytes && !b.no_wave) {
-        if (!ws_window_wave(b, n, root, y0, x0, bh, bw, lds)) return false;
+    if (root >= 0 && !b.no_wave) {
+        const int A2 = (bh + 2) * (bw + 2);
+        if ((long)28 * A2 <= lds_bytes) {
+            if (!ws_window_wave<false>(b, n, root, y0, x0, bh, bw, nullptr, nullptr, A2)) return false;
+        } else if (lds_bytes >= WS_LDS_BYTES) {
+            // window beyond the LDS (a clump of many nuclei, a tile-filling blob): its value keys and labels live in HBM
+            // scratch (planes that are dead by now; a window is a few 100 KB, i.e. L2-resident), the frontier keeps all of the LDS
+            if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, A2);
+            __syncthreads();
+            const long off = *s_flag;
+            __syncthreads();
+            if (off + A2 <= b.P) {
+                const long g0s = (long)n * b.P;
+                if (!ws_window_wave<true>(b, n, root, y0, x0, bh, bw, (u64 *)(b.dist + g0s) + off, (int *)(b.overall + g0s) + off, lds_bytes / 16))
+                    return false;
+            }
+        }
     }
     const long g0 = (long)n * b.P;
     const int A = bh * bw;
@@ -915,11 +952,6 @@ __global__ __launch_bounds__(64) void ws_component(PPBuf b, int cls, int lds_byt
     const int n = blockIdx.y;
     const long g0 = (long)n * b.P;
     const int ncomp = b.stat[n].n_comp;
-    // a tile that IS one blob gains nothing from the per-component split: replay it whole (exactly, so no tie bookkeeping)
-    if (ncomp == 1 && 2L * b.stat[n].max_area > b.P) {
-        if (cls == 1 && blockIdx.x == 0) ws_window(b, n, -1, 0, 0, b.H, b.W, ws_lds, &s_flag, lds_bytes);
-        return;
-    }
     for (int k = blockIdx.x; k < ncomp; k += gridDim.x) {
         const int root = b.par[g0 + k];
         const int y0 = b.par2[g0 + root], y1 = ((const int32_t *)b.hraw)[g0 + root];

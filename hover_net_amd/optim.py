@@ -21,9 +21,10 @@ def _check(rc):
 
 
 def _bump(params):
-    """The kernel writes the weights through raw pointers, behind torch's version counters; bump them so that anything keyed
-    on `p._version` (HoVerNet._weights_version -> the cached inference plan) sees the update."""
-    for p in params:
+    """The kernel writes the weights through raw pointers, behind torch's version counters; bump one so that anything keyed
+    on `p._version` (HoVerNet._weights_version hashes every parameter's version -> the cached inference plan) sees the
+    update.  One parameter per group is enough for that key and keeps the step free of a 400-iteration python loop."""
+    for p in params[:1]:
         torch._C._increment_version(p)
 
 
