@@ -44,6 +44,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
 {
+    // Two workgroups share a CU (LDS), i.e. two waves share each SIMD's matrix pipe.  Launched together and doing identical
+    // work they run in lock-step: both in the k-loop (each at half rate), then both in the epilogue, where the pipe idles
+    // while 16 rows of residual loads / stores per thread trickle out (ablation, profiles/r02_experiments.md: the epilogue's
+    // global traffic costs 20-40 % of a K <= 512 launch although HBM is far from saturated).  Raising the issue priority of
+    // the wave in the odd slot of every SIMD lets it finish its k-loop first; from then on one workgroup's epilogue runs
+    // under the other's k-loop.
+    if (p.stagger) {
+        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
+        if (slot & 1u) __builtin_amdgcn_s_setprio(1);
+    }
     if (p.nbatch > 1) {  // batched launch: one of nbatch independent problems per blockIdx.y
         p.x += (long)blockIdx.y * p.xb;
         p.w += (long)blockIdx.y * p.wb;
@@ -462,6 +472,12 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bo
 static int launch_conv(const ConvArgs &a, hipStream_t stream)
 {
     ConvArgs p = a;
+    static int stagger = -1;
+    if (stagger < 0) {
+        const char *e = getenv("HVN_STAGGER");
+        stagger = e ? atoi(e) : 1;
+    }
+    p.stagger = stagger;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);

@@ -22,6 +22,7 @@ struct ConvArgs {
     long x2sn, x2sy, x2sx;
     int Cin2, stride2;
     int nbatch;           // > 1: blockIdx.y selects one of nbatch independent problems
+    int stagger;          // 1: the wave in the odd slot of each SIMD runs at raised issue priority (see hvn_conv.hip)
     long xb, wb, yb;      // element strides between them
 };
 

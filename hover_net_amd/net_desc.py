@@ -10,8 +10,10 @@ key-shaped tree, and `forward` lowers them once to the fused HIP launch plan
 the library or off a gfx950 device `forward` raises.
 
 In train() mode `forward` runs the training engine's forward (batch-statistics BatchNorm, running stats updated,
-activations kept for `run_desc.train_step`'s backward pass); gradients are produced by the HIP backward plan,
-not by torch autograd, so the returned logits carry no grad_fn.
+activations kept for the backward pass).  The returned logits are nodes of torch's autograd graph (`_TrainForward`): a loss
+computed on them in torch and `loss.backward()` hand the logit gradients to the HIP backward plan, which fills the
+parameters' gradients -- so the module is "autograd-capable in train mode"  although no torch op computes a
+gradient.  `run_desc.train_step` does not take this detour: its losses and logit gradients are fused kernels.
 """
 import os
 from collections import OrderedDict
@@ -58,6 +60,34 @@ def _attach(root, key, kind, shape, gen):
         node.register_buffer(leaf, torch.ones(shape))
     else:  # pragma: no cover
         raise KeyError(kind)
+
+
+class _TrainForward(torch.autograd.Function):
+    """Autograd node around the training engine: forward = HIP train-mode forward, backward = HIP backward plan.
+    Inputs: the module, the images, then every trainable parameter (they make the outputs require grad and receive the
+    gradients).  The engine writes the gradients into its slab, which is also the memory behind `p.grad`; autograd ADDS what
+    backward() returns to `p.grad`, so the slab is cloned and zeroed before returning -- `p.grad` then ends up holding exactly
+    the gradient (or the running sum over several backward calls, torch's semantics)."""
+
+    @staticmethod
+    def forward(ctx, net, imgs, *params):
+        from . import train_engine
+
+        teng = train_engine.engine_for(net, imgs.shape[0])
+        teng.img.copy_(imgs.detach().permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8))   # the loader's uint8 pixels
+        logits = teng.forward()
+        ctx.teng, ctx.keys = teng, list(logits.keys())
+        ctx.param_keys = [k for k, p in net.named_parameters() if p.requires_grad and k in teng.plan.trainable]
+        return tuple(v.clone() for v in logits.values())
+
+    @staticmethod
+    def backward(ctx, *grads):
+        teng = ctx.teng
+        teng.backward_from({k: g for k, g in zip(ctx.keys, grads) if g is not None})
+        snap = teng.gslab.clone()
+        teng.gslab.zero_()
+        out = tuple(teng._param_view(snap, k, teng._poff[k]) for k in ctx.param_keys)
+        return (None, None) + out
 
 
 class HoVerNet(nn.Module):
@@ -118,9 +148,10 @@ class HoVerNet(nn.Module):
         if self.training:
             from . import train_engine
 
-            teng = train_engine.engine_for(self, imgs.shape[0])
-            teng.img.copy_(imgs.detach().permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8))   # the loader's uint8 pixels
-            return OrderedDict((k, v.clone()) for k, v in teng.forward().items())
+            teng = train_engine.engine_for(self, imgs.shape[0])      # re-points the parameters at its slab on first use
+            params = [p for k, p in self.named_parameters() if p.requires_grad and k in teng.plan.trainable]
+            outs = _TrainForward.apply(self, imgs, *params)
+            return OrderedDict(zip(teng.logits.keys(), outs))
         eng = self.engine(imgs.shape[0])
         logits, _ = eng.run(imgs)
         # fresh tensors: the engine's buffers are overwritten by the next call

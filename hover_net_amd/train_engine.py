@@ -468,6 +468,23 @@ class TrainEngine:
                 w.wait()
         return self.gslab
 
+    def backward_from(self, dlogits):
+        """Backward plan from caller-supplied logit gradients (dict branch -> [n, c, h, w]): what torch autograd hands
+        `HoVerNet.forward`'s graph node when the loss was computed in torch.  Fills the gradient slab (the parameters' .grad
+        memory) like `backward`, without the fused loss stage."""
+        lib = L.lib()
+        self.gmem.zero_()
+        for br, buf in self.dlogits.items():
+            g = dlogits.get(br)
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g.to(buf.dtype).reshape(buf.shape))
+        rc = lib.hvn_run_train_plan(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), self.n, self._stream())
+        if rc:
+            raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        return self.gslab
+
     def loss_and_backward(self, world=1, all_reduce=None):
         """loss stage 1 -> (SUM all-reduce of the partial sums) -> backward with the bucketed gradient all-reduce.
         `all_reduce(tensor, async_op)`: torch.distributed's SUM all-reduce (RCCL), returning a work handle when

@@ -633,3 +633,53 @@ def test_winograd_domain_weight_gradient(n, H, cin, cout, pad):
     run_tops([t0, t1_, t2, t3], n)
     want = train_interp.wgrad_ref(TOp("wgrad", "t", stride=1, pad=(pad, pad), groups=1), x.cpu(), dy.cpu(), (cout, cin, 5, 5))
     close(dW.cpu().view(cout, 5, 5, cin).permute(0, 3, 1, 2) - 1.0, want, 1e-4, "winograd-domain wgrad")
+
+
+@pytest.mark.parametrize("freeze", [False, True])
+def test_train_mode_forward_is_a_torch_autograd_node(freeze):
+    """`HoVerNet.forward` is "autograd-capable in train mode".  The logits carry a grad_fn; a loss written in plain
+    torch on them and `loss.backward()` drive the HIP backward plan; parameter gradients agree with the training oracle's
+    autograd (torch-CPU restatement of the reference's train-mode forward) for the same loss, accumulate over two backward
+    calls like torch's, respect the freeze scoping, and feed FusedAdam's single-launch path."""
+    from hover_net_amd import net_desc
+    from hover_net_amd.optim import FusedAdam
+    from hover_net_amd.synth import synth_state_dict, synth_train_batch
+    from oracle import train_torch
+    mode, nt, n = "fast", None, 2
+    sd = synth_state_dict(mode, nt, seed=12)
+    batch = synth_train_batch(n, mode, nt, seed=13)
+    imgs = torch.as_tensor(batch["img"]).float().permute(0, 3, 1, 2).contiguous()
+    g = torch.Generator().manual_seed(3)
+    wts = {"np": torch.randn(n, 2, 164, 164, generator=g), "hv": torch.randn(n, 2, 164, 164, generator=g)}
+
+    def loss_of(logits, dev):
+        return sum((logits[k] * wts[k].to(dev)).sum() for k in wts) / float(n * 164 * 164) + (logits["np"] ** 2).mean()
+
+    # oracle: same loss through torch autograd on the CPU restatement
+    sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k and "unpool" not in k else v.clone()) for k, v in sd.items()}
+    lg_o, _ = train_torch.forward_train(sd_o, imgs, mode, freeze)
+    loss_of(lg_o, "cpu").backward()
+    want = {k: v.grad for k, v in sd_o.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
+
+    net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda").train()
+    out = net(imgs.cuda())
+    assert list(out.keys()) == ["np", "hv"] and all(v.grad_fn is not None and v.requires_grad for v in out.values())
+    for k in out:
+        assert float((out[k].detach().cpu() - lg_o[k].detach()).abs().max()) < 1e-3, k
+    loss_of(out, "cuda").backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    have = {k for k, p in params.items() if p.grad is not None and float(p.grad.abs().sum()) > 0}
+    assert have == {k for k, gr in want.items() if float(gr.abs().sum()) > 0}      # frozen encoder: no gradient on either side
+    errs = sorted(_rel_l2(params[k].grad.cpu(), want[k]) for k in have)
+    assert errs[len(errs) // 2] < 5e-3 and errs[-1] < 5e-2, (errs[len(errs) // 2], errs[-1])
+    first = {k: params[k].grad.clone() for k in list(have)[:5]}
+    loss_of(net(imgs.cuda()), "cuda").backward()                                  # no zero_grad: gradients accumulate
+    for k, g1 in first.items():
+        assert _rel_l2(params[k].grad, 2.0 * g1) < 2e-2, k                        # (running stats moved between the passes: not exactly 2x)
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    before = params["decoder.np.u0.conv.weight"].detach().clone()
+    opt.step()
+    assert opt.fused_launches == 1 and not torch.equal(params["decoder.np.u0.conv.weight"].detach(), before)
