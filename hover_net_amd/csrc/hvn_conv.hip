@@ -51,8 +51,14 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     // the wave in the odd slot of every SIMD lets it finish its k-loop first; from then on one workgroup's epilogue runs
     // under the other's k-loop.
     if (p.stagger) {
-        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID[3:0] = wave slot on its SIMD
-        if (slot & 1u) __builtin_amdgcn_s_setprio(1);
+        // the two workgroups of a CU are told apart by where their LDS allocation starts (HW_REG_LDS_ALLOC[7:0] = LDS_BASE)
+        const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | ((8 - 1) << 11));
+        if (p.stagger == 1 && lds_base != 0u) __builtin_amdgcn_s_setprio(3);
+        if (p.stagger == 2) {               // variant: by the wave slot on the SIMD (HW_REG_HW_ID[3:0])
+            const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));
+            if (slot & 1u) __builtin_amdgcn_s_setprio(3);
+        }
+        if (p.stagger == 3 && lds_base != 0u) __builtin_amdgcn_s_sleep(127);   // variant: the second workgroup starts ~8k cycles late (no priority)
     }
     if (p.nbatch > 1) {  // batched launch: one of nbatch independent problems per blockIdx.y
         p.x += (long)blockIdx.y * p.xb;
