@@ -29,7 +29,10 @@
 //             cout tile) get the same blockIdx % 8, i.e. the same XCD L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include <type_traits>
 
@@ -60,6 +63,8 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
         }
         if (p.stagger == 3 && lds_base != 0u) __builtin_amdgcn_s_sleep(127);   // variant: the second workgroup starts ~8k cycles late (no priority)
     }
+    unsigned long long t_start = 0, t_kend = 0;
+    if (p.dbg) t_start = __builtin_readcyclecounter();
     if (p.nbatch > 1) {  // batched launch: one of nbatch independent problems per blockIdx.y
         p.x += (long)blockIdx.y * p.xb;
         p.w += (long)blockIdx.y * p.wb;
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     }
     mma(KT - 1, integral_constant<int, 0>{}, integral_constant<int, NQ>{});
     __syncthreads();
+    if (p.dbg) t_kend = __builtin_readcyclecounter();
 
     // ---- epilogue ------------------------------------------------------------------
     // 1. accumulators -> LDS tile [BM][EP_LD] (32 consecutive floats per half-wave: conflict-free)
@@ -472,6 +478,15 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
             } else if (v.x == 12345.678f && ok[u]) *(f32x4 *)(p.y + yoff[u]) = v;   // keeps the math alive, stores nothing
         }
     }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of this thread have left
+        unsigned long long *d = p.dbg + 4ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+        d[0] = t_start;
+        d[1] = t_kend;
+        d[2] = __builtin_readcyclecounter();
+        d[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | ((32 - 1) << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg(6 | (0 << 6) | ((8 - 1) << 11)) << 32);
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
@@ -484,6 +499,14 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
         stagger = e ? atoi(e) : 1;
     }
     p.stagger = stagger;
+    static unsigned long long *dbg_buf = nullptr;
+    static int dbg_on = -1;
+    if (dbg_on < 0) {
+        const char *e = getenv("HVN_CONV_TRACE");   // path of a file to dump per-workgroup timestamps of the LAST launch into
+        dbg_on = e ? 1 : 0;
+        if (dbg_on) hipMalloc(&dbg_buf, 4 * 8 * (size_t)(1 << 20));
+    }
+    p.dbg = dbg_on ? dbg_buf : nullptr;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
@@ -498,6 +521,16 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     const long grid = groups * 8 * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, p.nbatch > 1 ? p.nbatch : 1), dim3(256), lds, stream, p);
+    if (dbg_on && grid * (p.nbatch > 1 ? p.nbatch : 1) <= (1 << 20)) {   // experiment mode only: synchronous dump
+        hipStreamSynchronize(stream);
+        const size_t n = (size_t)grid * (p.nbatch > 1 ? p.nbatch : 1);
+        std::vector<unsigned long long> h(4 * n);
+        hipMemcpy(h.data(), dbg_buf, 32 * n, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("HVN_CONV_TRACE"), "wb")) {
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

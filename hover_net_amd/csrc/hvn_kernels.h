@@ -22,7 +22,8 @@ struct ConvArgs {
     long x2sn, x2sy, x2sx;
     int Cin2, stride2;
     int nbatch;           // > 1: blockIdx.y selects one of nbatch independent problems
-    int stagger;          // 1: the wave in the odd slot of each SIMD runs at raised issue priority (see hvn_conv.hip)
+    int stagger;          // experiment switch, see hvn_conv.hip
+    unsigned long long *dbg;  // optional: per-workgroup {start, k-loop end, epilogue end, HW_ID | LDS base << 32} (tools/conv_trace.py)
     long xb, wb, yb;      // element strides between them
 };
 

@@ -66,8 +66,8 @@ class _TrainForward(torch.autograd.Function):
     """Autograd node around the training engine: forward = HIP train-mode forward, backward = HIP backward plan.
     Inputs: the module, the images, then every trainable parameter (they make the outputs require grad and receive the
     gradients).  The engine writes the gradients into its slab, which is also the memory behind `p.grad`; autograd ADDS what
-    backward() returns to `p.grad`, so the slab is cloned and zeroed before returning -- `p.grad` then ends up holding exactly
-    the gradient (or the running sum over several backward calls, torch's semantics)."""
+    backward() returns to `p.grad`, so the slab's previous content is put back and the new gradients are handed over as a
+    copy -- `p.grad` ends up holding the running sum over the backward calls since the last zero_grad, torch's semantics."""
 
     @staticmethod
     def forward(ctx, net, imgs, *params):
@@ -83,9 +83,10 @@ class _TrainForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         teng = ctx.teng
+        held = teng.gslab.clone()                 # what p.grad holds so far (the slab IS the parameters' .grad memory)
         teng.backward_from({k: g for k, g in zip(ctx.keys, grads) if g is not None})
         snap = teng.gslab.clone()
-        teng.gslab.zero_()
+        teng.gslab.copy_(held)                    # autograd adds `snap` to it: p.grad = previous + this pass, torch's semantics
         out = tuple(teng._param_view(snap, k, teng._poff[k]) for k in ctx.param_keys)
         return (None, None) + out
 
