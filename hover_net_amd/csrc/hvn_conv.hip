@@ -434,6 +434,26 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
         e_oy = rem / (unsigned)p.Wo;
         e_ox = rem - e_oy * (unsigned)p.Wo;
     }
+    f32x4 rall[ABL == 7 ? NIT : 1];
+    if constexpr (ABL == 7) {   // experiment: every residual load of the tile in flight before the first is used
+        unsigned a_n = e_n, a_oy = e_oy, a_ox = e_ox;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const unsigned m = m0 + erow0 + it * RPP;
+            const long ro = (m < M && cok && has_res) ? (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co : 0;
+            rall[it] = *(const f32x4 *)(resp + ro);
+            a_ox += RPP;
+            while (a_ox >= (unsigned)p.Wo) {
+                a_ox -= (unsigned)p.Wo;
+                ++a_oy;
+            }
+            while (a_oy >= (unsigned)p.Ho) {
+                a_oy -= (unsigned)p.Ho;
+                ++a_n;
+            }
+        }
+    }
+#pragma unroll(ABL == 7 ? NIT / 4 : 1)
     for (int it0 = 0; it0 < NIT; it0 += 4) {
         long yoff[4], roff[4];
         bool ok[4];
@@ -444,7 +464,11 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
             const unsigned m = m0 + erow0 + (it0 + u) * RPP;
             ok[u] = m < M && cok;
             yoff[u] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
-            roff[u] = (ok[u] && has_res) ? (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co : 0;
+            if constexpr (ABL == 6) {   // experiment: the tile's 64 KB written as ONE contiguous block (wrong place, right amount)
+                yoff[u] = ((long)(m_tile * NT + n_tile) * BM + (erow0 + (it0 + u) * RPP)) * BN + ecol;
+                ok[u] = ok[u] && yoff[u] + 4 <= (long)M * p.Cout;
+            }
+            roff[u] = (ABL != 7 && ok[u] && has_res) ? (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co : 0;
             e_ox += RPP;
             while (e_ox >= (unsigned)p.Wo) {
                 e_ox -= (unsigned)p.Wo;
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if constexpr (ABL == 4) rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};   // ablation: epilogue without global traffic
+            else if constexpr (ABL == 7) rv[u] = rall[it0 + u];
             else rv[u] = *(const f32x4 *)(resp + roff[u]);
         }
 #pragma unroll
@@ -565,6 +590,8 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
         if (abl == 2) return launch_conv<128, 128, 2, 2, true, 2>(a, stream);
         if (abl == 3) return launch_conv<128, 128, 2, 2, true, 3>(a, stream);
         if (abl == 4) return launch_conv<128, 128, 2, 2, true, 4>(a, stream);
+        if (abl == 6) return launch_conv<128, 128, 2, 2, true, 6>(a, stream);
+        if (abl == 7) return launch_conv<128, 128, 2, 2, true, 7>(a, stream);
         if (abl == 5) return launch_conv<128, 128, 2, 2, true, 0>(a, stream);   // the same instantiation without ablation (PADDED + prologue code paths on): the baseline of the ablation series
         if (!a.pre_s && !getenv("HVN_NO_RAWSTORE"))
             return padded ? launch_conv<128, 128, 2, 2, true, 0, false, false>(a, stream) : launch_conv<128, 128, 2, 2, false, 0, false, false>(a, stream);
