@@ -423,7 +423,6 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
     const float post_lo = has_post ? 0.f : -__builtin_inff();
     constexpr int NIT = BM / RPP;         // rows per thread: 16 / 8 / 4
-    const float *resp = has_res ? p.res : p.w;  // valid address either way; value unused without a residual
     // this thread's rows are m0 + erow0 + k*RPP: decode the first with divisions, walk the rest (n, oy, ox) incrementally
     // (32 integer divisions per thread and tile were ~10 % of a short-K tile's instruction stream)
     unsigned e_n, e_oy, e_ox;
@@ -434,14 +433,19 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
         e_oy = rem / (unsigned)p.Wo;
         e_ox = rem - e_oy * (unsigned)p.Wo;
     }
-    f32x4 rall[ABL == 7 ? NIT : 1];
-    if constexpr (ABL == 7) {   // experiment: every residual load of the tile in flight before the first is used
+    // Residual tile first: ALL of this thread's residual loads are issued before any store.  vmcnt retires loads and stores
+    // in order, so a load issued after a store cannot be waited for without draining that store: the round-1 epilogue
+    // (4 rounds of "4 loads, wait, 4 stores" -- with a dummy load per row when there is no residual) paid four loaded-memory
+    // round trips per tile, 30-50 k cycles against a 14-40 k cycle k-loop on the K <= 512 layers (per-workgroup timelines,
+    // profiles/r02_experiments.md).  Now: one wait, then 16 stores back to back.
+    f32x4 rall[NIT];
+    if (has_res && ABL != 4) {
         unsigned a_n = e_n, a_oy = e_oy, a_ox = e_ox;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const unsigned m = m0 + erow0 + it * RPP;
-            const long ro = (m < M && cok && has_res) ? (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co : 0;
-            rall[it] = *(const f32x4 *)(resp + ro);
+            const long ro = (m < M && cok) ? (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co : 0;
+            rall[it] = *(const f32x4 *)(p.res + ro);
             a_ox += RPP;
             while (a_ox >= (unsigned)p.Wo) {
                 a_ox -= (unsigned)p.Wo;
@@ -452,56 +456,42 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
                 ++a_n;
             }
         }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll(ABL == 7 ? NIT / 4 : 1)
-    for (int it0 = 0; it0 < NIT; it0 += 4) {
-        long yoff[4], roff[4];
-        bool ok[4];
-        f32x4 rv[4];
-        // locate 4 rows, then issue their residual loads together, then do the math / stores
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned m = m0 + erow0 + (it0 + u) * RPP;
-            ok[u] = m < M && cok;
-            yoff[u] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
-            if constexpr (ABL == 6) {   // experiment: the tile's 64 KB written as ONE contiguous block (wrong place, right amount)
-                yoff[u] = ((long)(m_tile * NT + n_tile) * BM + (erow0 + (it0 + u) * RPP)) * BN + ecol;
-                ok[u] = ok[u] && yoff[u] + 4 <= (long)M * p.Cout;
-            }
-            roff[u] = (ABL != 7 && ok[u] && has_res) ? (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co : 0;
-            e_ox += RPP;
-            while (e_ox >= (unsigned)p.Wo) {
-                e_ox -= (unsigned)p.Wo;
-                ++e_oy;
-            }
-            while (e_oy >= (unsigned)p.Ho) {
-                e_oy -= (unsigned)p.Ho;
-                ++e_n;
-            }
+    for (int it = 0; it < NIT; ++it) {
+        const unsigned m = m0 + erow0 + it * RPP;
+        bool ok = m < M && cok;
+        long yoff = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+        if constexpr (ABL == 6) {   // experiment: the tile's 64 KB written as ONE contiguous block (wrong place, right amount)
+            yoff = ((long)(m_tile * NT + n_tile) * BM + (erow0 + it * RPP)) * BN + ecol;
+            ok = ok && yoff + 4 <= (long)M * p.Cout;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if constexpr (ABL == 4) rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};   // ablation: epilogue without global traffic
-            else if constexpr (ABL == 7) rv[u] = rall[it0 + u];
-            else rv[u] = *(const f32x4 *)(resp + roff[u]);
+        e_ox += RPP;
+        while (e_ox >= (unsigned)p.Wo) {
+            e_ox -= (unsigned)p.Wo;
+            ++e_oy;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rr = erow0 + (it0 + u) * RPP;
-            f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol);
-            v.x = fmaxf(v.x + bias.x, relu_lo);
-            v.y = fmaxf(v.y + bias.y, relu_lo);
-            v.z = fmaxf(v.z + bias.z, relu_lo);
-            v.w = fmaxf(v.w + bias.w, relu_lo);
-            if (has_res) v += rv[u];
-            v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
-            v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
-            v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
-            v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
-            if constexpr (ABL != 4) {
-                if (ok[u]) *(f32x4 *)(p.y + yoff[u]) = v;
-            } else if (v.x == 12345.678f && ok[u]) *(f32x4 *)(p.y + yoff[u]) = v;   // keeps the math alive, stores nothing
+        while (e_oy >= (unsigned)p.Ho) {
+            e_oy -= (unsigned)p.Ho;
+            ++e_n;
         }
+        const int rr = erow0 + it * RPP;
+        f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol);
+        v.x = fmaxf(v.x + bias.x, relu_lo);
+        v.y = fmaxf(v.y + bias.y, relu_lo);
+        v.z = fmaxf(v.z + bias.z, relu_lo);
+        v.w = fmaxf(v.w + bias.w, relu_lo);
+        v += rall[it];
+        v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
+        v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
+        v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
+        v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
+        if constexpr (ABL != 4) {
+            if (ok) *(f32x4 *)(p.y + yoff) = v;
+        } else if (v.x == 12345.678f && ok) *(f32x4 *)(p.y + yoff) = v;   // keeps the math alive, stores nothing
     }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of this thread have left
@@ -591,7 +581,6 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
         if (abl == 3) return launch_conv<128, 128, 2, 2, true, 3>(a, stream);
         if (abl == 4) return launch_conv<128, 128, 2, 2, true, 4>(a, stream);
         if (abl == 6) return launch_conv<128, 128, 2, 2, true, 6>(a, stream);
-        if (abl == 7) return launch_conv<128, 128, 2, 2, true, 7>(a, stream);
         if (abl == 5) return launch_conv<128, 128, 2, 2, true, 0>(a, stream);   // the same instantiation without ablation (PADDED + prologue code paths on): the baseline of the ablation series
         if (!a.pre_s && !getenv("HVN_NO_RAWSTORE"))
             return padded ? launch_conv<128, 128, 2, 2, true, 0, false, false>(a, stream) : launch_conv<128, 128, 2, 2, false, 0, false, false>(a, stream);
