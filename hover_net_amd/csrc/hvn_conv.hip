@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     // in order, so a load issued after a store cannot be waited for without draining that store: the round-1 epilogue
     // (4 rounds of "4 loads, wait, 4 stores" -- with a dummy load per row when there is no residual) paid four loaded-memory
     // round trips per tile, 30-50 k cycles against a 14-40 k cycle k-loop on the K <= 512 layers (per-workgroup timelines,
-    // profiles/r02_experiments.md).  Now: one wait, then 16 stores back to back.
+    // profiles/r02_experiments.md).
     f32x4 rall[NIT];
     if (has_res && ABL != 4) {
         unsigned a_n = e_n, a_oy = e_oy, a_ox = e_ox;
@@ -460,14 +460,20 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // ... then every output value is finished in registers (the waits for the residual loads fall here, while no store is in
+    // flight: with loads AND stores pending the compiler has to assume they retire out of order and waits for vmcnt(0), i.e.
+    // for the previous store, before every use of a loaded value) ...
+    f32x4 vout[NIT];
+    long yoffs[NIT];
+    bool oks[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const unsigned m = m0 + erow0 + it * RPP;
-        bool ok = m < M && cok;
-        long yoff = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+        oks[it] = m < M && cok;
+        yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
         if constexpr (ABL == 6) {   // experiment: the tile's 64 KB written as ONE contiguous block (wrong place, right amount)
-            yoff = ((long)(m_tile * NT + n_tile) * BM + (erow0 + it * RPP)) * BN + ecol;
-            ok = ok && yoff + 4 <= (long)M * p.Cout;
+            yoffs[it] = ((long)(m_tile * NT + n_tile) * BM + (erow0 + it * RPP)) * BN + ecol;
+            oks[it] = oks[it] && yoffs[it] + 4 <= (long)M * p.Cout;
         }
         e_ox += RPP;
         while (e_ox >= (unsigned)p.Wo) {
@@ -489,9 +495,18 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
         v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
         v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
         v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
+        vout[it] = v;
+    }
+    // ... and the 16 stores leave back to back.  (The empty asm pins every value and address in a VGPR here: LLVM otherwise sinks
+    // the arithmetic into the `if (ok)` blocks of the stores, which puts the load waits right back between them.)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
         if constexpr (ABL != 4) {
-            if (ok) *(f32x4 *)(p.y + yoff) = v;
-        } else if (v.x == 12345.678f && ok) *(f32x4 *)(p.y + yoff) = v;   // keeps the math alive, stores nothing
+            if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
+        } else if (vout[it].x == 12345.678f && oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];   // keeps the math alive, stores nothing
     }
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of this thread have left

@@ -273,7 +273,30 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
             oy = rem / (unsigned)p.Wo;
             ox = rem - oy * (unsigned)p.Wo;
         }
-        for (int it = 0; it < (BM + RPP - 1) / RPP; ++it, ox += RPP) {
+        // all residual loads of the tile first, then the stores back to back: vmcnt retires loads and stores in order, so a
+        // load issued after a store cannot be waited for without draining that store (see hvn_conv.hip)
+        constexpr int NIT = (BM + RPP - 1) / RPP;
+        u32x4 rall[NIT];
+        {
+            unsigned a_n = n, a_oy = oy, a_ox = ox;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it, a_ox += RPP) {
+                while (a_ox >= (unsigned)p.Wo) {
+                    a_ox -= (unsigned)p.Wo;
+                    ++a_oy;
+                }
+                while (a_oy >= (unsigned)p.Ho) {
+                    a_oy -= (unsigned)p.Ho;
+                    ++a_n;
+                }
+                const int rr = erow0 + it * RPP;
+                rall[it] = (u32x4){0u, 0u, 0u, 0u};
+                if (has_res && rr < BM && m0 + rr < M && cok)
+                    rall[it] = *(const u32x4 *)(pres + (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it, ox += RPP) {
             while (ox >= (unsigned)p.Wo) {
                 ox -= (unsigned)p.Wo;
                 ++oy;
@@ -285,8 +308,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
             const int rr = erow0 + it * RPP;
             const unsigned m = m0 + rr;
             if (rr >= BM || !(m < M && cok)) continue;
-            u32x4 r4 = {0u, 0u, 0u, 0u};
-            if (has_res) r4 = *(const u32x4 *)(pres + (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co);
+            const u32x4 r4 = rall[it];
             u32x4 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
