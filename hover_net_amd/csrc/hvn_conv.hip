@@ -47,12 +47,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
 {
-    // Two workgroups share a CU (LDS), i.e. two waves share each SIMD's matrix pipe.  Launched together and doing identical
-    // work they run in lock-step: both in the k-loop (each at half rate), then both in the epilogue, where the pipe idles
-    // while 16 rows of residual loads / stores per thread trickle out (ablation, profiles/r02_experiments.md: the epilogue's
-    // global traffic costs 20-40 % of a K <= 512 launch although HBM is far from saturated).  Raising the issue priority of
-    // the wave in the odd slot of every SIMD lets it finish its k-loop first; from then on one workgroup's epilogue runs
-    // under the other's k-loop.
+    // EXPERIMENT (off by default, HVN_STAGGER=1|2|3): two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe; giving
+    // one of them a raised issue priority (told apart by LDS base or wave slot) or a delayed start was meant to keep one
+    // workgroup's epilogue under the other's k-loop.  Measured: no effect (profiles/r02_experiments.md section 7).
     if (p.stagger) {
         // the two workgroups of a CU are told apart by where their LDS allocation starts (HW_REG_LDS_ALLOC[7:0] = LDS_BASE)
         const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | ((8 - 1) << 11));
@@ -525,8 +522,8 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     ConvArgs p = a;
     static int stagger = -1;
     if (stagger < 0) {
-        const char *e = getenv("HVN_STAGGER");
-        stagger = e ? atoi(e) : 1;
+        const char *e = getenv("HVN_STAGGER");   // experiment switch (profiles/r02_experiments.md section 7): 0 = off (default)
+        stagger = e ? atoi(e) : 0;
     }
     p.stagger = stagger;
     static unsigned long long *dbg_buf = nullptr;
