@@ -41,6 +41,66 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16 (cfg 3 only: --dtype bf16)
 
 
+def _control_flow_selftest(args, rank, world, dev):
+    """The distributed skeleton of main() with the GPU pipeline replaced by correctly shaped dummy tensors (see the flag's help)."""
+    import torch
+    import torch.distributed as dist
+
+    from hover_net_amd import infer_tile
+
+    b, hw, max_inst = args.batch, 80, 80 * 80 // 13 + 1
+    gather = infer_tile.gather_to_rank0 if world > 1 else None
+
+    def submit():
+        out = (torch.full((b, hw, hw), rank + 1, dtype=torch.int32), torch.zeros((b, max_inst, 56), dtype=torch.uint8),
+               torch.full((b,), rank, dtype=torch.int32))
+        return gather(out) if gather is not None else out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    def timed(steps):
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = submit()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    for _ in range(args.warmup):
+        submit()
+    dt, out = timed(args.steps)
+    if rank == 0:
+        assert out[0].shape[0] == world * b and out[0][::b, 0, 0].tolist() == list(range(1, world + 1)), "gather order = rank order"
+        assert out[2][::b].tolist() == list(range(world))
+    else:
+        assert out is None or world == 1
+    reps, t_end = 0, time.perf_counter() + min(args.sustain_seconds, 1.0)
+    while True:                                   # the sustained leg's stop vote: every rank leaves in the same iteration
+        for _ in range(args.steps):
+            submit()
+        reps += args.steps
+        flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0])
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0.0:
+            break
+    if rank == 0:
+        print(json.dumps({"metric": "control-flow self-test (no kernels, nothing measured)", "value": 0.0, "unit": "tiles/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "data": "dummy",
+                          "config": {"global_batch": world * b, "world_size": world, "sustained_steps": reps}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +119,10 @@ def main():
     ap.add_argument("--quiet-net-output", action="store_true",
                     help="bias the NP head of the random-init checkpoint towards background, so that the network's own output "
                          "holds no nuclei and the instance-separation load of the step comes from the structured maps only")
+    ap.add_argument("--control-flow-selftest", action="store_true",
+                    help="CI only (tests/test_bench_dist.py): run the N-rank control flow of this script -- barriers, max-over-ranks clock, "
+                         "the per-batch gather to rank 0, the sustained leg's stop vote, the closing barrier -- on CPU tensors over gloo with "
+                         "a stand-in for the GPU pipeline that moves correctly shaped dummy results.  Measures nothing; the JSON line says so.")
     ap.add_argument("--dtype", default="fp32", choices=("fp32", "bf16"),
                     help="fp32 = the headline configuration (BASELINE cfg 2); bf16 = cfg 3 (use with --mode fast --nr-types 6 --batch 64)")
     args = ap.parse_args()
@@ -70,13 +134,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    selftest = args.control_flow_selftest
+    if selftest:
+        dev = torch.device("cpu")
+        args.no_roofline = args.no_cpu_baseline = True
+        torch.cuda.synchronize = lambda *a, **k: None       # nothing to wait for: the stand-in pipeline is synchronous
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if selftest:
+        return _control_flow_selftest(args, rank, world, dev)
 
     from hover_net_amd import infer_tile, post_proc, run_desc
     from hover_net_amd import lib as L
