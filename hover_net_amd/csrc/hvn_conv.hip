@@ -376,10 +376,6 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
         ++kt;
     }
     mma(KT - 1, integral_constant<int, 0>{}, integral_constant<int, NQ>{});
-    // The epilogue's few hundred VALU / LDS / VMEM instructions compete for issue slots with the MFMA-dense k-loop of the
-    // co-resident workgroup on the same SIMDs (measured: an epilogue WITHOUT global traffic stretches to the partner's whole
-    // k-loop).  Raised priority lets them through; the partner loses a few slots, the CU gets its next workgroup sooner.
-    if (p.stagger != 9) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     if (p.dbg) t_kend = __builtin_readcyclecounter();
 
