@@ -270,9 +270,11 @@ def run_sharded(items, step_fn, batch_size):
 
 
 # --------------------------------------------------------------------------------------------
-def process_images(images, model, nr_types=None, batch_size=32, return_centroids=True):
+def process_images(images, model, nr_types=None, batch_size=32, return_centroids=True, return_raw=False):
     """images: list of uint8 [H,W,3] arrays (RGB).  Returns a list of (pred_inst int32 [H,W] numpy, inst_info_dict | None)
     in input order: complete on rank 0 (the writer); the other ranks hold their own images' results and None elsewhere.
+    `return_raw=True` appends the stitched float32 prediction map [H,W,3|4] to each tuple (`--save_raw_map`,
+    infer/tile.py:193-194); it travels to rank 0 with the other arrays.
 
     Pipeline per call: host patch extraction -> sharded HIP network (`run_desc.infer_step_device`)
     -> one all_gather of the per-patch maps -> per-image stitch on the GPU -> on-GPU instance
@@ -306,9 +308,17 @@ def process_images(images, model, nr_types=None, batch_size=32, return_centroids
             inst_h = inst[0].cpu().numpy()
             rec_h = rec[0].cpu().numpy().view(post_proc._REC_DTYPE).reshape(-1) if rec is not None else np.zeros(0, post_proc._REC_DTYPE)
             mine[i] = result_to_arrays(inst_h, rec_h, nr_types)
+            if return_raw:
+                mine[i].append(full.cpu().numpy())
         k += n
     every = gather_items_to_rank0(mine)          # the instance maps + record tables + contours travel as tensors to rank 0
     if every is None:                            # not rank 0: keeps only what it computed itself
         every = mine
-    return [arrays_to_result(every[i], nr_types, with_info=(return_centroids or nr_types is not None)) if i in every else None
-            for i in range(len(images))]
+    out = []
+    for i in range(len(images)):
+        if i not in every:
+            out.append(None)
+            continue
+        res = arrays_to_result(every[i][:4], nr_types, with_info=(return_centroids or nr_types is not None))
+        out.append(res + (np.array(every[i][4]),) if return_raw else res)
+    return out

@@ -1,6 +1,8 @@
 """-m gpu: the whole HIP network path through the reference-shaped interface
 (hover_net_amd.net_desc / run_desc) against the torch fp32 oracle and the golden logits made by
 the reference's own code.  Tolerance = BASELINE.json north_star: logits within 1e-3 (fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -111,6 +113,42 @@ def test_process_images_tile_pipeline():
     inst2, info2 = post_proc.process(np.ascontiguousarray(full), nr_types=5, return_centroids=True)
     np.testing.assert_array_equal(inst, inst2)
     assert sorted(info.keys()) == sorted(info2.keys())
+
+
+def test_process_file_list_end_to_end(tmp_path):
+    """infer/tile.py:150-387 through hover_net_amd.infer_manager: a directory of images (checkpoint loaded from a `.tar` with
+    DataParallel-prefixed keys) -> mat / json / overlay / qupath.  The written instance map equals the oracle on the written raw map."""
+    import json
+
+    import scipy.io as sio
+
+    from hover_net_amd import infer_manager
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    from oracle import process_np
+
+    sd = synth_state_dict("original", 5, seed=81)
+    torch.save({"desc": {"module." + k: v for k, v in sd.items()}}, tmp_path / "net.tar")
+    inp = tmp_path / "in"
+    inp.mkdir()
+    shapes = {"a": (270, 270), "b": (283, 300), "c": (120, 95)}
+    for i, (name, (h, w)) in enumerate(shapes.items()):
+        np.save(inp / (name + ".npy"), synth_tiles(1, 300, seed=82 + i)[0][:h, :w])
+    mgr = infer_manager.InferManager({"model_args": {"nr_types": 5, "mode": "original"}, "model_path": str(tmp_path / "net.tar")})
+    out = str(tmp_path / "out")
+    done = mgr.process_file_list({"input_dir": str(inp), "output_dir": out, "batch_size": 8, "save_raw_map": True, "save_qupath": True,
+                                  "draw_dot": True, "patch_input_shape": 270, "patch_output_shape": 80})
+    assert done == ["a", "b", "c"] and mgr.rounds == [3]
+    for name, (h, w) in shapes.items():
+        mat = sio.loadmat("%s/mat/%s.mat" % (out, name))
+        assert mat["inst_map"].shape == (h, w) and mat["raw_map"].shape == (h, w, 4) and mat["raw_map"].dtype == np.float32
+        o_inst, o_info = process_np.process(np.ascontiguousarray(mat["raw_map"]), 5, True)
+        np.testing.assert_array_equal(mat["inst_map"], o_inst)
+        assert mat["inst_uid"].reshape(-1).tolist() == list(o_info)
+        js = json.load(open("%s/json/%s.json" % (out, name)))["nuc"]
+        assert [int(k) for k in js] == list(o_info)
+        for k, v in o_info.items():
+            assert js[str(k)]["contour"] == v["contour"].tolist() and js[str(k)]["type"] == v["type"] and js[str(k)]["centroid"] == v["centroid"].tolist()
+        assert os.path.exists("%s/overlay/%s.png" % (out, name)) and os.path.exists("%s/qupath/%s.tsv" % (out, name))
 
 
 def test_two_stream_pipeline_equals_sequential():
