@@ -121,7 +121,7 @@ class InferManager:
     (infer/base.py:22-27 takes the same keywords).  `model=` hands over an already built network instead of a checkpoint
     (tests, in-process callers); `process_fn` replaces `infer_tile.process_images` (CPU tests of the host loop)."""
 
-    def __init__(self, method, type_info_path=None, device="cuda", model=None, process_fn=None):
+    def __init__(self, method, type_info_path=None, device="cuda", model=None, process_fn=None, load=True):
         self.method = method
         self.nr_types = method["model_args"]["nr_types"]
         self.mode = method["model_args"].get("mode", "original")
@@ -129,7 +129,7 @@ class InferManager:
         self.type_info_dict = load_type_info(self.nr_types, type_info_path)
         self.process_fn = process_fn
         self.model = model
-        if model is None and process_fn is None:
+        if model is None and process_fn is None and load:
             self.model = self._load_model(device)
 
     def _load_model(self, device):
@@ -205,3 +205,91 @@ class InferManager:
             to_qupath("%s/qupath/%s.tsv" % (output_dir, name), np.array([v["centroid"] for v in vals]).reshape(-1, 2),
                       np.array([v["type"] for v in vals]), self.type_info_dict)
         io_utils.save_json("%s/json/%s.json" % (output_dir, name), inst_info, None)
+
+
+# ----------------------------------------------------------------------------------------------
+def open_slide(path):
+    """Slide backend by extension.  `.npy` -> memory-mapped `ArraySlide`; plain images -> in-memory `ArraySlide`.
+    OpenSlide formats (`.svs`, `.ndpi`, ... -- misc/wsi_handler.py:84-99) need the openslide binding, which this image does
+    not have: they raise, and `process_wsi_list` logs the slide as crashed like the reference does (infer/wsi.py:744-749)."""
+    from .infer_wsi import ArraySlide
+
+    ext = pathlib.Path(path).suffix.lower()
+    if ext == ".npy":
+        return ArraySlide(np.load(path, mmap_mode="r"))
+    if ext in (".png", ".jpg", ".jpeg", ".tif", ".tiff", ".bmp"):
+        return ArraySlide(read_image(path))
+    raise ValueError("no slide backend for %r in this build (OpenSlide is not available)" % ext)
+
+
+def read_mask(path):
+    """infer/wsi.py:477-480: grey image, > 0 -> 1."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        return (np.asarray(im.convert("L")) > 0).astype(np.uint8)
+
+
+class WsiManager(InferManager):
+    """`infer/wsi.py:438-750` around `infer_wsi.WsiInference`: slide list, skip-if-done, mask file or the 1.25x heuristic,
+    `json/<name>.json` with `mag`, optional `thumb/` and `mask/`.  No cache directory: the prediction map lives in HBM and
+    the instance map in host RAM (`cache_path` is accepted and ignored).  `wsi_fn(slide, mask) -> (inst_map, inst_info)`
+    replaces the GPU run in CPU tests."""
+
+    def __init__(self, method, type_info_path=None, device="cuda", model=None, wsi_fn=None):
+        super().__init__(method, type_info_path, device, model, load=wsi_fn is None)
+        self.wsi_fn = wsi_fn
+
+    def process_wsi_list(self, run_args):
+        """run_args (run_infer.py:173-187): input_dir, output_dir, input_mask_dir, proc_mag, ambiguous_size, chunk_shape,
+        tile_shape, save_thumb, save_mask, batch_size.  Returns {name: "done" | "skip" | "empty mask" | "crash"}."""
+        import logging
+
+        from . import infer_tile, infer_wsi, tissue_mask
+
+        input_dir, output_dir = run_args["input_dir"], run_args["output_dir"]
+        mask_dir = run_args.get("input_mask_dir") or ""
+        save_thumb, save_mask = bool(run_args.get("save_thumb", False)), bool(run_args.get("save_mask", False))
+        proc_mag = run_args.get("proc_mag", 40)
+        _, rank, _world = infer_tile._dist()
+        nested = save_thumb or save_mask                     # infer/wsi.py:700-703: json goes under json/ only then
+        if rank == 0:
+            os.makedirs(output_dir + "/json/", exist_ok=True)
+            if save_thumb:
+                os.makedirs(output_dir + "/thumb/", exist_ok=True)
+            if save_mask:
+                os.makedirs(output_dir + "/mask/", exist_ok=True)
+        status = {}
+        for wsi_path in sorted(glob.glob(input_dir + "/*")):
+            if os.path.isdir(wsi_path):
+                continue
+            name = pathlib.Path(wsi_path).stem
+            json_path = ("%s/json/%s.json" if nested else "%s/%s.json") % (output_dir, name)
+            if os.path.exists(json_path):
+                status[name] = "skip"
+                continue
+            try:
+                slide = open_slide(wsi_path)
+                msk_path = "%s/%s.png" % (mask_dir, name)
+                mask = read_mask(msk_path) if os.path.isfile(msk_path) else tissue_mask.simple_get_mask(slide.thumbnail(32))
+                if int(np.sum(mask)) == 0:
+                    status[name] = "empty mask"
+                    continue
+                if rank == 0 and save_mask:
+                    viz.save_png("%s/mask/%s.png" % (output_dir, name), np.repeat((mask * 255).astype(np.uint8)[..., None], 3, -1))
+                if rank == 0 and save_thumb:
+                    viz.save_png("%s/thumb/%s.png" % (output_dir, name), slide.thumbnail(32))
+                if self.wsi_fn is not None:
+                    _inst_map, inst_info = self.wsi_fn(slide, mask)
+                else:
+                    wsi = infer_wsi.WsiInference(self.model, nr_types=self.nr_types, batch_size=int(run_args.get("batch_size", 32)),
+                                                 chunk_shape=int(run_args.get("chunk_shape", 10000)), tile_shape=int(run_args.get("tile_shape", 2048)),
+                                                 ambiguous_size=int(run_args.get("ambiguous_size", 128)))
+                    _inst_map, inst_info = wsi.run(slide, mask)
+                if rank == 0:
+                    io_utils.save_json(json_path, inst_info, mag=proc_mag)
+                status[name] = "done"
+            except Exception:                                 # noqa: BLE001  (the reference logs and moves on to the next slide)
+                logging.exception("Crash")
+                status[name] = "crash"
+        return status

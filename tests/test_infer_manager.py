@@ -154,3 +154,44 @@ def test_overlay_drawing():
     out = viz.visualize_instances_dict(img, {1: {"contour": np.array([[-3, 5], [25, 5]]), "centroid": [0.0, 0.0]}}, draw_dot=True)
     assert out[5, 10].any() and out[0, 0].tolist() == [255, 0, 0]
     assert viz.visualize_instances_dict(img, {}).sum() == 0
+
+
+def test_process_wsi_list(tmp_path):
+    """infer/wsi.py:698-750: sorted slide list, directories skipped, existing json skipped, mask file or heuristic, empty mask skipped,
+    a slide without a backend is logged as a crash and the list goes on; json carries `mag`."""
+    from PIL import Image
+
+    inp = tmp_path / "slides"
+    inp.mkdir()
+    (inp / "subdir").mkdir()
+    rng = np.random.default_rng(1)
+    tissue = rng.integers(30, 120, (640, 960, 3), dtype=np.uint8)
+    np.save(inp / "s1.npy", tissue)
+    np.save(inp / "s2.npy", tissue)
+    np.save(inp / "s3_blank.npy", np.full((640, 640, 3), 255, np.uint8))
+    (inp / "s4.svs").write_bytes(b"not a slide")
+    masks = tmp_path / "masks"
+    masks.mkdir()
+    m = np.zeros((20, 30), np.uint8)
+    m[5:10, 5:20] = 7
+    Image.fromarray(m).save(masks / "s1.png")
+    Image.fromarray(np.zeros((20, 20), np.uint8)).save(masks / "s3_blank.png")
+    calls = []
+
+    def wsi_fn(slide, mask):
+        calls.append((slide.shape[:2], int(mask.sum()), mask.dtype))
+        return None, {3: {"bbox": np.array([[1, 2], [3, 4]]), "centroid": np.array([2.5, 2.0]), "contour": np.array([[2, 1], [3, 3], [2, 3]]), "type_prob": None, "type": None}}
+
+    mgr = im.WsiManager({"model_args": {"nr_types": None, "mode": "fast"}, "model_path": None}, wsi_fn=wsi_fn)
+    out = str(tmp_path / "out")
+    args = {"input_dir": str(inp), "output_dir": out, "input_mask_dir": str(masks), "proc_mag": 40, "save_thumb": True, "save_mask": True}
+    st = mgr.process_wsi_list(args)
+    assert st == {"s1": "done", "s2": "done", "s3_blank": "empty mask", "s4": "crash"}
+    assert calls[0] == ((640, 960), 75, np.uint8)              # the mask file, binarised
+    assert calls[1][0] == (640, 960) and calls[1][1] > 0        # the thresholding heuristic on the 1.25x thumbnail
+    js = json.load(open(out + "/json/s1.json"))
+    assert js["mag"] == 40 and js["nuc"]["3"]["contour"] == [[2, 1], [3, 3], [2, 3]]
+    assert np.asarray(Image.open(out + "/mask/s1.png")).max() == 255 and np.asarray(Image.open(out + "/thumb/s2.png")).shape == (20, 30, 3)
+    assert mgr.process_wsi_list(args)["s1"] == "skip" and len(calls) == 2          # finished slides are not redone
+    st = mgr.process_wsi_list({"input_dir": str(inp), "output_dir": str(tmp_path / "flat")})
+    assert st["s2"] == "done" and os.path.exists(str(tmp_path / "flat") + "/s2.json")   # json at the top level without thumb / mask output
