@@ -69,6 +69,19 @@ double hvn_profile_conv_ms(void)
 
 int hvn_profile_conv_launches(void) { return (int)(g_ev_used / 2); }
 
+int hvn_profile_conv_ms_list(double *out, int cap)
+{
+    if (g_ev_used < 2) return 0;
+    hipEventSynchronize(g_ev[g_ev_used - 1]);
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_ev_used && n < cap; i += 2, ++n) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]);
+        out[n] = ms;
+    }
+    return n;
+}
+
 // ---- one op ---------------------------------------------------------------------------------
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -19,9 +19,9 @@
 //             A[i=l&31][k=l>>5] / B[k=l>>5][j=l&31]; the k-ORDER inside a chunk of 8
 //             is permuted (lanes <32 take k 0..3, lanes >=32 take k 4..7) so that each
 //             lane reads its 4 operands with ONE ds_read_b128 -- a sum is a sum.
-// LDS:        rows padded to 36 floats: the 16-lane groups of ds_read_b128 and the
-//             8-lane groups of ds_write_b128 then hit disjoint banks (MI355X_MICROARCH
-//             section LDS).
+// LDS:        rows of 32 floats with an XOR chunk swizzle (see LDS_LD below): the 16-lane
+//             groups of ds_read_b128 and ds_write_b128 hit disjoint banks without padding
+//             (MI355X_MICROARCH section LDS), and three 128x64 workgroups fit one CU.
 // Epilogue:   accumulators are transposed through LDS (the k-loop is done with it) so
 //             that every global access is 16 B per lane and 512 B contiguous per row:
 //             bias / ReLU / residual add / block-closing BN-ReLU are applied on float4s.
@@ -42,10 +42,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 struct copies lower to memcpy -> scratch
 
 #define BK 32
+// LDS row layout of the staged A / B tiles (rows of BK = 32 floats = eight 16-byte chunks):
+//   HVN_SWZ=1  (default) unpadded rows of 32 floats, chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the 16 lanes of one
+//              ds_read_b128 phase (16 consecutive rows, one logical chunk) cover all 64 banks -- rows 2k / 2k+1 share a chunk slot
+//              but lie in opposite bank halves.  The staging buffers are 1/9 smaller than with padding: a 128x64 tile needs 48 KB,
+//              so THREE workgroups fit a CU's 160 KB (128x32: four); measured in profiles/r02_experiments.md section 8.
+//   HVN_SWZ=0  rows padded to 36 floats (16-byte skew per row, the round-1 layout; 54 KB per 128x64 tile = two per CU).  Kept as
+//              the A/B build `libhvn_hip_pad.so` (lib.VARIANTS).
+#ifndef HVN_SWZ
+#define HVN_SWZ 1
+#endif
+#if HVN_SWZ
+#define LDS_LD 32
+#else
 #define LDS_LD 36  // padded row length in floats
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
-__global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
+__global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_igemm_f32(ConvArgs p)
 {
     // EXPERIMENT (off by default, HVN_STAGGER=1|2|3): two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe; giving
     // one of them a raised issue priority (told apart by LDS base or wave slot) or a delayed start was meant to keep one
@@ -73,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     constexpr int EP_LD = BN + 4;              // epilogue tile row length (floats)
     static_assert(WAVES_M * WAVES_N == 4, "256 threads");
     static_assert(!GROUPED || (BN == 32 && WM == 32 && WN == 32), "grouped mode: 4 groups x 8 output channels per 32-wide tile");
-    static_assert(BM * EP_LD <= 2 * (BM + BN) * LDS_LD, "epilogue tile must fit in the staging buffers");
+    // dynamic LDS = max(staging buffers, epilogue tile): see launch_conv
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                       // [2][BM][LDS_LD]
     float *Bs = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
@@ -99,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     // the k-loop then carries no vector address arithmetic at all.
     const int srow = tid >> 3;      // 0..31
     const int scol = (tid & 7) * 4; // float offset inside the 32-wide k chunk
+    const int lcol = HVN_SWZ ? (((tid & 7) ^ ((srow >> 1) & 7)) * 4) : scol;  // ... and where that chunk lives in the LDS row
     const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
     const unsigned n_blk = m0 / HoWo;                                        // sample of the tile's first row
     const long padoff = (long)p.pad_t * p.xsy + (long)p.pad_l * p.xsx;       // keeps every thread offset >= 0
@@ -218,10 +233,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
                 v.z = fmaxf(fmaf(v.z, ps.z, pb.z), pre_lo);
                 v.w = fmaxf(fmaf(v.w, ps.w, pb.w), pre_lo);
             }
-            *(f32x4 *)(a + (srow + 32 * j) * LDS_LD + scol) = v;
+            *(f32x4 *)(a + (srow + 32 * j) * LDS_LD + lcol) = v;
         }
 #pragma unroll
-        for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * LDS_LD + scol) = st.rb[j];
+        for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * LDS_LD + lcol) = st.rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -246,13 +261,15 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
         const int l15 = lane & 15, l4 = lane >> 4;
         const int grp = kt / taps;                 // slab == group (32 input channels per group)
         const int nt = grp >> 1;                   // column tile holding this group's 8 output channels
-        const float *a = As + cur * BM * LDS_LD + (wm * WM + l15) * LDS_LD + 4 * l4;
-        const float *b = Bs + cur * BN * LDS_LD + (nt * 16 + l15) * LDS_LD + 4 * l4;
+        const float *a = As + cur * BM * LDS_LD + (wm * WM + l15) * LDS_LD;
+        const float *b = Bs + cur * BN * LDS_LD + (nt * 16 + l15) * LDS_LD;
+        const int key = (l15 >> 1) & 7;             // rows +16 / +nt*16 leave bits 1..3 of the row alone
 #pragma unroll
         for (int c = Q0 / 2; c < (Q1 + 1) / 2; ++c) {  // chunks of 16 k (4 lane groups x 4)
-            const f32x4 fb = *(const f32x4 *)(b + c * 16);
-            const f32x4 fa0 = *(const f32x4 *)(a + c * 16);
-            const f32x4 fa1 = *(const f32x4 *)(a + 16 * LDS_LD + c * 16);
+            const int off = HVN_SWZ ? (((l4 + 4 * c) ^ key) * 4) : (4 * l4 + c * 16);
+            const f32x4 fb = *(const f32x4 *)(b + off);
+            const f32x4 fa0 = *(const f32x4 *)(a + off);
+            const f32x4 fa1 = *(const f32x4 *)(a + 16 * LDS_LD + off);
             if (nt == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -270,15 +287,17 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_f32(ConvArgs p)
     };
     auto compute = [&](int cur, auto q0c, auto q1c) {
         constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
-        const float *a = As + cur * BM * LDS_LD + (wm * WM + l31) * LDS_LD + 4 * lh;
-        const float *b = Bs + cur * BN * LDS_LD + (wn * WN + l31) * LDS_LD + 4 * lh;
+        const float *a = As + cur * BM * LDS_LD + (wm * WM + l31) * LDS_LD;
+        const float *b = Bs + cur * BN * LDS_LD + (wn * WN + l31) * LDS_LD;
+        const int key = (l31 >> 1) & 7;             // the +32-row steps and the wave's row base leave bits 1..3 of the row alone
 #pragma unroll
         for (int q = Q0; q < Q1; ++q) {
             f32x4 fa[TM], fb[TN];
+            const int off = HVN_SWZ ? (((2 * q + lh) ^ key) * 4) : (q * 8 + 4 * lh);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4 *)(a + i * 32 * LDS_LD + q * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *(const f32x4 *)(a + i * 32 * LDS_LD + off);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * LDS_LD + q * 8);
+            for (int j = 0; j < TN; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * LDS_LD + off);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -536,7 +555,8 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     p.dbg = dbg_on ? dbg_buf : nullptr;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t stage_fl = (size_t)2 * (BM + BN) * LDS_LD, ep_fl = (size_t)BM * (BN + 4);   // staging buffers / epilogue tile (floats)
+    const size_t lds = (stage_fl > ep_fl ? stage_fl : ep_fl) * sizeof(float);
     static bool attr_done = false;
     auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED, HAS_PRE, HAS_X2>;
     if (!attr_done) {

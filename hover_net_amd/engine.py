@@ -27,24 +27,32 @@ def _view_struct(v, base_ptr, sn, itemsize=4):
     return s
 
 
-WG_SLOTS = 512          # conv workgroups resident at once: 2 per CU (LDS) x 256 CUs
-NARROW_TILE_COST = 0.54  # a 128x64 tile's time relative to a 128x128 tile (half the MFMAs, A tile re-read, measured ~8 % less efficient)
+WG_SLOTS = 512            # resident 128x128 conv workgroups: 2 per CU (VGPRs) x 256 CUs
+WG_SLOTS_NARROW = 768     # resident 128x64 workgroups: 3 per CU (48 KB of LDS each with the swizzled layout, <= 168 VGPRs)
+NARROW_TILE_COST = 0.45   # time of a round of 128x64 tiles relative to a round of 128x128 tiles (3 x 1/2 vs 2 x 1 tiles of MFMA work per CU)
 
 
 def pick_tile_n(op, batch):
-    """Column tile (128 or 64) of a CONV launch by its wave quantisation: a launch of W workgroups runs in ceil(W / 512)
-    rounds, so 1092 workgroups of 128x128 tiles (2.13 rounds -> 3) lose 29 % to the last round, while 2184 workgroups of
-    128x64 tiles need 5 half-length rounds.  The packed weights are the same for both (cout is padded to 128).  Only plain
-    launches with cout >= 128 are re-tiled; HVN_TILE_SELECT=0 keeps the static choice of plan._tile_n."""
+    """Column tile (128 or 64) of a CONV launch by its wave quantisation -- the MODEL behind `HVN_TILE_SELECT=model` and the
+    starting point of the measured selection (`Engine.autotune_tiles`, the default): a launch of W workgroups runs in
+    ceil(W / slots) rounds, so 1092 workgroups of 128x128 tiles (2.13 rounds -> 3) lose 29 % to the last round.  The packed
+    weights are the same for both widths (cout is padded to 128) and so is every output bit (same k order per element).  Only
+    plain launches with cout >= 128 are re-tiled; HVN_TILE_SELECT=0 keeps the static choice of plan._tile_n.
+    Experiment knobs: HVN_FORCE_TILE_N=64|128, HVN_WG_SLOTS_64, HVN_NARROW_COST."""
     import math
     import os
 
-    if op.tile_n != 128 or os.environ.get("HVN_TILE_SELECT", "1") == "0":
+    if op.tile_n != 128 or os.environ.get("HVN_TILE_SELECT", "auto") == "0":
         return op.tile_n
+    force = os.environ.get("HVN_FORCE_TILE_N")
+    if force:
+        return int(force)
+    slots64 = int(os.environ.get("HVN_WG_SLOTS_64", WG_SLOTS_NARROW))
+    cost64 = float(os.environ.get("HVN_NARROW_COST", NARROW_TILE_COST))
     m_tiles = math.ceil(batch * op.y.h * op.y.w / 128.0)
     nb = int(op.extra.get("nbatch", 1))
     wide = math.ceil(m_tiles * math.ceil(op.cout / 128.0) * nb / WG_SLOTS)
-    narrow = math.ceil(m_tiles * math.ceil(op.cout / 64.0) * nb / WG_SLOTS) * NARROW_TILE_COST
+    narrow = math.ceil(m_tiles * math.ceil(op.cout / 64.0) * nb / slots64) * cost64
     return 64 if narrow < wide else 128
 
 
@@ -97,6 +105,9 @@ class Engine:
         self.ops = (L.hvn_op * len(plan.ops))()
         self._bind()
         self._sub_ops = {}
+        self.tile_choice = {}
+        if dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
+            self.autotune_tiles()
 
     # ---------------------------------------------------------------------------------
     def _upload_params(self):
@@ -188,6 +199,46 @@ class Engine:
             o.bias = self._pptr(i, "bias")
             o.pre_scale, o.pre_shift = self._pptr(i, "pre_s"), self._pptr(i, "pre_b")
             o.post_scale, o.post_shift = self._pptr(i, "post_s"), self._pptr(i, "post_b")
+
+    # ---------------------------------------------------------------------------------
+    def autotune_tiles(self, reps=3, margin=0.985):
+        """Measured column-tile selection (the default; `HVN_TILE_SELECT=model` keeps `pick_tile_n`'s rounds model): every
+        re-tileable CONV launch is timed once per distinct shape with 128x128 and with 128x64 tiles at this engine's batch
+        (min of `reps` HIP-event timings after a warm-up launch, on whatever the arena holds -- MFMA time does not depend
+        on the values) and gets the narrow tile when that is faster by more than 1.5 %.  Both widths produce the same bits
+        (identical k order per output element), so the choice is invisible in the results.  ~1 s per engine."""
+        lib = L.lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        osz = ctypes.sizeof(L.hvn_op)
+        base = ctypes.addressof(self.ops)
+
+        def time_op(i):
+            best = float("inf")
+            for r in range(reps + 1):
+                e0.record()
+                L.check(lib.hvn_run_op(base + i * osz, self.max_batch, ctypes.c_void_p(stream)), "hvn_run_op (autotune)")
+                e1.record()
+                e1.synchronize()
+                if r:
+                    best = min(best, e0.elapsed_time(e1))
+            return best
+
+        for i, op in enumerate(self.plan.ops):
+            if op.kind != PL.OP_CONV or op.tile_n != 128:
+                continue
+            x2 = op.extra.get("x2")
+            key = (op.kh, op.kw, op.stride, op.x.c, op.cout, op.y.h, op.y.w, op.x.h, op.x.w, op.res is not None, op.pre is not None,
+                   op.post is not None, int(op.extra.get("nbatch", 1)), x2.c if x2 is not None else 0)
+            if key not in self.tile_choice:
+                o = self.ops[i]
+                t = {}
+                for tn in (128, 64):
+                    o.tile_n = tn
+                    t[tn] = time_op(i)
+                self.tile_choice[key] = (64 if t[64] < margin * t[128] else 128, t[128], t[64])
+            self.ops[i].tile_n = self.tile_choice[key][0]
+        torch.cuda.synchronize(self.device)
 
     # ---------------------------------------------------------------------------------
     def _set_input(self, imgs):

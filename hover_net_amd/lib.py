@@ -6,6 +6,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhvn_hip.so")
+# Experiment builds of the same sources (`build_variant`), loaded INSTEAD of the default library when HVN_LIB_VARIANT names one:
+# kernel A/B runs on one box without rebuilding there.  Not used by the product path (unset = libhvn_hip.so).
+VARIANTS = {"pad": ("-DHVN_SWZ=0",)}     # padded LDS rows (round-1 layout) instead of the XOR swizzle
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("hvn_conv.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
            "hvn_train_api.hip", "hvn_contour.cpp")
@@ -47,7 +50,7 @@ class hvn_inst_rec(ctypes.Structure):
 
 EXPORTS = (
     "hvn_version", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
-    "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_postproc_workspace_bytes", "hvn_postproc",
+    "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_profile_conv_ms_list", "hvn_postproc_workspace_bytes", "hvn_postproc",
     "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
     "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
     "hvn_extract_patches", "hvn_gen_targets", "hvn_gen_targets_workspace_bytes",
@@ -71,6 +74,29 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def build_variant(name, verbose=False):
+    """`libhvn_hip_<name>.so`: the library compiled with VARIANTS[name]'s extra flags."""
+    out = os.path.join(_HERE, "libhvn_hip_%s.so" % name)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "hvn_kernels.h"), os.path.join(os.path.dirname(_HERE), "include", "hvn.h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["hipcc", *HIPCC_FLAGS, *VARIANTS[name], *srcs, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def lib_path():
+    v = os.environ.get("HVN_LIB_VARIANT", "")
+    if not v:
+        return LIB_PATH
+    if v not in VARIANTS:
+        raise HvnError("HVN_LIB_VARIANT=%r: unknown variant (known: %s)" % (v, ", ".join(VARIANTS)))
+    return os.path.join(_HERE, "libhvn_hip_%s.so" % v)
+
+
 _LIB = None
 
 
@@ -78,12 +104,14 @@ def lib():
     """The loaded library (ctypes.CDLL); raises HvnError if it has not been built."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise HvnError("libhvn_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(there is no CPU fallback for the HoVer-Net hot path)")
-        L = ctypes.CDLL(LIB_PATH)
+        path = lib_path()
+        if not os.path.exists(path):
+            raise HvnError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HoVer-Net hot path)" % os.path.basename(path))
+        L = ctypes.CDLL(path)
         L.hvn_last_error.restype = ctypes.c_char_p
         L.hvn_profile_conv_ms.restype = ctypes.c_double
+        L.hvn_profile_conv_ms_list.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.hvn_postproc_workspace_bytes.restype = ctypes.c_size_t
         L.hvn_postproc_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.hvn_run_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

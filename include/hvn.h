@@ -96,6 +96,8 @@ HVN_API int hvn_run_op(const hvn_op *op, int batch, void *stream);
 HVN_API int    hvn_profile_enable(int on);
 HVN_API double hvn_profile_conv_ms(void);
 HVN_API int    hvn_profile_conv_launches(void);
+/* the same measurements one by one, in launch order: fills out[0..min(cap, launches)) and returns that count */
+HVN_API int    hvn_profile_conv_ms_list(double *out, int cap);
 
 /* -- patch extraction: infer/tile.py:46-94 _prepare_patching (numpy "reflect" padding) + dataloader/infer_loader.py:59-72
  * img: dev uint8 [h][w][3] (the UNPADDED source image); coords: dev int32 [n_patches][2] = (y, x) top-left corners in the
