@@ -198,6 +198,10 @@ struct hvn_op;
 int hvn_internal_run_one(const hvn_op *op, int batch, hipStream_t s);
 
 // ---- training targets (hvn_targets.hip) ---------------------------------------------------------
+struct hvn_aug_sample;   // include/hvn.h
+int hvn_launch_aug_shape(const uint8_t *img, const int32_t *ann, int h, int w, int c, const struct hvn_aug_sample *prm, int n, int oh, int ow,
+                         uint8_t *oimg, int32_t *oann, hipStream_t stream);
+int hvn_launch_aug_input(const uint8_t *src, const struct hvn_aug_sample *prm, const float *noise, int n, int h, int w, uint8_t *dst, hipStream_t stream);
 size_t hvn_targets_ws_bytes(int n, int h, int w);
 int hvn_launch_gen_targets(const int32_t *ann, int n, int h, int w, int ch, int cw, float *hv, int32_t *np_map, void *ws, size_t ws_bytes,
                            hipStream_t stream);

@@ -205,6 +205,23 @@ int hvn_gen_targets(const int32_t *ann, int n, int h, int w, int crop_h, int cro
     return rc == -2 ? tfail(HVN_E_LAUNCH, "gen_targets launch failed", -1) : rc;
 }
 
+int hvn_augment_shape(const uint8_t *img, const int32_t *ann, int n_resident, int h, int w, int c, const hvn_aug_sample *prm, int n, int out_h,
+                      int out_w, uint8_t *out_img, int32_t *out_ann, void *stream)
+{
+    if (!img || !ann || !prm || !out_img || !out_ann || n_resident <= 0 || n <= 0 || h <= 0 || w <= 0 || c < 1 || c > 4 || out_h <= 0 || out_w <= 0 ||
+        out_h > h || out_w > w || (long)n_resident * h * w >= (1L << 40))
+        return tfail(HVN_E_ARG, "augment_shape: bad arguments", -1);
+    int rc = hvn_launch_aug_shape(img, ann, h, w, c, prm, n, out_h, out_w, out_img, out_ann, (hipStream_t)stream);
+    return rc ? tfail(HVN_E_LAUNCH, "augment_shape launch failed", -1) : 0;
+}
+
+int hvn_augment_input(const uint8_t *src, const hvn_aug_sample *prm, const float *noise, int n, int h, int w, uint8_t *dst, void *stream)
+{
+    if (!src || !prm || !dst || src == dst || n <= 0 || h <= 0 || w <= 0) return tfail(HVN_E_ARG, "augment_input: bad arguments", -1);
+    int rc = hvn_launch_aug_input(src, prm, noise, n, h, w, dst, (hipStream_t)stream);
+    return rc ? tfail(HVN_E_LAUNCH, "augment_input launch failed", -1) : 0;
+}
+
 int hvn_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
                   void *stream)
 {

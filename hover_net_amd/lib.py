@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libhvn_hip.so")
 VARIANTS = {"pad": ("-DHVN_SWZ=0",)}     # padded LDS rows (round-1 layout) instead of the XOR swizzle
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("hvn_conv.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
-           "hvn_train_api.hip", "hvn_contour.cpp")
+           "hvn_augment.hip", "hvn_train_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fvisibility=hidden", "-Wno-unused-value", "-pthread")
 
@@ -53,7 +53,7 @@ EXPORTS = (
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_profile_conv_ms_list", "hvn_postproc_workspace_bytes", "hvn_postproc",
     "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
     "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
-    "hvn_extract_patches", "hvn_gen_targets", "hvn_gen_targets_workspace_bytes",
+    "hvn_extract_patches", "hvn_gen_targets", "hvn_gen_targets_workspace_bytes", "hvn_augment_shape", "hvn_augment_input",
 )
 
 
@@ -135,6 +135,10 @@ def lib():
         L.hvn_gen_targets_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.hvn_gen_targets.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.hvn_augment_shape.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.hvn_augment_input.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p]
         L.hvn_train_last_error.restype = ctypes.c_char_p
         L.hvn_run_train_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.hvn_loss_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -218,6 +218,32 @@ HVN_API size_t hvn_gen_targets_workspace_bytes(int n, int h, int w);
 HVN_API int hvn_gen_targets(const int32_t *ann, int n, int h, int w, int crop_h, int crop_w, float *hv_map, int32_t *np_map,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* Training-time augmentation of a RESIDENT patch set: dataloader/train_loader.py:76-199 (FileLoader.__getitem__ + __get_augmentation)
+ * and the image functions of dataloader/augs.py:36-113.  One record per OUTPUT sample, drawn on the host:
+ *   shape part (image + annotation): out(y, x) = in[src](round_half_up(inv * (x', y', 1))) or 0 outside, where (x', y') is the
+ *   output pixel after the flips, offset to the centre-crop window of the source patch (CropToFixedSize / cropping_center);
+ *   input part (image only): kind 0 = cv2.GaussianBlur((p0, p1), 0) | 1 = cv2.medianBlur(p0) | 2 = additive Gaussian noise
+ *   (noise_scale * z, z from the caller's N(0,1) buffer, one plane if !per_channel) | 3 = none; then order[0..3] in turn:
+ *   0 = add_to_hue(hue), 1 = add_to_saturation(sat = 1 + draw), 2 = add_to_brightness(bright), 3 = add_to_contrast (returns its
+ *   input unchanged in the reference, augs.py:96-97), < 0 = skip. */
+typedef struct hvn_aug_sample {
+    double  inv[6];            /* destination -> source affine: x_s = inv[0] x + inv[1] y + inv[2], y_s = inv[3] x + inv[4] y + inv[5] */
+    int32_t src;               /* index of the source patch in the resident set */
+    int32_t flip_lr, flip_ud;
+    int32_t kind, p0, p1;
+    int32_t per_channel;
+    float   noise_scale;
+    int32_t order[4];
+    double  hue, sat, bright, contrast;
+} hvn_aug_sample;
+/* img: dev uint8 [P][h][w][3], ann: dev int32 [P][h][w][c] (c = 1 or 2: instance ids, types); out_img: dev uint8 [n][oh][ow][3],
+ * out_ann: dev int32 [n][oh][ow][c]; prm: dev hvn_aug_sample[n] with 0 <= src < P. */
+HVN_API int hvn_augment_shape(const uint8_t *img, const int32_t *ann, int n_resident, int h, int w, int c, const hvn_aug_sample *prm, int n,
+                              int out_h, int out_w, uint8_t *out_img, int32_t *out_ann, void *stream);
+/* src / dst: dev uint8 [n][h][w][3] (must not alias: the blurs read neighbours); noise: dev float32 [n][h][w][3] standard normal samples
+ * (may be NULL when no record has kind 2). */
+HVN_API int hvn_augment_input(const uint8_t *src, const hvn_aug_sample *prm, const float *noise, int n, int h, int w, uint8_t *dst, void *stream);
+
 /* torch.optim.Adam (opt.py:38-44: lr 1e-4, betas (0.9, 0.999), eps 1e-8, no weight decay) over flat dev slabs;
  * step = 1 for the first update. */
 HVN_API int hvn_adam_step(float *w, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
