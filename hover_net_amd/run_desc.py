@@ -87,9 +87,9 @@ def train_step(batch_data, run_info):
     didx = idx.to(eng.device)
     prob_np = torch.softmax(eng.logits["np"][didx], 1)[:, 1].cpu().numpy()
     pred_hv = eng.logits["hv"][didx].permute(0, 2, 3, 1).cpu().numpy()
-    true_np = torch.as_tensor(batch_data["np_map"])[idx].type(torch.int64).numpy()
-    true_hv = torch.as_tensor(batch_data["hv_map"])[idx].type(torch.float32).numpy()
-    result["raw"] = {"img": torch.as_tensor(imgs)[idx].byte().numpy(), "np": (true_np, prob_np), "hv": (true_hv, pred_hv)}
+    true_np = torch.as_tensor(batch_data["np_map"])[idx].type(torch.int64).cpu().numpy()      # .cpu(): the feed may already live on the device
+    true_hv = torch.as_tensor(batch_data["hv_map"])[idx].type(torch.float32).cpu().numpy()
+    result["raw"] = {"img": torch.as_tensor(imgs)[idx].byte().cpu().numpy(), "np": (true_np, prob_np), "hv": (true_hv, pred_hv)}
     return result
 
 
@@ -100,15 +100,15 @@ def valid_step(batch_data, run_info):
     model = run_info["net"]["desc"]
     net = _unwrap(model)
     imgs = batch_data["img"]
-    true_np = torch.squeeze(batch_data["np_map"]).type(torch.int64)
-    true_hv = torch.squeeze(batch_data["hv_map"]).type(torch.float32)
+    true_np = torch.squeeze(batch_data["np_map"]).type(torch.int64).cpu()        # .cpu(): a device-resident feed (augment.DevicePatchLoader) is fine too
+    true_hv = torch.squeeze(batch_data["hv_map"]).type(torch.float32).cpu()
     pred = infer_step_device(imgs, model)            # [N,h,w,3|4] = [type?, p_nuc, h, v] on the device
     pred = pred.cpu()
     c0 = 0 if net.nr_types is None else 1
-    result = {"raw": {"imgs": imgs.numpy(), "true_np": true_np.numpy(), "true_hv": true_hv.numpy(),
+    result = {"raw": {"imgs": imgs.cpu().numpy(), "true_np": true_np.numpy(), "true_hv": true_hv.numpy(),
                       "prob_np": pred[..., c0].numpy().copy(), "pred_hv": pred[..., c0 + 1:c0 + 3].numpy().copy()}}
     if net.nr_types is not None:
-        result["raw"]["true_tp"] = torch.squeeze(batch_data["tp_map"]).type(torch.int64).numpy()
+        result["raw"]["true_tp"] = torch.squeeze(batch_data["tp_map"]).type(torch.int64).cpu().numpy()
         result["raw"]["pred_tp"] = pred[..., 0].numpy().copy()
     return result
 

@@ -1,0 +1,79 @@
+"""CPU: sanity of the augmentation oracle (oracle/augment_np.py) against independent references that ARE available here --
+numpy's own rot90 / flips, python's colorsys for the HSV conversions (to the 8-bit rounding), exact identities.  imgaug and cv2
+themselves are absent: the oracle's header says "parity unpinned" for their sub-pixel / rounding conventions."""
+import colorsys
+
+import numpy as np
+
+from oracle import augment_np as A
+
+
+def _img(seed=0, shape=(40, 50)):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, shape + (3,), dtype=np.uint8), rng.integers(0, 5, shape + (2,)).astype(np.int32)
+
+
+def test_shape_identity_crop_flips_and_quarter_turn():
+    img, ann = _img()
+    o, a = A.shape_augment(img, ann, np.eye(3), (20, 30), False, False)
+    assert np.array_equal(o, img[10:30, 10:40]) and np.array_equal(a, ann[10:30, 10:40])      # cropping_center
+    o2, a2 = A.shape_augment(img, ann, np.eye(3), (20, 30), True, True)
+    assert np.array_equal(o2, o[::-1, ::-1]) and np.array_equal(a2, a[::-1, ::-1])
+    sq = np.random.default_rng(1).integers(0, 256, (31, 31, 3), dtype=np.uint8)
+    fwd = A.affine_matrix(31, 31, (1, 1), (0, 0), 0, 90)
+    o3, _ = A.shape_augment(sq, np.zeros((31, 31, 1), np.int32), np.linalg.inv(fwd), (31, 31), False, False)
+    assert np.array_equal(o3, np.rot90(sq, 3))                # +90 degrees with y pointing down = clockwise
+    # translation moves content by whole pixels; what comes from outside is 0
+    fwd = A.affine_matrix(31, 31, (1, 1), (3, -2), 0, 0)
+    o4, _ = A.shape_augment(sq, np.zeros((31, 31, 1), np.int32), np.linalg.inv(fwd), (31, 31), False, False)
+    assert np.array_equal(o4[:-2, 3:], sq[2:, :-3]) and not o4[-2:].any() and not o4[:, :3].any()
+    # scale 2 about the centre: nearest-neighbour pixel doubling around the centre pixel
+    fwd = A.affine_matrix(31, 31, (2, 2), (0, 0), 0, 0)
+    o5, _ = A.shape_augment(sq, np.zeros((31, 31, 1), np.int32), np.linalg.inv(fwd), (31, 31), False, False)
+    assert np.array_equal(o5[15, 15], sq[15, 15]) and np.array_equal(o5[15, 18], sq[15, 17]) and np.array_equal(o5[11, 15], sq[13, 15])
+
+
+def test_hsv_conversions_agree_with_colorsys_to_8bit_rounding():
+    img, _ = _img(2)
+    hsv = A.rgb2hsv_u8(img)
+    ref = np.array([[colorsys.rgb_to_hsv(*(p / 255.0)) for p in row] for row in img])
+    dh = np.abs(((hsv[..., 0] - ref[..., 0] * 180 + 90) % 180) - 90)
+    sat = ref[..., 1] > 0.05                                   # hue of near-grey pixels is ill-conditioned
+    assert dh[sat].max() <= 1.0 and np.abs(hsv[..., 1] - ref[..., 1] * 255).max() <= 1.0 and np.array_equal(hsv[..., 2], img.max(-1))
+    back = A.hsv2rgb_u8(hsv)
+    ref_back = np.array([[colorsys.hsv_to_rgb(h / 180.0, s / 255.0, v / 255.0) for h, s, v in row] for row in hsv]) * 255
+    assert np.abs(back - ref_back).max() <= 0.5 + 1e-3          # exact HSV -> RGB of the quantised triple, rounded
+    grey = np.full((4, 4, 3), 90, np.uint8)
+    assert np.array_equal(A.rgb2hsv_u8(grey)[..., :2], np.zeros((4, 4, 2))) and np.array_equal(A.hsv2rgb_u8(A.rgb2hsv_u8(grey)), grey)
+    assert np.abs(A.rgb2gray_u8(img) - img @ np.array([0.299, 0.587, 0.114])).max() <= 0.51
+
+
+def test_colour_ops_identities_and_reference_quirks():
+    img, _ = _img(3)
+    assert np.array_equal(A.add_to_saturation(img, 1.0), img) and np.array_equal(A.add_to_brightness(img, 0.0), img)
+    assert np.array_equal(A.add_to_contrast(img, 0.75), img)   # augs.py:96-97: the contrast op returns its input
+    assert np.array_equal(A.add_to_saturation(img, 0.0), np.repeat(A.rgb2gray_u8(img)[..., None], 3, -1))
+    b = A.add_to_brightness(img, 300.0)
+    assert b.min() == 255 and A.add_to_brightness(img, -300.0).max() == 0
+    assert np.array_equal(A.add_to_brightness(img, 10.7), np.clip(img.astype(int) + 10, 0, 255))      # truncation, not rounding
+    h0 = A.rgb2hsv_u8(img)
+    h1 = A.rgb2hsv_u8(A.add_to_hue(img, 7.0))
+    satur = h0[..., 1] > 60
+    d = (h1[..., 0].astype(int) - h0[..., 0].astype(int)) % 180
+    assert np.median(d[satur]) == 7
+
+
+def test_blurs():
+    img, _ = _img(4)
+    assert np.array_equal(A.gaussian_blur(img, 1, 1), img) and np.array_equal(A.median_blur(img, 1), img)
+    flat = np.full((9, 9, 3), 77, np.uint8)
+    assert np.array_equal(A.gaussian_blur(flat, 5, 3), flat) and np.array_equal(A.median_blur(flat, 5), flat)
+    f = img.astype(np.float64)
+    p = np.pad(f, ((0, 0), (1, 1), (0, 0)), "edge")
+    want = np.floor((p[:, :-2] + 2 * p[:, 1:-1] + p[:, 2:]) / 4 + 0.5)
+    assert np.array_equal(A.gaussian_blur(img, 3, 1), want.astype(np.uint8))
+    spike = flat.copy()
+    spike[4, 4] = 255
+    assert np.array_equal(A.median_blur(spike, 3), flat)
+    assert np.array_equal(A.additive_noise(flat, np.full((9, 9, 1), 2.5, np.float32)), flat + 2)       # rint: half to even
+    assert A.additive_noise(flat, np.full((9, 9, 3), -500.0, np.float32)).max() == 0
