@@ -160,10 +160,13 @@ class DevicePatchLoader:
         mine = len(range(self.rank, self.img.shape[0], self.world))
         return mine // self.batch_size if self.mode == "train" else -(-mine // self.batch_size)
 
-    def batch(self, prm, noise=None):
-        """The device pipeline for one batch of parameter records."""
+    def batch(self, prm, noise=None, generator=None):
+        """The device pipeline for one batch of parameter records.  `noise` / `generator`: the N(0,1) samples of the additive-noise
+        records, or the torch device generator to draw them with (the loader seeds one per epoch and rank)."""
         img, ann = augment_shape(self.img, self.ann, prm, self.input_shape)
         if (prm["kind"] != 3).any() or (prm["order"] >= 0).any():
+            if noise is None and (prm["kind"] == 2).any():
+                noise = torch.randn((len(prm),) + self.input_shape + (3,), dtype=torch.float32, device=self.device, generator=generator)
             img = augment_input(img, prm, noise)
         feed = {"img": img}
         if self.with_type:
@@ -175,10 +178,14 @@ class DevicePatchLoader:
         p, h, w = self.img.shape[:3]
         order_rng = np.random.default_rng([self.seed, self.epoch])                 # the same permutation on every rank
         rng = np.random.default_rng([self.seed, self.epoch, self.rank + 1])        # this rank's augmentation draws
+        gen = None
+        if self.device.type == "cuda":                                              # ... and its noise samples
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(int(rng.integers(0, 2 ** 62)))
         self.epoch += 1
         order = order_rng.permutation(p) if self.mode == "train" else np.arange(p)
         mine = order[self.rank::self.world]
         for b in range(len(self)):
             src = mine[b * self.batch_size:(b + 1) * self.batch_size]
             prm = draw_params(rng, src, h, w) if self.mode == "train" else identity_params(len(src), src)
-            yield self.batch(prm)
+            yield self.batch(prm, generator=gen)

@@ -45,7 +45,7 @@ def test_loader_epochs_and_rank_slices(monkeypatch):
     seen = {}
     for rank in range(2):
         ld = G.DevicePatchLoader(data, (4, 4), (2, 2), batch_size=2, mode="train", with_type=True, seed=3, device="cpu", rank=rank, world=2)
-        monkeypatch.setattr(ld, "batch", lambda prm, noise=None: prm["src"].copy())
+        monkeypatch.setattr(ld, "batch", lambda prm, noise=None, generator=None: prm["src"].copy())
         assert len(ld) == (3 if rank == 0 else 2)                # 6 / 5 patches per rank, ragged batch dropped
         seen[rank] = [np.concatenate(list(ld)) for _epoch in range(2)]
     for epoch in range(2):
@@ -53,6 +53,6 @@ def test_loader_epochs_and_rank_slices(monkeypatch):
         assert len(set(a) & set(b)) == 0 and len(set(a) | set(b)) == 10      # disjoint slices of ONE permutation (one patch dropped)
     assert not np.array_equal(seen[0][0], seen[0][1])                            # reshuffled every epoch
     ld = G.DevicePatchLoader(data, (4, 4), (2, 2), batch_size=4, mode="valid", device="cpu")
-    monkeypatch.setattr(ld, "batch", lambda prm, noise=None: (prm["src"].copy(), prm["kind"].copy()))
+    monkeypatch.setattr(ld, "batch", lambda prm, noise=None, generator=None: (prm["src"].copy(), prm["kind"].copy()))
     out = list(ld)
     assert [o[0].tolist() for o in out] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]] and all((o[1] == 3).all() for o in out)   # in order, ragged batch kept
