@@ -8,6 +8,8 @@ oracle/hvn_oracle.c.  The scipy / skimage / numpy parts of the golden vectors ar
 therefore the real thing; the cv2 image filters are the C restatement, cross-checked by a second,
 scipy-based stand-in (oracle/cv2_shim_scipy/cv2.py, tests/test_oracle_cv2_independent.py);
 moments / findContours (post_proc.py:131-135) are python (_suzuki.py).
+For the reference's dataloader/augs.py (oracle/make_golden_augs.py) the 8-bit GaussianBlur / medianBlur / cvtColor entry points
+resolve to oracle/augment_np.py: the numpy glue of the six augmentation functions is then the reference's own code.
 """
 import os
 import sys
@@ -25,6 +27,8 @@ MORPH_ELLIPSE = 2
 RETR_TREE = 3
 CHAIN_APPROX_SIMPLE = 2
 COLOR_BGR2RGB = 4
+COLOR_RGB2GRAY, COLOR_RGB2HSV, COLOR_HSV2RGB = 7, 41, 55
+BORDER_REPLICATE = 1
 
 
 def normalize(src, dst=None, alpha=0, beta=1, norm_type=NORM_MINMAX, dtype=CV_32F):
@@ -41,9 +45,27 @@ def Sobel(src, ddepth, dx, dy, ksize=3):
     return _o.sobel21(src, dx)
 
 
-def GaussianBlur(src, ksize, sigmaX):
+def GaussianBlur(src, ksize, sigmaX, sigmaY=0, borderType=None):
+    if src.dtype == np.uint8:          # dataloader/augs.py:42-44 (8-bit image, ksize in {1,3,5}^2, BORDER_REPLICATE): oracle/augment_np.py
+        import augment_np as _a
+        assert sigmaX == 0 and sigmaY == 0 and borderType == BORDER_REPLICATE
+        return _a.gaussian_blur(src, int(ksize[0]), int(ksize[1]))
     assert tuple(ksize) == (3, 3) and sigmaX == 0 and src.dtype == np.float64
     return _o.gauss3_64f(src)
+
+
+def medianBlur(src, ksize):
+    """dataloader/augs.py:56."""
+    import augment_np as _a
+    assert src.dtype == np.uint8
+    return _a.median_blur(src, int(ksize))
+
+
+def cvtColor(src, code):
+    """dataloader/augs.py:66,74,83 on 8-bit images."""
+    import augment_np as _a
+    assert src.dtype == np.uint8
+    return {COLOR_RGB2HSV: _a.rgb2hsv_u8, COLOR_HSV2RGB: _a.hsv2rgb_u8, COLOR_RGB2GRAY: _a.rgb2gray_u8}[code](src)
 
 
 def getStructuringElement(shape, ksize):

@@ -77,6 +77,29 @@ def test_input_kernel_matches_oracle():
     np.testing.assert_array_equal(out[10], img[10])
 
 
+def test_input_kernel_equals_the_references_own_functions():
+    """Each op alone against tests/golden/augs.npz = outputs of the reference's unmodified dataloader/augs.py functions."""
+    import os
+
+    from hover_net_amd import augment as G
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augs.npz"))
+    img = torch.from_numpy(g["img"]).cuda()
+
+    def run(n, **fields):
+        prm = G.identity_params(n)
+        for k, v in fields.items():
+            prm[k] = v
+        return G.augment_input(img[:n].contiguous(), prm).cpu().numpy()
+
+    np.testing.assert_array_equal(run(6, kind=0, p0=g["gauss_k"][:, 0], p1=g["gauss_k"][:, 1]), g["gauss_out"])
+    np.testing.assert_array_equal(run(3, kind=1, p0=g["median_k"]), g["median_out"])
+    np.testing.assert_array_equal(run(6, order=[[0, -1, -1, -1]] * 6, hue=g["hue_val"]), g["hue_out"])
+    np.testing.assert_array_equal(run(6, order=[[-1, 1, -1, -1]] * 6, sat=1 + g["sat_val"]), g["sat_out"])
+    np.testing.assert_array_equal(run(6, order=[[-1, -1, 2, -1]] * 6, bright=g["bright_val"]), g["bright_out"])
+    np.testing.assert_array_equal(run(6, order=[[-1, -1, -1, 3]] * 6, contrast=g["contrast_val"]), g["contrast_out"])
+
+
 def test_resident_loader_end_to_end():
     from hover_net_amd import augment as G
     from hover_net_amd import targets as T
@@ -113,7 +136,7 @@ def test_loader_feeds_train_step():
     from hover_net_amd import net_desc, optim, run_desc
     from hover_net_amd.synth import synth_state_dict
 
-    img, ann = _resident(p=4, h=300, w=300, seed=4)
+    img, ann = _resident(p=2, h=300, w=300, seed=4)          # one training batch: the engine build dominates this test
     data = np.concatenate([img.astype(np.int32), ann], -1)
     ld = G.DevicePatchLoader(data, (270, 270), (80, 80), batch_size=2, mode="train", with_type=True, seed=1)
     net = net_desc.create_model(mode="original", nr_types=5, input_ch=3, freeze=True)

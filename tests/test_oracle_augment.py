@@ -77,3 +77,21 @@ def test_blurs():
     assert np.array_equal(A.median_blur(spike, 3), flat)
     assert np.array_equal(A.additive_noise(flat, np.full((9, 9, 1), 2.5, np.float32)), flat + 2)       # rint: half to even
     assert A.additive_noise(flat, np.full((9, 9, 3), -500.0, np.float32)).max() == 0
+
+
+def test_oracle_equals_the_references_own_functions():
+    """tests/golden/augs.npz: outputs of the reference's unmodified dataloader/augs.py (oracle/make_golden_augs.py, cv2 entry points =
+    this oracle's restatements) -- pins the glue: draw -> kernel size, float64 promotion, `% 180`, clip + truncation, the contrast no-op."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augs.npz"))
+    img = g["img"]
+    for k in range(6):
+        assert np.array_equal(A.gaussian_blur(img[k], *g["gauss_k"][k]), g["gauss_out"][k])
+        assert np.array_equal(A.add_to_hue(img[k], g["hue_val"][k]), g["hue_out"][k])
+        assert np.array_equal(A.add_to_saturation(img[k], 1 + g["sat_val"][k]), g["sat_out"][k])
+        assert np.array_equal(A.add_to_brightness(img[k], g["bright_val"][k]), g["bright_out"][k])
+        assert np.array_equal(A.add_to_contrast(img[k], g["contrast_val"][k]), g["contrast_out"][k])
+        assert np.array_equal(g["contrast_out"][k], img[k])
+    for k in range(3):
+        assert np.array_equal(A.median_blur(img[k], g["median_k"][k]), g["median_out"][k])
