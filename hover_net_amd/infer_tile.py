@@ -270,11 +270,35 @@ def run_sharded(items, step_fn, batch_size):
 
 
 # --------------------------------------------------------------------------------------------
-def process_images(images, model, nr_types=None, batch_size=32, return_centroids=True, return_raw=False):
+def process_images(images, model, nr_types=None, batch_size=32, return_centroids=True, return_raw=False, max_patches=16384):
     """images: list of uint8 [H,W,3] arrays (RGB).  Returns a list of (pred_inst int32 [H,W] numpy, inst_info_dict | None)
     in input order: complete on rank 0 (the writer); the other ranks hold their own images' results and None elsewhere.
     `return_raw=True` appends the stitched float32 prediction map [H,W,3|4] to each tuple (`--save_raw_map`,
     infer/tile.py:193-194); it travels to rank 0 with the other arrays.
+    The images are worked off in groups of at most `max_patches` network patches (3.6 GB of uint8 patches + 1.7 GB of maps at the
+    default), so that a large cache round of `process_file_list` never has all its overlapping patches in HBM at once; every rank
+    forms the same groups (the collectives inside stay matched)."""
+    win = 270 if (model.module if hasattr(model, "module") and not hasattr(model, "engine") else model).mode == "original" else 256
+    msk = 80 if win == 270 else 164
+    groups, cur, cur_n = [], [], 0
+    for i, img in enumerate(images):
+        n = patch_grid(img.shape, win, msk)[0].shape[0]
+        if cur and cur_n + n > max_patches:
+            groups.append(cur)
+            cur, cur_n = [], 0
+        cur.append(i)
+        cur_n += n
+    if cur:
+        groups.append(cur)
+    out = [None] * len(images)
+    for grp in groups:
+        for i, res in zip(grp, _process_image_group([images[i] for i in grp], model, nr_types, batch_size, return_centroids, return_raw)):
+            out[i] = res
+    return out
+
+
+def _process_image_group(images, model, nr_types, batch_size, return_centroids, return_raw):
+    """One group of `process_images`.
 
     Pipeline per call: host patch extraction -> sharded HIP network (`run_desc.infer_step_device`)
     -> one all_gather of the per-patch maps -> per-image stitch on the GPU -> on-GPU instance

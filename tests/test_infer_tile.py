@@ -130,3 +130,26 @@ def test_device_patch_extraction_equals_host_reflect_padding(shape, win, msk):
     info2, pad_tl = T.patch_grid(shape, win, msk)
     got = T.extract_patches_device(torch.from_numpy(img).cuda(), info2, win, pad_tl).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def test_process_images_bounds_the_patches_in_flight(monkeypatch):
+    """A large cache round is worked off in groups of <= max_patches network patches (an oversized image goes alone); the results
+    come back in input order."""
+    class Net:
+        mode = "original"
+
+    calls = []
+
+    def fake_group(images, model, nr_types, batch_size, return_centroids, return_raw):
+        calls.append([im.shape[0] for im in images])
+        return [("res", im.shape[0]) for im in images]
+
+    monkeypatch.setattr(T, "_process_image_group", fake_group)
+    sizes = [80, 160, 240, 1000, 80, 80]            # 1, 4, 9, 169, 1, 1 patches of an 80-pixel output step
+    imgs = [np.zeros((s, s, 3), np.uint8) for s in sizes]
+    out = T.process_images(imgs, Net(), max_patches=12)
+    assert calls == [[80, 160], [240], [1000], [80, 80]]
+    assert [o[1] for o in out] == sizes
+    calls.clear()
+    T.process_images(imgs, Net())
+    assert calls == [sizes]
