@@ -128,6 +128,32 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
                      a.pre_s || (long)(a.Ho - 1) * a.stride2 >= op->x2.h || (long)(a.Wo - 1) * a.stride2 >= op->x2.w))
             return fail(HVN_E_ARG, "conv: second input needs a 1x1 stride-1 op without prologue and a view that covers the output grid%s", "");
         a.M = (long)batch * a.Ho * a.Wo;
+        {   // EXPERIMENT, timing only (results are garbage): address dense 1x1 operands channel-BLOCKED, [C/32][H][W][32], inside the same buffers.
+            // HVN_EXP_BLOCKED bit 0 = input, bit 1 = output + residual.  profiles/r02_experiments.md section 9.
+            static int blk = -1, bsz = 32;
+            if (blk < 0) {
+                const char *e = getenv("HVN_EXP_BLOCKED");
+                blk = e ? atoi(e) : 0;
+                const char *b = getenv("HVN_EXP_BLOCK");     // channels per block: 32 (default) or 128
+                bsz = b ? atoi(b) : 32;
+            }
+            const bool plain = op->kh == 1 && op->kw == 1 && a.stride == 1 && !a.x2 && op->nbatch <= 1 && op->act_dtype == 0;
+            if (blk && plain && (bsz == 32 || bsz == 128)) {
+                bool any = false;
+                if ((blk & 1) && a.xsx == a.Cin && a.xsy == (long)a.W * a.Cin && a.xsn >= (long)a.H * a.W * a.Cin && a.H == a.Ho && a.W == a.Wo && a.Cin % bsz == 0) {
+                    a.xsb = (long)a.H * a.W * bsz; a.xsx = bsz; a.xsy = (long)a.W * bsz;
+                    any = true;
+                }
+                if ((blk & 2) && a.ysx == a.Cout && a.ysy == (long)a.Wo * a.Cout && a.ysn >= (long)a.Ho * a.Wo * a.Cout && a.Cout % bsz == 0) {
+                    a.ysb = (long)a.Ho * a.Wo * bsz; a.ysx = bsz; a.ysy = (long)a.Wo * bsz;
+                    any = true;
+                    if (a.res && a.rsx == a.Cout && a.rsy == (long)a.Wo * a.Cout && a.rsn >= (long)a.Ho * a.Wo * a.Cout) {
+                        a.rsb = a.ysb; a.rsx = bsz; a.rsy = a.ysy;
+                    }
+                }
+                if (any) a.blk_shift = bsz == 32 ? 5 : 7;
+            }
+        }
         if (!a.x || !a.w || !a.y) return fail(HVN_E_ARG, "conv: null pointer%s", "");
         if (a.Cin % 32) return fail(HVN_E_ARG, "conv: input channels must be a multiple of 32 (got %s%ld)", "", a.Cin);
         if (!aligned16(a.x) || !aligned16(a.w) || (a.xsx & 3) || (a.xsy & 3) || (a.xsn & 3))

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
 
     // issue the raw loads of one k-step (nothing here waits on memory)
     auto load_global = [&](Stage &st, int kt) {
-        int a_soff = (int)(((long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BK) * 4);  // uniform (SALU)
+        // uniform (SALU).  Channels-last: slab ld_c starts at channel 32 ld_c.  Blocked experiment: block (ld_c >> s) + slab (ld_c & mask) inside it
+        const unsigned cs = p.blk_shift ? (unsigned)p.blk_shift - 5u : 31u;
+        int a_soff = (int)(((long)ld_r * p.xsy + (long)ld_s * p.xsx + (long)((unsigned)ld_c >> cs) * p.xsb + (long)((unsigned)ld_c & ((1u << cs) - 1u)) * BK) * 4);
         const int w_soff = kt * (BK * 4);
         const bool second = HAS_X2 && kt >= KT1;                                             // uniform
         if constexpr (HAS_X2) a_soff = second ? (kt - KT1) * (BK * 4) : a_soff;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const unsigned m = m0 + erow0 + it * RPP;
-            const long ro = (m < M && cok) ? (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co : 0;
+            const long ro = (m < M && cok) ? (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + (p.rsb ? (long)(co >> p.blk_shift) * p.rsb + (co & ((1 << p.blk_shift) - 1)) : (long)co) : 0;
             rall[it] = *(const f32x4 *)(p.res + ro);
             a_ox += RPP;
             while (a_ox >= (unsigned)p.Wo) {
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
     for (int it = 0; it < NIT; ++it) {
         const unsigned m = m0 + erow0 + it * RPP;
         oks[it] = m < M && cok;
-        yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+        yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + (p.ysb ? (long)(co >> p.blk_shift) * p.ysb + (co & ((1 << p.blk_shift) - 1)) : (long)co);
         if constexpr (ABL == 6) {   // experiment: the tile's 64 KB written as ONE contiguous block (wrong place, right amount)
             yoffs[it] = ((long)(m_tile * NT + n_tile) * BM + (erow0 + it * RPP)) * BN + ecol;
             oks[it] = oks[it] && yoffs[it] + 4 <= (long)M * p.Cout;

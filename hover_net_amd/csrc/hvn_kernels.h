@@ -25,6 +25,11 @@ struct ConvArgs {
     int stagger;          // experiment switch, see hvn_conv.hip
     unsigned long long *dbg;  // optional: per-workgroup {start, k-loop end, epilogue end, HW_ID | LDS base << 32} (tools/conv_trace.py)
     long xb, wb, yb;      // element strides between them
+    // EXPERIMENT (HVN_EXP_BLOCKED, timing only -- profiles/r02_experiments.md section 9): channel-BLOCKED addressing [C/32][H][W][32]:
+    // xsb = element stride between 32-channel input blocks (launch_conv sets BK = channels-last when 0); ysb / rsb likewise for the
+    // output / residual (0 = channels-last)
+    long xsb, ysb, rsb;
+    int blk_shift;        // log2 of the channel block of the experiment (5 or 7); 0 = off
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);
