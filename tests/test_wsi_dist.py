@@ -146,3 +146,46 @@ def test_wsi_run_two_ranks_equals_single_process():
     # every chunk is read by exactly one rank, and together the ranks predict every patch exactly once
     assert len(reads) > 2 and sorted(reads0 + reads1) == sorted(reads) and not set(reads0) & set(reads1)
     assert n0 + n1 == wsi.stage1_patches and n0 > 0 and n1 > 0
+
+
+# ---- tile manager on 2 ranks ------------------------------------------------------------------------------------------------------
+def _manager_worker(rank, world, port, q, inp, out):
+    _init(rank, world, port)
+    from hover_net_amd import infer_manager as im
+    from hover_net_amd import infer_tile as T
+
+    def process(images):
+        """process_images' contract with the GPU pieces replaced: every rank computes the images it owns, rank 0 receives all of them."""
+        mine = {}
+        for i, img in enumerate(images):
+            if i % world == rank:
+                inst = (img[..., 0] > 127).astype(np.int32) * (i + 1)
+                mine[i] = [inst, np.zeros((0, 56), np.uint8), np.zeros((0, 2), np.int32), np.zeros(1, np.int64)]
+        every = T.gather_items_to_rank0(mine)
+        every = mine if every is None else every
+        return [(np.array(every[i][0]), {}) if i in every else None for i in range(len(images))]
+
+    mgr = im.InferManager({"model_args": {"nr_types": None, "mode": "original"}, "model_path": None}, process_fn=process)
+    done = mgr.process_file_list({"input_dir": inp, "output_dir": out, "ram_budget_bytes": 10 ** 12})
+    dist.barrier()
+    q.put((rank, (done, sorted(os.listdir(out + "/mat")) if os.path.isdir(out + "/mat") else None)))
+    dist.destroy_process_group()
+
+
+def test_process_file_list_two_ranks_only_rank0_writes(tmp_path):
+    import scipy.io as sio
+
+    inp = tmp_path / "in"
+    inp.mkdir()
+    rng = np.random.default_rng(0)
+    imgs = {}
+    for k in range(5):
+        imgs["im%d" % k] = rng.integers(0, 256, (30 + k, 40, 3), dtype=np.uint8)
+        np.save(inp / ("im%d.npy" % k), imgs["im%d" % k])
+    out = _spawn(_manager_worker, 2, str(inp), str(tmp_path / "out"))
+    done0, mats = out[0]
+    assert done0 == ["im%d" % k for k in range(5)] and out[1][0] == []          # rank 1 reports nothing written
+    assert mats == ["im%d.mat" % k for k in range(5)]
+    for k in range(5):                                                             # every image complete on disk, also those rank 1 computed
+        m = sio.loadmat(str(tmp_path / "out" / "mat" / ("im%d.mat" % k)))["inst_map"]
+        assert np.array_equal(m, (imgs["im%d" % k][..., 0] > 127).astype(np.int32) * (k + 1))
