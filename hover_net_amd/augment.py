@@ -140,14 +140,24 @@ class DevicePatchLoader:
 
     def __init__(self, patches, input_shape, mask_shape, batch_size, mode="train", with_type=False, seed=0, device="cuda", rank=0, world=1):
         assert mode in ("train", "valid")
-        if isinstance(patches, (list, tuple)):
-            data = np.stack([np.load(p) for p in patches])
+        self.device = torch.device(device)
+        if isinstance(patches, (list, tuple)):          # one file at a time: the set never exists as one host array
+            first = np.load(patches[0])
+            assert first.ndim == 3 and first.shape[-1] >= 4, "patch files: [H, W, 5] = RGB + instance id (+ type)"
+            h, w, c = first.shape
+            self.img = torch.empty((len(patches), h, w, 3), dtype=torch.uint8, device=self.device)
+            self.ann = torch.empty((len(patches), h, w, min(c - 3, 2)), dtype=torch.int32, device=self.device)
+            for i, path in enumerate(patches):
+                d = first if i == 0 else np.load(path)
+                if d.shape != first.shape:
+                    raise ValueError("patch %s has shape %s, the set's is %s" % (path, d.shape, first.shape))
+                self.img[i] = torch.from_numpy(np.ascontiguousarray(d[..., :3]).astype(np.uint8)).to(self.device)
+                self.ann[i] = torch.from_numpy(np.ascontiguousarray(d[..., 3:5]).astype(np.int32)).to(self.device)
         else:
             data = np.asarray(patches)
-        assert data.ndim == 4 and data.shape[-1] >= 4, "patches: [P, H, W, 5] = RGB + instance id (+ type)"
-        self.device = torch.device(device)
-        self.img = torch.from_numpy(np.ascontiguousarray(data[..., :3]).astype(np.uint8)).to(self.device)
-        self.ann = torch.from_numpy(np.ascontiguousarray(data[..., 3:5]).astype(np.int32)).to(self.device)
+            assert data.ndim == 4 and data.shape[-1] >= 4, "patches: [P, H, W, 5] = RGB + instance id (+ type)"
+            self.img = torch.from_numpy(np.ascontiguousarray(data[..., :3]).astype(np.uint8)).to(self.device)
+            self.ann = torch.from_numpy(np.ascontiguousarray(data[..., 3:5]).astype(np.int32)).to(self.device)
         self.with_type = bool(with_type)
         if self.with_type:
             assert self.ann.shape[-1] == 2, "with_type needs the type plane (channel 4)"

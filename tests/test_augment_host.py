@@ -56,3 +56,19 @@ def test_loader_epochs_and_rank_slices(monkeypatch):
     monkeypatch.setattr(ld, "batch", lambda prm, noise=None, generator=None: (prm["src"].copy(), prm["kind"].copy()))
     out = list(ld)
     assert [o[0].tolist() for o in out] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]] and all((o[1] == 3).all() for o in out)   # in order, ragged batch kept
+
+
+def test_loader_reads_patch_files_one_by_one(tmp_path):
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(3):
+        d = rng.integers(0, 200, (8, 9, 5)).astype(np.int32)
+        np.save(tmp_path / ("p%d.npy" % i), d)
+        paths.append(str(tmp_path / ("p%d.npy" % i)))
+    ld = G.DevicePatchLoader(paths, (4, 4), (2, 2), batch_size=2, mode="valid", with_type=True, device="cpu")
+    assert ld.img.shape == (3, 8, 9, 3) and ld.img.dtype.is_floating_point is False and ld.ann.shape == (3, 8, 9, 2)
+    assert np.array_equal(ld.ann[1].numpy(), np.load(paths[1])[..., 3:5]) and np.array_equal(ld.img[2].numpy(), np.load(paths[2])[..., :3].astype(np.uint8))
+    np.save(tmp_path / "bad.npy", np.zeros((7, 9, 5), np.int32))
+    import pytest
+    with pytest.raises(ValueError, match="has shape"):
+        G.DevicePatchLoader(paths + [str(tmp_path / "bad.npy")], (4, 4), (2, 2), batch_size=2, device="cpu")
