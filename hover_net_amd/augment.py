@@ -166,8 +166,14 @@ class DevicePatchLoader:
         self.seed, self.rank, self.world = int(seed), int(rank), int(world)
         self.epoch = 0
 
+    def _share(self):
+        """Patches per epoch on this rank: train = the same count on every rank (P // world, like DistributedSampler(drop_last=True) --
+        `train.run_phases` refuses ranks that disagree on the number of steps: their collectives would not pair up); valid = every patch."""
+        p = self.img.shape[0]
+        return p // self.world if self.mode == "train" else len(range(self.rank, p, self.world))
+
     def __len__(self):
-        mine = len(range(self.rank, self.img.shape[0], self.world))
+        mine = self._share()
         return mine // self.batch_size if self.mode == "train" else -(-mine // self.batch_size)
 
     def batch(self, prm, noise=None, generator=None):
@@ -194,7 +200,7 @@ class DevicePatchLoader:
             gen.manual_seed(int(rng.integers(0, 2 ** 62)))
         self.epoch += 1
         order = order_rng.permutation(p) if self.mode == "train" else np.arange(p)
-        mine = order[self.rank::self.world]
+        mine = order[self.rank::self.world][:self._share()]
         for b in range(len(self)):
             src = mine[b * self.batch_size:(b + 1) * self.batch_size]
             prm = draw_params(rng, src, h, w) if self.mode == "train" else identity_params(len(src), src)

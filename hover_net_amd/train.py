@@ -80,6 +80,35 @@ class _DropRagged:
         return (b for b in self.loader if int(b["img"].shape[0]) == self.batch_size)
 
 
+def device_loaders(train_patches, valid_patches, mode, with_type, seed=0, device=None):
+    """`make_loaders` for `run_phases` over HBM-resident patch sets (`augment.DevicePatchLoader`): the FileLoader + DataLoader pair of
+    run_train.py:106-133 with the shapes of config.py (original: 270 -> 80, fast: 256 -> 164).  `*_patches`: lists of `.npy` paths or
+    [P,H,W,5] arrays.  The sets are uploaded once and shared by both phases; rank / world come from torch.distributed."""
+    from . import augment
+
+    act, out = ((270, 270), (80, 80)) if mode == "original" else ((256, 256), (164, 164))
+    rank, world = _dist_info()
+    if device is None:
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    cache = {}
+
+    def make(phase_idx, batch_size):
+        out_d = {}
+        for split, patches in (("train", train_patches), ("valid", valid_patches)):
+            if patches is None:
+                out_d[split] = None
+                continue
+            if split not in cache:
+                cache[split] = augment.DevicePatchLoader(patches, act, out, batch_size[split], mode=split, with_type=with_type, seed=seed,
+                                                         device=device, rank=rank, world=world)
+            ld = cache[split]
+            ld.batch_size = int(batch_size[split])      # phase 1 runs smaller batches over the same resident set
+            out_d[split] = ld
+        return out_d
+
+    return make
+
+
 def _dist_info():
     import torch.distributed as dist
 

@@ -46,11 +46,11 @@ def test_loader_epochs_and_rank_slices(monkeypatch):
     for rank in range(2):
         ld = G.DevicePatchLoader(data, (4, 4), (2, 2), batch_size=2, mode="train", with_type=True, seed=3, device="cpu", rank=rank, world=2)
         monkeypatch.setattr(ld, "batch", lambda prm, noise=None, generator=None: prm["src"].copy())
-        assert len(ld) == (3 if rank == 0 else 2)                # 6 / 5 patches per rank, ragged batch dropped
+        assert len(ld) == 2                                      # 11 // 2 = 5 patches on EVERY rank, ragged batch dropped
         seen[rank] = [np.concatenate(list(ld)) for _epoch in range(2)]
     for epoch in range(2):
         a, b = seen[0][epoch], seen[1][epoch]
-        assert len(set(a) & set(b)) == 0 and len(set(a) | set(b)) == 10      # disjoint slices of ONE permutation (one patch dropped)
+        assert len(a) == len(b) == 4 and len(set(a) & set(b)) == 0           # disjoint slices of ONE permutation, same step count
     assert not np.array_equal(seen[0][0], seen[0][1])                            # reshuffled every epoch
     ld = G.DevicePatchLoader(data, (4, 4), (2, 2), batch_size=4, mode="valid", device="cpu")
     monkeypatch.setattr(ld, "batch", lambda prm, noise=None, generator=None: (prm["src"].copy(), prm["kind"].copy()))
@@ -72,3 +72,16 @@ def test_loader_reads_patch_files_one_by_one(tmp_path):
     import pytest
     with pytest.raises(ValueError, match="has shape"):
         G.DevicePatchLoader(paths + [str(tmp_path / "bad.npy")], (4, 4), (2, 2), batch_size=2, device="cpu")
+
+
+def test_device_loaders_callback_for_run_phases():
+    from hover_net_amd import train
+
+    data = np.zeros((6, 300, 300, 5), np.int32)
+    make = train.device_loaders(data, data[:2], "original", with_type=True, seed=4, device="cpu")
+    l0 = make(0, {"train": 2, "valid": 2})
+    assert len(l0["train"]) == 3 and len(l0["valid"]) == 1 and l0["train"].input_shape == (270, 270) and l0["train"].mask_shape == (80, 80)
+    l1 = make(1, {"train": 4, "valid": 1})
+    assert l1["train"] is l0["train"] and len(l1["train"]) == 1 and len(l1["valid"]) == 2      # same resident set, phase-1 batch sizes
+    assert train.device_loaders(data, None, "fast", False, device="cpu")(0, {"train": 2, "valid": 2})["valid"] is None
+    assert train.device_loaders(data, None, "fast", False, device="cpu")(0, {"train": 2, "valid": 2})["train"].mask_shape == (164, 164)
