@@ -95,3 +95,28 @@ def test_oracle_equals_the_references_own_functions():
         assert np.array_equal(g["contrast_out"][k], img[k])
     for k in range(3):
         assert np.array_equal(A.median_blur(img[k], g["median_k"][k]), g["median_out"][k])
+
+
+def test_affine_gather_agrees_with_scipy_affine_transform():
+    """Independent check of the warp geometry: scipy.ndimage.affine_transform (order 0, constant 0) with the same destination -> source
+    matrix in (row, col) order.  Random parameters never land on exact .5 source coordinates, where the two rounding rules could differ."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(9)
+    img = rng.integers(1, 256, (64, 80, 3), dtype=np.uint8)
+    ann = rng.integers(1, 9, (64, 80, 1)).astype(np.int32)
+    for _ in range(6):
+        fwd = A.affine_matrix(64, 80, rng.uniform(0.8, 1.2, 2), (rng.uniform(-3, 3), rng.uniform(-3, 3)), rng.uniform(-5, 5), rng.uniform(-179, 179))
+        inv = np.linalg.inv(fwd)
+        got_i, got_a = A.shape_augment(img, ann, inv, (64, 80), False, False)
+        # (x, y) -> (row, col): swap the axes of the 2x2 part and of the offset
+        m_rc = np.array([[inv[1, 1], inv[1, 0]], [inv[0, 1], inv[0, 0]]])
+        off_rc = np.array([inv[1, 2], inv[0, 2]])
+        for c in range(3):
+            want = ndimage.affine_transform(img[..., c], m_rc, offset=off_rc, order=0, mode="constant", cval=0)
+            both = (want != 0) & (got_i[..., c] != 0)             # scipy's "constant" mode also blanks the outer half-pixel band (source in (-0.5, 0))
+            assert both.mean() > 0.4 and np.array_equal(want[both], got_i[..., c][both])
+            assert ((want != 0) != (got_i[..., c] != 0)).mean() < 0.04 and not ((want != 0) & (got_i[..., c] == 0)).any()
+        want_a = ndimage.affine_transform(ann[..., 0], m_rc, offset=off_rc, order=0, mode="constant", cval=0)
+        both = (want_a != 0) & (got_a[..., 0] != 0)
+        assert np.array_equal(want_a[both], got_a[..., 0][both])
