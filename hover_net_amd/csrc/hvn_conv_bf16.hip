@@ -295,6 +295,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
                     rall[it] = *(const u32x4 *)(pres + (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co);
             }
         }
+        // ... then every output value is finished in registers (the waits for the residual loads fall here, with no store in flight) ...
+        u32x4 vout[NIT];
+        long yoffs[NIT];
+        bool oks[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it, ox += RPP) {
             while (ox >= (unsigned)p.Wo) {
@@ -306,13 +310,13 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
                 ++n;
             }
             const int rr = erow0 + it * RPP;
-            const unsigned m = m0 + rr;
-            if (rr >= BM || !(m < M && cok)) continue;
+            oks[it] = rr < BM && m0 + rr < M && cok;
+            yoffs[it] = (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co;
             const u32x4 r4 = rall[it];
             u32x4 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol + 4 * h);
+                f32x4 v = *(const f32x4 *)(ep + (rr < BM ? rr : 0) * EP_LD + ecol + 4 * h);
                 v.x = fmaxf(v.x + bias[h].x, relu_lo);
                 v.y = fmaxf(v.y + bias[h].y, relu_lo);
                 v.z = fmaxf(v.z + bias[h].z, relu_lo);
@@ -330,8 +334,16 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
                 o[2 * h] = pack_bf(v.x, v.y);
                 o[2 * h + 1] = pack_bf(v.z, v.w);
             }
-            *(u32x4 *)(py + (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co) = o;
+            vout[it] = o;
         }
+        // ... and the stores leave back to back (the empty asm keeps LLVM from sinking the arithmetic into the store blocks, which
+        // would put a vmcnt(0) -- a wait for the previous STORE -- between them; hvn_conv.hip has the measurements)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (oks[it]) *(u32x4 *)(py + yoffs[it]) = vout[it];
     }
 }
 
