@@ -52,6 +52,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #ifndef HVN_SWZ
 #define HVN_SWZ 1
 #endif
+// Experiment builds (lib.VARIANTS, default 0: the default library is byte-identical without them; NOT yet measured -- prepared for the next GPU session):
+//   HVN_EPI_LINEAR=1  branch-free epilogue addressing for row-contiguous output / residual views (offset = base[sample] + m * pixel stride)
+//   HVN_NT=1          non-temporal hints on the epilogue's residual loads and output stores (read once / written once per launch)
+#ifndef HVN_EPI_LINEAR
+#define HVN_EPI_LINEAR 0
+#endif
+#ifndef HVN_NT
+#define HVN_NT 0
+#endif
 #if HVN_SWZ
 #define LDS_LD 32
 #else
@@ -443,7 +452,19 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
     constexpr int NIT = BM / RPP;         // rows per thread: 16 / 8 / 4
     // this thread's rows are m0 + erow0 + k*RPP: decode the first with divisions, walk the rest (n, oy, ox) incrementally
     // (32 integer divisions per thread and tile were ~10 % of a short-K tile's instruction stream)
+#if HVN_EPI_LINEAR
+    // row-contiguous views: offset(n, oy, ox) = n * sn + (m - n * HoWo) * sx; a 128-row tile touches at most two samples (HoWo >= BM)
+    const bool lin = p.ysy == (long)p.Wo * p.ysx && (!has_res || p.rsy == (long)p.Wo * p.rsx) && HoWo >= (unsigned)BM && !p.ysb && !p.rsb;   // uniform
+    const unsigned lin_bound = (n_blk + 1u) * HoWo;                       // first pixel row of the next sample
+    const long ybase0 = (long)n_blk * p.ysn - (long)n_blk * HoWo * p.ysx + co, ybase1 = ybase0 + p.ysn - (long)HoWo * p.ysx;
+    const long rbase0 = (long)n_blk * p.rsn - (long)n_blk * HoWo * p.rsx + co, rbase1 = rbase0 + p.rsn - (long)HoWo * p.rsx;
+#endif
+#if HVN_EPI_LINEAR
+    unsigned e_n = 0, e_oy = 0, e_ox = 0;
+    if (!lin)
+#else
     unsigned e_n, e_oy, e_ox;
+#endif
     {
         const unsigned m = m0 + erow0;
         e_n = m / HoWo;
@@ -457,13 +478,31 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
     // round trips per tile, 30-50 k cycles against a 14-40 k cycle k-loop on the K <= 512 layers (per-workgroup timelines,
     // profiles/r02_experiments.md).
     f32x4 rall[NIT];
+#if HVN_EPI_LINEAR
+    if (has_res && ABL != 4 && lin) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const unsigned m = m0 + erow0 + it * RPP;
+            const long ro = (m < M && cok) ? (m >= lin_bound ? rbase1 : rbase0) + (long)m * p.rsx : 0;
+#if HVN_NT
+            rall[it] = __builtin_nontemporal_load((const f32x4 *)(p.res + ro));
+#else
+            rall[it] = *(const f32x4 *)(p.res + ro);
+#endif
+        }
+    } else
+#endif
     if (has_res && ABL != 4) {
         unsigned a_n = e_n, a_oy = e_oy, a_ox = e_ox;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const unsigned m = m0 + erow0 + it * RPP;
             const long ro = (m < M && cok) ? (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + (p.rsb ? (long)(co >> p.blk_shift) * p.rsb + (co & ((1 << p.blk_shift) - 1)) : (long)co) : 0;
+#if HVN_NT
+            rall[it] = __builtin_nontemporal_load((const f32x4 *)(p.res + ro));
+#else
             rall[it] = *(const f32x4 *)(p.res + ro);
+#endif
             a_ox += RPP;
             while (a_ox >= (unsigned)p.Wo) {
                 a_ox -= (unsigned)p.Wo;
@@ -489,18 +528,26 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
         const unsigned m = m0 + erow0 + it * RPP;
         oks[it] = m < M && cok;
         yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + (p.ysb ? (long)(co >> p.blk_shift) * p.ysb + (co & ((1 << p.blk_shift) - 1)) : (long)co);
+#if HVN_EPI_LINEAR
+        if (lin) yoffs[it] = (m >= lin_bound ? ybase1 : ybase0) + (long)m * p.ysx;
+#endif
         if constexpr (ABL == 6) {   // experiment: the tile's 64 KB written as ONE contiguous block (wrong place, right amount)
             yoffs[it] = ((long)(m_tile * NT + n_tile) * BM + (erow0 + it * RPP)) * BN + ecol;
             oks[it] = oks[it] && yoffs[it] + 4 <= (long)M * p.Cout;
         }
-        e_ox += RPP;
-        while (e_ox >= (unsigned)p.Wo) {
-            e_ox -= (unsigned)p.Wo;
-            ++e_oy;
-        }
-        while (e_oy >= (unsigned)p.Ho) {
-            e_oy -= (unsigned)p.Ho;
-            ++e_n;
+#if HVN_EPI_LINEAR
+        if (!lin)
+#endif
+        {
+            e_ox += RPP;
+            while (e_ox >= (unsigned)p.Wo) {
+                e_ox -= (unsigned)p.Wo;
+                ++e_oy;
+            }
+            while (e_oy >= (unsigned)p.Ho) {
+                e_oy -= (unsigned)p.Ho;
+                ++e_n;
+            }
         }
         const int rr = erow0 + it * RPP;
         f32x4 v = *(const f32x4 *)(ep + rr * EP_LD + ecol);
@@ -523,7 +570,11 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         if constexpr (ABL != 4) {
+#if HVN_NT
+            if (oks[it]) __builtin_nontemporal_store(vout[it], (f32x4 *)(p.y + yoffs[it]));
+#else
             if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
+#endif
         } else if (vout[it].x == 12345.678f && oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];   // keeps the math alive, stores nothing
     }
     if (p.dbg && tid == 0) {

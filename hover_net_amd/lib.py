@@ -8,7 +8,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhvn_hip.so")
 # Experiment builds of the same sources (`build_variant`), loaded INSTEAD of the default library when HVN_LIB_VARIANT names one:
 # kernel A/B runs on one box without rebuilding there.  Not used by the product path (unset = libhvn_hip.so).
-VARIANTS = {"pad": ("-DHVN_SWZ=0",)}     # padded LDS rows (round-1 layout) instead of the XOR swizzle
+VARIANTS = {
+    "pad": ("-DHVN_SWZ=0",),                        # padded LDS rows (round-1 layout) instead of the XOR swizzle
+    "lin": ("-DHVN_EPI_LINEAR=1",),                 # prepared, NOT yet measured: branch-free epilogue addressing for row-contiguous views
+    "nt": ("-DHVN_NT=1",),                          # prepared, NOT yet measured: non-temporal hints on the epilogue's residual loads / stores
+    "lin_nt": ("-DHVN_EPI_LINEAR=1", "-DHVN_NT=1"),
+}
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("hvn_conv.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
            "hvn_augment.hip", "hvn_train_api.hip", "hvn_contour.cpp")
