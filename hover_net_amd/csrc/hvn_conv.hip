@@ -61,6 +61,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #ifndef HVN_NT
 #define HVN_NT 0
 #endif
+//   HVN_TRACE_FINE=1  (with HVN_CONV_TRACE) 8 instead of 4 words per workgroup: + the end of each epilogue phase (accumulators in LDS and
+//                     barrier passed, residual loads returned, values finished, stores issued); the phase waits it inserts perturb the timing
+//                     a little -- a diagnosis build (tools/conv_trace.py --fine)
+#ifndef HVN_TRACE_FINE
+#define HVN_TRACE_FINE 0
+#endif
+#define HVN_TRACE_WORDS (HVN_TRACE_FINE ? 8 : 4)
 #if HVN_SWZ
 #define LDS_LD 32
 #else
@@ -431,6 +438,10 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
                 ep[row * EP_LD + wn * WN + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
+#if HVN_TRACE_FINE
+    unsigned long long t_f[4] = {0, 0, 0, 0};
+    if (p.dbg) t_f[0] = __builtin_readcyclecounter();
+#endif
     // 2. each thread owns one float4 column chunk and walks rows: 16 B per lane, BN*4 B contiguous per row
     constexpr int CH = BN / 4;            // float4 chunks per row
     constexpr int RPP = 256 / CH;         // rows per pass
@@ -520,6 +531,12 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
     // ... then every output value is finished in registers (the waits for the residual loads fall here, while no store is in
     // flight: with loads AND stores pending the compiler has to assume they retire out of order and waits for vmcnt(0), i.e.
     // for the previous store, before every use of a loaded value) ...
+#if HVN_TRACE_FINE
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the residual tile has arrived
+        t_f[1] = __builtin_readcyclecounter();
+    }
+#endif
     f32x4 vout[NIT];
     long yoffs[NIT];
     bool oks[NIT];
@@ -567,6 +584,9 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
 #pragma unroll
     for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
     __builtin_amdgcn_sched_barrier(0);
+#if HVN_TRACE_FINE
+    if (p.dbg) t_f[2] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         if constexpr (ABL != 4) {
@@ -577,9 +597,18 @@ __global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_i
 #endif
         } else if (vout[it].x == 12345.678f && oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];   // keeps the math alive, stores nothing
     }
+#if HVN_TRACE_FINE
+    if (p.dbg) t_f[3] = __builtin_readcyclecounter();        // stores issued (not yet acknowledged)
+#endif
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of this thread have left
-        unsigned long long *d = p.dbg + 4ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+        unsigned long long *d = p.dbg + (unsigned long long)HVN_TRACE_WORDS * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y);
+#if HVN_TRACE_FINE
+        d[4] = t_f[0];
+        d[5] = t_f[1];
+        d[6] = t_f[2];
+        d[7] = t_f[3];
+#endif
         d[0] = t_start;
         d[1] = t_kend;
         d[2] = __builtin_readcyclecounter();
@@ -603,7 +632,7 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     if (dbg_on < 0) {
         const char *e = getenv("HVN_CONV_TRACE");   // path of a file to dump per-workgroup timestamps of the LAST launch into
         dbg_on = e ? 1 : 0;
-        if (dbg_on) hipMalloc(&dbg_buf, 4 * 8 * (size_t)(1 << 20));
+        if (dbg_on) hipMalloc(&dbg_buf, HVN_TRACE_WORDS * 8 * (size_t)(1 << 20));
     }
     p.dbg = dbg_on ? dbg_buf : nullptr;
     p.m_tiles = (p.M + BM - 1) / BM;
@@ -624,8 +653,8 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     if (dbg_on && grid * (p.nbatch > 1 ? p.nbatch : 1) <= (1 << 20)) {   // experiment mode only: synchronous dump
         hipStreamSynchronize(stream);
         const size_t n = (size_t)grid * (p.nbatch > 1 ? p.nbatch : 1);
-        std::vector<unsigned long long> h(4 * n);
-        hipMemcpy(h.data(), dbg_buf, 32 * n, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h(HVN_TRACE_WORDS * n);
+        hipMemcpy(h.data(), dbg_buf, 8 * HVN_TRACE_WORDS * n, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(getenv("HVN_CONV_TRACE"), "wb")) {
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);

@@ -6,8 +6,16 @@ import sys
 
 import numpy as np
 
-a = np.fromfile(sys.argv[1], np.uint64).reshape(-1, 4)
+FINE = "--fine" in sys.argv          # dump of the `trace` build (lib.VARIANTS): 8 words per workgroup, + the end of each epilogue phase
+a = np.fromfile(sys.argv[1], np.uint64).reshape(-1, 8 if FINE else 4)
 a = a[a[:, 2] > 0]
+if FINE:
+    ph = a[:, [1, 4, 5, 6, 7, 2]].astype(np.int64)      # k-loop end, LDS tile + barrier, residual arrived, values done, stores issued, stores acknowledged
+    d = np.diff(ph, axis=1)
+    names = ["accumulators -> LDS + barrier", "residual loads return", "values finished", "stores issued", "stores acknowledged"]
+    print("epilogue phases (ticks: median / p10 / p90):")
+    for i, nm in enumerate(names):
+        print("  %-32s %8d %8d %8d" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
 t0, t1, t2, hw = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2].astype(np.int64), a[:, 3]
 hwid = (hw & 0xffffffff).astype(np.int64)
 lds = (hw >> np.uint64(32)).astype(np.int64)
