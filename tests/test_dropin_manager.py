@@ -49,6 +49,28 @@ bad = [k for k in sd if not torch.equal(got[k].double().flatten(), sd[k].double(
 assert not bad, bad[:5]
 assert mgr.post_proc_func is hover_net_amd.post_proc.process
 assert mgr.nr_types == 5 and len(mgr.type_info_dict) == 5
+# ---- the writers of hover_net_amd.infer_manager / io_utils against the reference's own (infer/base.py:29-53,80-94, convert_format.py:17-49)
+from hover_net_amd import infer_manager as im, io_utils
+assert {k: (v[0], tuple(int(c) for c in v[1])) for k, v in mgr.type_info_dict.items()} == im.load_type_info(5, None)      # the 'hot' lookup-table colours
+import json
+tj = os.path.join(tmp, "type.json")
+json.dump({str(k): ["t%d" % k, [10 * k, 20, 30]] for k in range(6)}, open(tj, "w"))
+mgr2 = InferManager(method={"model_args": {"nr_types": 5, "mode": "original"}, "model_path": path}, type_info_path=tj)
+assert mgr2.type_info_dict == im.load_type_info(5, tj)
+info = {3: {"bbox": np.array([[1, 2], [30, 40]]), "centroid": np.array([20.25, 15.5]), "contour": np.array([[2, 1], [39, 1], [39, 29], [2, 29]], np.int32),
+            "type_prob": 0.8125, "type": 2},
+        np.int32(7): {"bbox": np.array([[5, 5], [9, 9]]), "centroid": np.array([6.5, 7.0]), "contour": np.array([[5, 5], [8, 5], [8, 8]], np.int32),
+                      "type_prob": None, "type": None}}
+ja, jb = os.path.join(tmp, "ref.json"), os.path.join(tmp, "mine.json")
+ret_ref = mgr._InferManager__save_json(ja, info, mag=40)
+ret_mine = io_utils.save_json(jb, info, mag=40)
+assert open(ja).read() == open(jb).read() and ret_ref == ret_mine
+import convert_format as cf                                                  # the reference's QuPath writer
+cents, types = np.array([[20.25, 15.5], [6.5, 7.0]]), np.array([2, 4])
+cf.to_qupath(os.path.join(tmp, "ref.tsv"), cents, types, mgr2.type_info_dict)
+im.to_qupath(os.path.join(tmp, "mine.tsv"), cents, types, im.load_type_info(5, tj))
+assert open(os.path.join(tmp, "ref.tsv")).read() == open(os.path.join(tmp, "mine.tsv")).read()
+print("WRITERS_OK")
 if not torch.cuda.is_available():
     try:
         mgr.run_step(torch.zeros(1, 270, 270, 3, dtype=torch.uint8))
@@ -66,7 +88,7 @@ def test_reference_infer_manager_loads_the_dropins(tmp_path):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
     r = subprocess.run([sys.executable, "-c", SCRIPT, REPO, REF, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "DROPIN_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "LOUD:" in r.stdout
+    assert "LOUD:" in r.stdout and "WRITERS_OK" in r.stdout
 
 
 def test_shim_package_exports_the_boundary_names():
