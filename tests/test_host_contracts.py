@@ -1,6 +1,8 @@
 """CPU: host-side contracts of the product that need no GPU -- the library must be missing LOUDLY (no CPU fallback), the
 GPU entry points refuse to run off a gfx950 device, the fused optimizer recognises the training slab layout, and the
 training schedule mirrors opt.py's phase list."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -114,3 +116,49 @@ def test_save_json_protocol(tmp_path):
     d = json.load(open(p))
     assert d["mag"] == 40 and sorted(d["nuc"]) == ["7", "9"]
     assert d["nuc"]["7"] == {"bbox": [[1, 2], [5, 9]], "centroid": [4.5, 3.25], "contour": [[2, 1], [8, 1], [8, 4]], "type_prob": 0.75, "type": 3}
+
+
+_REF_VALID = r'''
+import sys, types, json
+sys.path.insert(0, "/root/reference")
+for name in ("cv2", "termcolor"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["termcolor"].colored = lambda s, *a, **k: s
+import numpy as np
+import models.hovernet.run_desc as ref                      # the reference, unmodified
+assert ref.__file__.startswith("/root/reference")
+ref.viz_step_output = lambda *a, **k: None                    # the image half needs cv2 / matplotlib colour maps: not under test
+raw = dict(np.load(sys.argv[1], allow_pickle=False))
+raw = {k: list(v) for k, v in raw.items()}
+raw["imgs"] = [np.zeros((4, 4, 3), np.uint8)] * len(raw["true_np"])
+out = ref.proc_valid_step_output(raw, nr_types=int(sys.argv[2]) if int(sys.argv[2]) > 0 else None)["scalar"]
+print("SCALARS " + json.dumps({k: float(v) for k, v in out.items()}))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/models/hovernet/run_desc.py"), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("nt", [0, 4])
+def test_proc_valid_step_output_equals_the_references_own_function(tmp_path, nt):
+    """run_desc.py:262-333 run unmodified (viz half patched out) on the same accumulated validation outputs."""
+    import json
+    import subprocess
+    import sys
+
+    from hover_net_amd import run_desc
+
+    rng = np.random.default_rng(11)
+    n, h = 6, 20
+    raw = {"prob_np": rng.random((n, h, h)), "true_np": rng.integers(0, 2, (n, h, h)), "pred_hv": rng.normal(size=(n, h, h, 2)).astype(np.float32),
+           "true_hv": rng.normal(size=(n, h, h, 2)).astype(np.float32)}
+    if nt:
+        raw["pred_tp"] = rng.integers(0, nt, (n, h, h)).astype(np.float32)
+        raw["true_tp"] = rng.integers(0, nt, (n, h, h))
+    np.savez(tmp_path / "raw.npz", **raw)
+    r = subprocess.run([sys.executable, "-c", _REF_VALID, str(tmp_path / "raw.npz"), str(nt)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg"))
+    assert r.returncode == 0 and "SCALARS " in r.stdout, (r.stdout[-800:], r.stderr[-2500:])
+    want = json.loads(r.stdout.split("SCALARS ", 1)[1].splitlines()[0])
+    got = run_desc.proc_valid_step_output({k: list(v) for k, v in raw.items()}, nr_types=nt or None)["scalar"]
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert abs(float(got[k]) - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got[k], want[k])
