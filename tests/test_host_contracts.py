@@ -162,3 +162,60 @@ def test_proc_valid_step_output_equals_the_references_own_function(tmp_path, nt)
     assert sorted(got) == sorted(want)
     for k in want:
         assert abs(float(got[k]) - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+_REF_OPT = r'''
+import sys, types, json
+sys.path.insert(0, "/root/reference")
+for name in ("cv2", "termcolor", "skimage", "skimage.morphology", "tensorboardX"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["skimage"].morphology = sys.modules["skimage.morphology"]
+sys.modules["termcolor"].colored = lambda s, *a, **k: s
+sys.modules["tensorboardX"].SummaryWriter = object
+import torch
+import models.hovernet.opt as opt                              # the reference, unmodified
+assert opt.__file__.startswith("/root/reference")
+out = {}
+for nt, mode in ((5, "original"), (None, "fast")):
+    cfg = opt.get_config(nt, mode)
+    phases = []
+    for ph in cfg["phase_list"]:
+        info = ph["run_info"]["net"]
+        net = info["desc"]()
+        sch = info["lr_scheduler"](torch.optim.SGD(torch.nn.Linear(1, 1).parameters(), lr=1.0))
+        phases.append({"batch_size": ph["batch_size"], "nr_epochs": ph["nr_epochs"], "opt_args": {k: list(v) if isinstance(v, tuple) else v for k, v in info["optimizer"][1].items()},
+                       "opt_name": info["optimizer"][0].__name__, "pretrained": info["pretrained"], "loss": info["extra_info"]["loss"],
+                       "freeze": bool(net.freeze), "nr_types": net.nr_types, "mode": net.mode, "sched": [type(sch).__name__, sch.step_size, sch.gamma]})
+    out["%s-%s" % (nt, mode)] = phases
+print("CONFIG " + json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/models/hovernet/opt.py"), reason="needs the reference tree (build container only)")
+def test_get_config_equals_the_references_own_phase_list():
+    """models/hovernet/opt.py:23-142 run unmodified vs hover_net_amd.train.get_config: batch sizes, epochs, Adam arguments, pretrained entries, loss table,
+    freeze flags, StepLR(25, 0.1).  (The optimizer CLASS differs on purpose: FusedAdam = torch.optim.Adam's update on the parameter slab.)"""
+    import json
+    import subprocess
+    import sys
+
+    from hover_net_amd import train
+
+    r = subprocess.run([sys.executable, "-c", _REF_OPT], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg"))
+    assert r.returncode == 0 and "CONFIG " in r.stdout, (r.stdout[-600:], r.stderr[-2500:])
+    ref = json.loads(r.stdout.split("CONFIG ", 1)[1].splitlines()[0])
+    for nt, mode in ((5, "original"), (None, "fast")):
+        want = ref["%s-%s" % (nt, mode)]
+        cfg = train.get_config(nt, mode, pretrained=want[0]["pretrained"])
+        assert len(cfg["phase_list"]) == len(want) == 2
+        for ph, w in zip(cfg["phase_list"], want):
+            info = ph["run_info"]["net"]
+            net = info["desc"]()
+            sch = info["lr_scheduler"](torch.optim.SGD(torch.nn.Linear(1, 1).parameters(), lr=1.0))
+            assert ph["batch_size"] == w["batch_size"] and ph["nr_epochs"] == w["nr_epochs"]
+            assert {k: list(v) if isinstance(v, tuple) else v for k, v in info["optimizer"][1].items()} == w["opt_args"] and w["opt_name"] == "Adam"
+            assert info["pretrained"] == w["pretrained"]
+            branches = ("np", "hv") + (("tp",) if nt is not None else ())                 # the reference lists `tp` always and skips it without a tp branch
+            assert {b: info["extra_info"]["loss"][b] for b in branches} == {b: w["loss"][b] for b in branches}
+            assert (bool(net.freeze), net.nr_types, net.mode) == (w["freeze"], w["nr_types"], w["mode"])
+            assert [type(sch).__name__, sch.step_size, sch.gamma] == w["sched"]
