@@ -132,29 +132,11 @@ def test_bf16_sized_map_perturbation_keeps_the_segmentation():
     rounded to bf16 (8 mantissa bits: relative 2^-9, i.e. up to 2e-3 on p ~ 0.9 and 4e-3 on |h|, |v| ~ 1) plus smooth noise of
     +-1e-2 on p_nuc / +-3e-2 on h, v (twice the mean logit error measured above) -- and post-processed on the GPU:
     mean panoptic quality against the unperturbed fp32 result must stay >= 0.985 (no tile below 0.93; measured 0.9906 / 0.9547) (metrics/stats_utils.py:178 get_fast_pq semantics:
-    IoU > 0.5 pairing, DQ x SQ), restated here in numpy."""
+    IoU > 0.5 pairing, DQ x SQ), restated in tests/pq_util.py."""
     from hover_net_amd.post_proc import PostProc
     from hover_net_amd.synth import synth_pred_maps
 
-    def pq(true, pred):
-        tl, pl = np.unique(true)[1:], np.unique(pred)[1:]
-        if len(tl) == 0 and len(pl) == 0:
-            return 1.0
-        tp, iou_sum, used = 0, 0.0, set()
-        for t in tl:
-            m = true == t
-            cand, cnt = np.unique(pred[m], return_counts=True)
-            for c, k in zip(cand, cnt):
-                if c == 0 or c in used:
-                    continue
-                iou = k / float(m.sum() + (pred == c).sum() - k)
-                if iou > 0.5:
-                    tp += 1
-                    iou_sum += iou
-                    used.add(c)
-                    break
-        fp, fn = len(pl) - tp, len(tl) - tp
-        return (tp / (tp + 0.5 * fp + 0.5 * fn + 1e-6)) * (iou_sum / (tp + 1e-6))
+    from pq_util import pq           # the reference's get_fast_pq restated; pinned to it in tests/test_oracle_metrics.py
 
     pred = synth_pred_maps(16, 164, 164, 6, seed=77)[0]
     rng = np.random.default_rng(5)
