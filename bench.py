@@ -319,8 +319,8 @@ def main():
         eng = net.engine(args.batch)
         assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: HVN_SPLIT=1 HVN_LANES=0"
         n_prof = 5
-        algo_flops = sum(o.flops() for o in eng.plan.ops if o.kind == 2) * args.batch
-        exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in eng.plan.ops if o.kind == 2) * args.batch
+        algo_flops = sum(o.flops() for o in eng.plan.ops if o.kind in (2, 8)) * args.batch
+        exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in eng.plan.ops if o.kind in (2, 8)) * args.batch
         torch.cuda.synchronize(dev)
         ms_list, launches = [], 0
         for _ in range(n_prof):
@@ -330,7 +330,7 @@ def main():
             launches = L.lib().hvn_profile_conv_launches()
             L.lib().hvn_profile_enable(0)
         ms = sorted(ms_list)[len(ms_list) // 2]
-        n_conv = sum(1 for o in eng.plan.ops if o.kind == 2)
+        n_conv = sum(1 for o in eng.plan.ops if o.kind in (2, 8))     # CONV + CHAIN (two chained 1x1 convs) launches
         peak = PEAK_FP32_MATRIX_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
         achieved = exec_flops / (ms * 1e-3) / 1e12
         traffic, tsrc = None, None

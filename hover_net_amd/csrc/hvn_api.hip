@@ -19,7 +19,7 @@ static int fail(int code, const char *fmt, const char *a = "", long b = 0)
 
 extern "C" {
 
-int hvn_version(void) { return 101; }   // 1.01: + training step, bf16 path, patch extraction, target generation
+int hvn_version(void) { return 102; }   // 1.02: + CHAIN op (two chained 1x1 convs), hvn_op grew y2 / w2 / bias2 / cout2
 
 const char *hvn_last_error(void) { return g_err; }
 
@@ -172,6 +172,50 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         int rc = bf16 ? hvn_launch_conv_bf16(a, op->tile_n, s) : hvn_launch_conv(a, op->tile_n, s);
         if (g_prof) prof_mark(s);
         if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "conv: launch failed (tile_n=%s%ld)", "", op->tile_n);
+        return 0;
+    }
+    case HVN_OP_CHAIN: {
+        ChainArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = (const float *)op->x.base;
+        a.xsn = op->x.sn; a.xsy = op->x.sy; a.xsx = op->x.sx; a.K1 = op->x.c;
+        a.x2 = (const float *)op->x2.base;
+        a.x2sn = op->x2.sn; a.x2sy = op->x2.sy; a.x2sx = op->x2.sx;
+        a.K1b = a.x2 ? op->x2.c : 0;
+        a.stride2 = op->_rsv > 0 ? op->_rsv : 1;
+        a.w1 = op->w;
+        a.res = (const float *)op->res.base;
+        a.rsn = op->res.sn; a.rsy = op->res.sy; a.rsx = op->res.sx;
+        a.y = (float *)op->y.base;
+        a.ysn = op->y.sn; a.ysy = op->y.sy; a.ysx = op->y.sx; a.C = op->cout;
+        a.post_s = op->post_scale; a.post_b = op->post_shift;
+        a.pre_s = op->pre_scale; a.pre_b = op->pre_shift;
+        a.w2 = op->w2; a.bias2 = op->bias2; a.relu2 = 1;
+        a.y2 = (float *)op->y2.base;
+        a.y2sn = op->y2.sn; a.y2sy = op->y2.sy; a.y2sx = op->y2.sx; a.N2 = op->cout2;
+        a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w;
+        a.M = (long)batch * a.Ho * a.Wo;
+        if (op->act_dtype != 0) return fail(HVN_E_ARG, "chain: fp32 only%s", "");
+        if (!a.x || !a.w1 || !a.y || !a.w2 || !a.y2) return fail(HVN_E_ARG, "chain: null pointer%s", "");
+        if (op->kh != 1 || op->kw != 1 || op->stride != 1 || op->pad_t || op->pad_l || op->relu || op->bias)
+            return fail(HVN_E_ARG, "chain: the first conv is a plain 1x1 (no bias / relu of its own)%s", "");
+        if (!hvn_chain_supported(a.C, a.N2) || op->y.c != a.C || op->y2.c != a.N2 || a.K1 % 32 || a.K1b % 32 || a.K1 + a.K1b < 64)
+            return fail(HVN_E_ARG, "chain: needs cout %% 64 == 0, cout2 in {64, 128}, input channels in slabs of 32 (>= 64) (cout2 = %s%ld)", "", a.N2);
+        if (op->x.h != a.Ho || op->x.w != a.Wo || op->y2.h != a.Ho || op->y2.w != a.Wo ||
+            (a.x2 && ((long)(a.Ho - 1) * a.stride2 >= op->x2.h || (long)(a.Wo - 1) * a.stride2 >= op->x2.w)))
+            return fail(HVN_E_ARG, "chain: views do not cover the output grid%s", "");
+        if (a.res && (a.rsn != a.ysn || a.rsy != a.ysy || a.rsx != a.ysx || op->res.c != a.C))
+            return fail(HVN_E_ARG, "chain: the residual view must have the output's strides%s", "");
+        if (!aligned16(a.x) || !aligned16(a.w1) || !aligned16(a.w2) || !aligned16(a.y) || !aligned16(a.y2) || (a.res && !aligned16(a.res)) ||
+            (a.x2 && !aligned16(a.x2)) || ((a.xsn | a.xsy | a.xsx | a.ysn | a.ysy | a.ysx | a.y2sn | a.y2sy | a.y2sx | a.x2sn | a.x2sy | a.x2sx) & 3))
+            return fail(HVN_E_ARG, "chain: views / weights not 16-byte aligned%s", "");
+        if ((!a.pre_s != !a.pre_b) || (!a.post_s != !a.post_b) || (a.pre_s && (!aligned16(a.pre_s) || !aligned16(a.pre_b))) ||
+            (a.post_s && (!aligned16(a.post_s) || !aligned16(a.post_b))) || (a.bias2 && !aligned16(a.bias2)))
+            return fail(HVN_E_ARG, "chain: per-channel vectors must be 16-byte aligned and come in pairs%s", "");
+        if (g_prof) prof_mark(s);
+        int rc = hvn_launch_conv_chain(a, s);
+        if (g_prof) prof_mark(s);
+        if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "chain: launch failed (cout2=%s%ld)", "", a.N2);
         return 0;
     }
     case HVN_OP_WINO_IN:

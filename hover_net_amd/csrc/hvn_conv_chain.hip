@@ -1,0 +1,379 @@
+// hvn_conv_chain.hip -- two chained 1x1 convolutions of a pre-activation residual block in ONE launch (gfx950, fp32 MFMA).
+//
+// Reference: /root/reference/models/hovernet/net_utils.py:250-266 (ResidualBlock.forward).  Unit i ends with
+//     y = conv3(t2) + shortcut                      (1x1, C/4 -> C; unit 0: shortcut = 1x1 conv of the block input)
+// and unit i+1 (or unit 0 of the next block, after blk_bna) begins with
+//     t1' = relu(bn(conv1(relu(bn_pre(y)))))        (1x1, C -> C/4)
+// Both are per-pixel: the second needs no neighbour of the first, so a workgroup that owns ALL C channels of its 128 pixels can
+// run conv1 straight on the y values it has just produced.  What this removes per pixel and seam: one read of y (4C bytes; the
+// dominant term of the HBM-bound d0 / d1 layers: 4 KB -> 3 KB per pixel and unit in d0), one launch, and one prologue-k-loop-
+// epilogue round trip of short-K workgroups (profiles/r02_experiments.md section 7).  No halo, so it composes with the Winograd
+// form of conv2 in d1..d3.
+//
+// Work of one 256-thread workgroup (128 pixels), for each 64-channel chunk c of C:
+//   GEMM1   acc1[128 px][64]  = sum_k x[px][k] W3[64c + j][k]  (+ the shortcut's channels appended to k)      K1 = C/4 (+ Cin2)
+//   epi 1   v = acc1 + res;  v = relu(v*qs + qb) if the block closes here;  y[px][64c..] = v   (16 B per lane, 256 B per row)
+//           a = relu(v*ps + pb) (next unit's pre-activation; identity after a block-closing BN-ReLU)  -> stays in LDS
+//   GEMM2   acc2[128 px][N2] += sum_{j<64} a[px][j] W1'[n][64c + j]                                     N2 = C'/4 in {64, 128}
+// and after the last chunk   t1'[px][n] = relu(acc2 + b2).
+// Every output element sums its products in exactly the order of hvn_conv_igemm_f32 (32-channel slabs in order, the same k
+// permutation inside a slab, one accumulator), so y and t1' are BIT-IDENTICAL to the two separate launches (tests/test_gpu_chain.py).
+//
+// LDS (floats): GEMM1 staging [2][128][32] + [2][64][32] (48 KB, XOR-swizzled rows as in hvn_conv.hip); the epilogue tile
+// [128][68] aliases it and doubles as GEMM2's A operand (row pitch 68: conflict-free ds_read_b128 for 16 consecutive rows);
+// W1' chunk [2][N2][32] behind it.  64 KB (N2 = 64) / 80 KB (N2 = 128): two workgroups per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "hvn_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CH_BM 128
+#define CH_BN 64
+#define CH_EP 68   // epilogue / GEMM2-A tile row pitch (floats)
+
+static __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+static __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+template <int N2, bool HAS_X2>
+__global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
+{
+    constexpr int PA = CH_BM / 32, PB = CH_BN / 32, PB2 = N2 / 32;
+    constexpr int WAVES_N2 = N2 >= 128 ? 2 : 1, WAVES_M2 = 4 / WAVES_N2;
+    constexpr int WM2 = CH_BM / WAVES_M2, WN2 = N2 / WAVES_N2;
+    constexpr int TM2 = WM2 / 32, TN2 = WN2 / 32;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                              // [2][128][32]
+    float *Bs = smem + 2 * CH_BM * 32;             // [2][64][32]
+    float *ep = smem;                              // [128][68], aliases As / Bs
+    float *B2s = smem + 2 * (CH_BM + CH_BN) * 32;  // [2][N2][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned M = (unsigned)p.M;
+    const unsigned m0 = blockIdx.x * (unsigned)CH_BM;
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+    const unsigned n_blk = m0 / HoWo;
+
+    // ---- staging coordinates (one 16-byte piece of a 32-float k-slab row per thread and pass) -------------------------
+    const int srow = tid >> 3;
+    const int scol = (tid & 7) * 4;
+    const int lcol = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
+    unsigned a_voff[PA], a2_voff[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const unsigned m = m0 + srow + 32 * j;
+        const bool ok = m < M;
+        const unsigned mm = ok ? m : m0;
+        const unsigned n = mm / HoWo;
+        const unsigned rem = mm - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        a_voff[j] = ok ? (unsigned)(((long)(n - n_blk) * p.xsn + (long)oy * p.xsy + (long)ox * p.xsx + scol) * 4) : OOB;
+        a2_voff[j] = (ok && HAS_X2) ? (unsigned)(((long)(n - n_blk) * p.x2sn + (long)(oy * p.stride2) * p.x2sy + (long)(ox * p.stride2) * p.x2sx + scol) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long)n_blk * p.xsn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2 =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_X2 ? p.x2 + (long)n_blk * p.x2sn : p.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)p.w2, 0, 0x7fffffff, 0x00020000);
+    const int KT1 = p.K1 / 32;
+    const int KT = KT1 + (HAS_X2 ? p.K1b / 32 : 0);
+    const int Ktot = KT * 32;
+    const int NC = p.C / CH_BN;
+    unsigned w_voff[PB], w2_voff[PB2];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) w_voff[j] = (unsigned)(((srow + 32 * j) * Ktot + scol) * 4);
+#pragma unroll
+    for (int j = 0; j < PB2; ++j) w2_voff[j] = (unsigned)(((srow + 32 * j) * p.C + scol) * 4);
+
+    // ---- epilogue coordinates: thread = (16-byte column piece, rows erow0 + 16 it) -------------------------------------
+    const int ecol = (tid & 15) * 4;
+    const int erow0 = tid >> 4;
+    constexpr int NIT = CH_BM / 16;
+    unsigned y_voff[NIT];      // the residual view has the output's strides (validated by the launcher): same offsets, other base
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const unsigned m = m0 + erow0 + 16 * it;
+        const bool ok = m < M;
+        const unsigned mm = ok ? m : m0;
+        const unsigned n = mm / HoWo;
+        const unsigned rem = mm - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        y_voff[it] = ok ? (unsigned)(((long)(n - n_blk) * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + ecol) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (long)n_blk * p.ysn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? p.res + (long)n_blk * p.rsn : p.x), 0, 0x7fffffff, 0x00020000);
+    const bool has_post = p.post_s != nullptr, has_pre = p.pre_s != nullptr;
+    const float post_lo = has_post ? 0.f : -__builtin_inff();
+    const float pre_lo = has_pre ? 0.f : -__builtin_inff();
+
+    struct Stage {
+        f32x4 ra[PA], rb[PB];
+    };
+    Stage st;
+    auto load1 = [&](int c, int kt) {   // raw loads of GEMM1 k-step kt of chunk c (nothing waits here)
+        const bool second = HAS_X2 && kt >= KT1;                  // uniform
+        const int a_soff = (second ? kt - KT1 : kt) * 128;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            if constexpr (HAS_X2)
+                st.ra[j] = buf_load(second ? rsrc_x2 : rsrc_x, second ? a2_voff[j] : a_voff[j], a_soff);
+            else
+                st.ra[j] = buf_load(rsrc_x, a_voff[j], a_soff);
+        }
+        const int w_soff = (c * CH_BN * Ktot + kt * 32) * 4;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) st.rb[j] = buf_load(rsrc_w1, w_voff[j], w_soff);
+    };
+    auto store1 = [&](int buf) {
+        float *a = As + buf * CH_BM * 32;
+        float *b = Bs + buf * CH_BN * 32;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) *(f32x4 *)(a + (srow + 32 * j) * 32 + lcol) = st.ra[j];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * 32 + lcol) = st.rb[j];
+    };
+
+    f32x16 acc1[2];
+    f32x16 acc2[TM2][TN2];
+#pragma unroll
+    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    const int key = (l31 >> 1) & 7;
+    const int wm2 = wave / WAVES_N2, wn2 = wave % WAVES_N2;
+
+    auto mma1 = [&](int buf) {          // wave = 32 pixels x 64 channels of the chunk
+        const float *a = As + buf * CH_BM * 32 + (wave * 32 + l31) * 32;
+        const float *b = Bs + buf * CH_BN * 32 + l31 * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = ((2 * q + lh) ^ key) * 4;
+            const f32x4 fa = *(const f32x4 *)(a + off);
+            f32x4 fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * 32 + off);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc1[j], 0, 0, 0);
+            }
+        }
+    };
+    auto mma2 = [&]() {                 // A = the activated chunk in the epilogue tile, B = W1' chunk: two k-steps of 32
+        const float *a = ep + (wm2 * WM2 + l31) * CH_EP;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float *b = B2s + ks * N2 * 32 + (wn2 * WN2 + l31) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 fa[TM2], fb[TN2];
+                const int off = ((2 * q + lh) ^ key) * 4;
+#pragma unroll
+                for (int i = 0; i < TM2; ++i) fa[i] = *(const f32x4 *)(a + i * 32 * CH_EP + ks * 32 + q * 8 + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < TN2; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * 32 + off);
+#pragma unroll
+                for (int i = 0; i < TM2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN2; ++j) {
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc2[i][j], 0, 0, 0);
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc2[i][j], 0, 0, 0);
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc2[i][j], 0, 0, 0);
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc2[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    load1(0, 0);
+    for (int c = 0; c < NC; ++c) {
+        // stage of this chunk's first k-step (loaded during the previous chunk's last one).  FIRST thing of the chunk: the wait
+        // for it also drains the previous chunk's y stores (one vmcnt for loads and stores), which have had all of GEMM2 to
+        // retire -- nothing else may be in flight yet or the wait would include it.
+        store1(0);
+        {
+            // W1' chunk (both k-steps of 32): loaded under the first GEMM1 step, parked in its own LDS region (free since the
+            // barrier behind the previous GEMM2) right after it
+            f32x4 rb2[2][PB2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < PB2; ++j) rb2[ks][j] = buf_load(rsrc_w2, w2_voff[j], ((2 * c + ks) * 32) * 4);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+            // first k-step (KT >= 2: validated by the launcher)
+            load1(c, 1);
+            mma1(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < PB2; ++j) *(f32x4 *)(B2s + ks * N2 * 32 + (srow + 32 * j) * 32 + lcol) = rb2[ks][j];
+            store1(1);
+            __syncthreads();
+        }
+        for (int kt = 1; kt + 1 < KT; ++kt) {
+            load1(c, kt + 1);
+            mma1(kt & 1);
+            store1((kt + 1) & 1);
+            __syncthreads();
+        }
+        // last k-step: the residual tile, then the first stage of the next chunk, fly under it
+        f32x4 rres[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            rres[it] = has_res ? buf_load(rsrc_r, y_voff[it], c * (CH_BN * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c + 1 < NC) load1(c + 1, 0);
+        mma1((KT - 1) & 1);
+        __syncthreads();               // every wave is done reading the staging buffers: the tile may overwrite them
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ep[row * CH_EP + j * 32 + l31] = acc1[j][r];
+            }
+        __syncthreads();
+        // ---- epilogue 1: + residual, block-closing BN-ReLU, store y, next unit's pre-activation back into the tile -----
+        {
+            const int co = c * CH_BN + ecol;
+            f32x4 qs = {1.f, 1.f, 1.f, 1.f}, qb = {0.f, 0.f, 0.f, 0.f}, ps = qs, pb = qb;
+            if (has_post) {
+                qs = *(const f32x4 *)(p.post_s + co);
+                qb = *(const f32x4 *)(p.post_b + co);
+            }
+            if (has_pre) {
+                ps = *(const f32x4 *)(p.pre_s + co);
+                pb = *(const f32x4 *)(p.pre_b + co);
+            }
+            f32x4 vout[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                float *e = ep + (erow0 + 16 * it) * CH_EP + ecol;
+                f32x4 v = *(const f32x4 *)e;
+                v += rres[it];
+                v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
+                v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
+                v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
+                v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
+                vout[it] = v;
+                f32x4 a;
+                a.x = fmaxf(fmaf(v.x, ps.x, pb.x), pre_lo);
+                a.y = fmaxf(fmaf(v.y, ps.y, pb.y), pre_lo);
+                a.z = fmaxf(fmaf(v.z, ps.z, pb.z), pre_lo);
+                a.w = fmaxf(fmaf(v.w, ps.w, pb.w), pre_lo);
+                *(f32x4 *)e = a;
+            }
+            // the stores leave back to back, after every value is final (see hvn_conv.hip: one vmcnt for loads and stores)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) buf_store(vout[it], rsrc_y, y_voff[it], c * (CH_BN * 4));
+        }
+        __syncthreads();
+        mma2();
+        __syncthreads();               // tile and W1' chunk are free again
+    }
+
+    // ---- epilogue 2: t1' = relu(acc2 + b2), 64 output channels at a time through the tile ----------------------------
+    unsigned y2_voff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const unsigned m = m0 + erow0 + 16 * it;
+        const bool ok = m < M;
+        const unsigned mm = ok ? m : m0;
+        const unsigned n = mm / HoWo;
+        const unsigned rem = mm - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        y2_voff[it] = ok ? (unsigned)(((long)(n - n_blk) * p.y2sn + (long)oy * p.y2sy + (long)ox * p.y2sx + ecol) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y2 + (long)n_blk * p.y2sn), 0, 0x7fffffff, 0x00020000);
+    const float relu_lo = p.relu2 ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int h = 0; h < N2 / 64; ++h) {
+        constexpr int JH = 2;                       // 32-column MFMA tiles per 64-channel half
+        const int own = (h * 64) / WN2;             // wave column that holds this half
+        const int jb = ((h * 64) % WN2) / 32;
+        if (wn2 == own) {
+#pragma unroll
+            for (int i = 0; i < TM2; ++i)
+#pragma unroll
+                for (int j = 0; j < JH; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm2 * WM2 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        ep[row * CH_EP + j * 32 + l31] = acc2[i][jb + j][r];
+                    }
+        }
+        __syncthreads();
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias2) bias = *(const f32x4 *)(p.bias2 + h * 64 + ecol);
+        f32x4 vout[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            f32x4 v = *(const f32x4 *)(ep + (erow0 + 16 * it) * CH_EP + ecol);
+            v.x = fmaxf(v.x + bias.x, relu_lo);
+            v.y = fmaxf(v.y + bias.y, relu_lo);
+            v.z = fmaxf(v.z + bias.z, relu_lo);
+            v.w = fmaxf(v.w + bias.w, relu_lo);
+            vout[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) buf_store(vout[it], rsrc_y2, y2_voff[it], h * 256);
+        if (h + 1 < N2 / 64) __syncthreads();
+    }
+}
+
+template <int N2, bool HAS_X2>
+static int launch_chain(const ChainArgs &a, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t)(2 * (CH_BM + CH_BN) * 32 + 2 * N2 * 32) * sizeof(float);
+    static_assert((size_t)CH_BM * CH_EP <= (size_t)2 * (CH_BM + CH_BN) * 32, "the epilogue tile must fit the staging buffers it aliases");
+    static bool attr_done = false;
+    auto kern = hvn_conv_chain_f32<N2, HAS_X2>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    const long grid = (a.M + CH_BM - 1) / CH_BM;
+    if (grid <= 0 || grid > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int hvn_chain_supported(int c, int n2) { return c > 0 && c % CH_BN == 0 && (n2 == 64 || n2 == 128); }
+
+int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream)
+{
+    if (!hvn_chain_supported(a.C, a.N2) || a.K1 <= 0 || a.K1 % 32 || a.K1 + a.K1b < 64 || (a.x2 && (a.K1b <= 0 || a.K1b % 32))) return -1;
+    if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
+    // 32-bit per-thread byte offsets below 2^31 (the top bit marks rows past the end): a tile spans at most two samples
+    const long spans[5] = {2 * a.xsn, a.x2 ? 2 * a.x2sn : 0, 2 * a.ysn, a.res ? 2 * a.rsn : 0, 2 * a.y2sn};
+    for (long s : spans)
+        if (s < 0 || s * 4 >= (1L << 31)) return -1;
+    if ((long)(a.C + 64) * (a.K1 + a.K1b) * 4 >= (1L << 31) || (long)(a.N2 + 64) * a.C * 4 >= (1L << 31)) return -1;
+    if (a.N2 == 64) return a.x2 ? launch_chain<64, true>(a, stream) : launch_chain<64, false>(a, stream);
+    return a.x2 ? launch_chain<128, true>(a, stream) : launch_chain<128, false>(a, stream);
+}

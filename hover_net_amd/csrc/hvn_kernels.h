@@ -33,6 +33,35 @@ struct ConvArgs {
 };
 
 int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);
+
+// Two chained 1x1 convs of a residual block in one launch (hvn_conv_chain.hip):
+//   y  = [relu(. * post_s + post_b)]( W1 . x (+ W1b . x2) + res )        C channels        (a unit's conv3 + shortcut)
+//   y2 = [relu]( W2 . a + bias2 ),  a = relu(y * pre_s + pre_b) or y     N2 channels       (the next unit's conv1)
+struct ChainArgs {
+    const float *x;       // conv3 input view [N][Ho][Wo][K1]
+    long xsn, xsy, xsx;
+    int K1;
+    const float *x2;      // optional second input (the strided 1x1 shortcut's), sampled at (oy * stride2, ox * stride2)
+    long x2sn, x2sy, x2sx;
+    int K1b, stride2;
+    const float *w1;      // [C_pad][(K1 + K1b) / 32][1][32]
+    const float *res;     // optional residual view (may alias y)
+    long rsn, rsy, rsx;
+    float *y;
+    long ysn, ysy, ysx;
+    int C;
+    const float *post_s, *post_b, *pre_s, *pre_b;   // optional per-channel affines [C]
+    const float *w2;      // [N2_pad][C / 32][1][32]
+    const float *bias2;   // optional [N2]
+    int relu2;
+    float *y2;
+    long y2sn, y2sy, y2sx;
+    int N2;
+    int N, Ho, Wo;
+    long M;
+};
+int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream);
+int hvn_chain_supported(int c, int n2);
 int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream);   // x, res, y, x2, w are bf16; bias / scales fp32
 
 struct Conv0Args {

@@ -132,6 +132,8 @@ class Engine:
             else:
                 put((i, "w"), op.w)
             put((i, "bias"), op.bias)
+            put((i, "w2"), op.extra.get("w2"))
+            put((i, "bias2"), op.extra.get("bias2"))
             if op.pre is not None:
                 put((i, "pre_s"), op.pre[0])
                 put((i, "pre_b"), op.pre[1])
@@ -182,7 +184,12 @@ class Engine:
                 o.y.base = self.pred_map.data_ptr()
                 o.y.h, o.y.w, o.y.c = P.pred_map.h, P.pred_map.w, P.pred_map.c
                 continue
-            for fld, v in (("x", op.x), ("res", op.res), ("y", op.y), ("x2", op.extra.get("x2"))):
+            if op.kind == PL.OP_CHAIN:
+                if self.dtype != "fp32":
+                    raise ValueError("OP_CHAIN is fp32 only: build the bf16 plan with chain=False")
+                o.cout2 = int(op.extra["cout2"])
+                o.w2, o.bias2 = self._pptr(i, "w2"), self._pptr(i, "bias2")
+            for fld, v in (("x", op.x), ("res", op.res), ("y", op.y), ("x2", op.extra.get("x2")), ("y2", op.extra.get("y2"))):
                 if v is None:
                     continue
                 if v.buf.offset >= 0:
@@ -280,7 +287,7 @@ class Engine:
             ctypes.memmove(ops, self.ops, ctypes.sizeof(self.ops))
             for i, op in enumerate(self.plan.ops):
                 o = ops[i]
-                for fld in ("x", "res", "y", "x2"):
+                for fld in ("x", "res", "y", "x2", "y2"):
                     v = getattr(o, fld)
                     if v.base:
                         if op.kind == PL.OP_HEAD and fld == "y":

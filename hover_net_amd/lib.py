@@ -16,7 +16,7 @@ VARIANTS = {
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("hvn_conv.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
+SOURCES = ("hvn_conv.hip", "hvn_conv_chain.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
            "hvn_augment.hip", "hvn_train_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fvisibility=hidden", "-Wno-unused-value", "-pthread")
@@ -31,7 +31,8 @@ class hvn_op(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("kind", "kh", "kw", "stride", "pad_t", "pad_l", "relu", "cout", "tile_n", "x_dtype", "groups", "_rsv")] + \
                [("x", hvn_view), ("res", hvn_view), ("y", hvn_view), ("x2", hvn_view)] + \
                [(k, ctypes.c_void_p) for k in ("w", "bias", "pre_scale", "pre_shift", "post_scale", "post_shift")] + \
-               [("batch_stride", ctypes.c_int64 * 3), ("nbatch", ctypes.c_int32), ("act_dtype", ctypes.c_int32)]
+               [("batch_stride", ctypes.c_int64 * 3), ("nbatch", ctypes.c_int32), ("act_dtype", ctypes.c_int32)] + \
+               [("y2", hvn_view), ("w2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("cout2", ctypes.c_int32), ("_rsv2", ctypes.c_int32)]
 
 
 class hvn_top(ctypes.Structure):

@@ -17,6 +17,9 @@ channels-last (NHWC) fp32 activations that stay resident in HBM:
   WINO_IN / WINO_OUT  input / output transforms of the Winograd F(2x2,5x5) form of the 5x5 decoder convs
            (51 % of the network's FLOPs): 36 multiplications per 2x2 outputs instead of 100; the 36
            independent [tiles x cin] . [cin x cout] products run as ONE batched launch of the CONV kernel
+  CHAIN    a residual unit's conv3 (+ residual / fused shortcut, + block-closing BN-ReLU) and the NEXT unit's pre-activation +
+           conv1 in one launch (`fuse_chains`): the 1x1 -> 1x1 seam needs no neighbour pixels, so conv1 runs on the sum while it
+           is still in LDS -- one read of the widest tensor of the block and one launch less per unit
   HEAD     1x1 conv to the 2..6 logits (+bias), written NCHW (the forward() contract)
   PREDMAP  infer_step's softmax / argmax / concat (run_desc.py:185-194)
 
@@ -31,7 +34,7 @@ import numpy as np
 
 from . import arch
 
-OP_CONV0, OP_CONV, OP_UPADD, OP_HEAD, OP_PREDMAP, OP_WINO_IN, OP_WINO_OUT = 1, 2, 3, 4, 5, 6, 7
+OP_CONV0, OP_CONV, OP_UPADD, OP_HEAD, OP_PREDMAP, OP_WINO_IN, OP_WINO_OUT, OP_CHAIN = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 @dataclass
@@ -104,6 +107,8 @@ class Op:
             return self.extra["algo_flops"]
         if self.kind == OP_CONV:
             return 2.0 * self.y.h * self.y.w * self.cout * self.kh * self.kw * self.extra.get("cin_real", self.x.c)
+        if self.kind == OP_CHAIN:
+            return 2.0 * self.y.h * self.y.w * (self.cout * self.extra["cin_real"] + self.extra["cout2"] * self.cout)
         if self.kind == OP_CONV0:
             return 2.0 * self.y.h * self.y.w * 64 * 147
         if self.kind == OP_HEAD:
@@ -183,7 +188,7 @@ class Plan:
 
     def add(self, op):
         i = len(self.ops)
-        for v in (op.x, op.y, op.res):
+        for v in (op.x, op.y, op.res, op.extra.get("y2")):
             if v is not None and v.buf.dtype == "f32":
                 v.buf.first = min(v.buf.first, i)
                 v.buf.last = max(v.buf.last, i)
@@ -266,6 +271,49 @@ class Plan:
                bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m, "r": r})
         return self.add(o)
 
+    def reindex(self):
+        """Recompute every buffer's live interval from the op list (after a pass that merged / removed ops)."""
+        ops, self.ops = self.ops, []
+        for b in self.bufs:
+            b.first, b.last = 10 ** 9, -1
+        for op in ops:
+            self.add(op)
+
+    def fuse_chains(self, max_n2=128):
+        """Merge each residual unit's closing 1x1 conv (conv3: + residual or fused shortcut, optional block-closing BN-ReLU)
+        with the 1x1 conv that directly consumes its output (the next unit's conv1, pre-activation included) into one
+        OP_CHAIN launch (csrc/hvn_conv_chain.hip; net_utils.py:250-266).  Both are per-pixel, so the second runs on the
+        first's output while it is still on chip; results are bit-identical to the two launches."""
+        out, i, ops = [], 0, self.ops
+        while i < len(ops):
+            a = ops[i]
+            b = ops[i + 1] if i + 1 < len(ops) else None
+
+            def plain1x1(o):
+                return (o is not None and o.kind == OP_CONV and o.kh == 1 and o.kw == 1 and o.stride == 1 and o.pad_t == 0 and
+                        not o.extra.get("nbatch") and o.extra.get("groups", 1) == 1)
+
+            ok = (plain1x1(a) and plain1x1(b) and (a.res is not None or a.extra.get("x2") is not None) and a.pre is None and
+                  a.bias is None and not a.relu and a.cout % 64 == 0 and a.x.c + (a.extra["x2"].c if a.extra.get("x2") is not None else 0) >= 64 and
+                  b.res is None and b.extra.get("x2") is None and b.post is None and b.relu == 1 and
+                  b.cout in (64, 128) and b.cout <= max_n2 and
+                  (b.x.buf is a.y.buf and (b.x.y0, b.x.x0, b.x.h, b.x.w, b.x.c0, b.x.c) == (a.y.y0, a.y.x0, a.y.h, a.y.w, a.y.c0, a.y.c)) and
+                  (b.y.h, b.y.w) == (a.y.h, a.y.w) and
+                  (a.res is None or (a.res.buf.w, a.res.buf.c, a.res.h, a.res.w, a.res.c) == (a.y.buf.w, a.y.buf.c, a.y.h, a.y.w, a.y.c)))
+            if not ok:
+                out.append(a)
+                i += 1
+                continue
+            op = Op(OP_CHAIN, a.name + "+" + b.name.split(".", 1)[1] if b.name.split(".")[0] == a.name.split(".")[0] else a.name + "+" + b.name,
+                    x=a.x, y=a.y, res=a.res, w=a.w, post=a.post, pre=b.pre, cout=a.cout, tile_n=0)
+            op.extra.update(cin_real=a.extra["cin_real"], groups=1, cout2=b.cout, w2=b.w, bias2=b.bias, y2=b.y, parts=(a, b))
+            if a.extra.get("x2") is not None:
+                op.extra.update(x2=a.extra["x2"], stride2=a.extra["stride2"], reads=a.extra.get("reads", []))
+            out.append(op)
+            i += 2
+        self.ops = out
+        self.reindex()
+
     # -- memory planning --------------------------------------------------------
     def pack(self, align=64):
         """Greedy interval packing of the per-sample activation arena (floats)."""
@@ -289,11 +337,15 @@ class Plan:
         return sum(o.flops() for o in self.ops)
 
 
-def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None):
+def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None, chain=None):
     """sd: reference-format state_dict (torch tensors or numpy arrays).
     winograd: output tile m (2 or 4) of the Winograd F(m x m, 5x5) form of the 5x5 decoder convs; 0 / False = direct
-    convolution; default 4 (env HVN_WINOGRAD)."""
+    convolution; default 4 (env HVN_WINOGRAD).
+    chain: fuse conv3 -> next conv1 seams of the encoder into OP_CHAIN launches (`Plan.fuse_chains`); default on
+    (env HVN_CHAIN=0 turns it off, HVN_CHAIN_MAXN2 = 64 | 128 bounds the second conv's width); fp32 only."""
     import os
+    if chain is None:
+        chain = os.environ.get("HVN_CHAIN", "1") != "0"
     if winograd is None:
         winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
     wino_m = 4 if winograd is True else int(winograd)
@@ -405,6 +457,8 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         pm = Buf("pred_map", g["out"], g["out"], 3 if nr_types is None else 4)
         P.pred_map = pm
         P.add(Op(OP_PREDMAP, "infer_step.epilogue", y=View(pm), extra={"branches": list(arch.branch_names(nr_types))}))
+    if chain:
+        P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
     # launch lanes: the decoder branches are independent between the shared u3 input and the
     # epilogue, so the engine may run them on concurrent streams (small dense-unit launches of one
     # branch then fill the chip together with the others')

@@ -38,7 +38,7 @@ typedef struct hvn_view {
     int32_t sc;          /* channel stride in elements (CONV0 input only, e.g. h*w for NCHW) */
 } hvn_view;
 
-enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN_OP_PREDMAP = 5, HVN_OP_WINO_IN = 6, HVN_OP_WINO_OUT = 7 };
+enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN_OP_PREDMAP = 5, HVN_OP_WINO_IN = 6, HVN_OP_WINO_OUT = 7, HVN_OP_CHAIN = 8 };
 
 /*
  * One fused launch of the network plan (hover_net_amd/plan.py lowers
@@ -63,6 +63,13 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           kh x kw = tile grid, w = B^T (n x n), stride = m, _rsv = r (both 0: r = 5 and m from y.h = 36 | 64),
  *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [n*n][tiles][cout] per sample, w = A^T (m x n), kh x kw = tile grid
  *           covering y (a partial last tile's surplus outputs are dropped); res = y: accumulate (y += ...),
+ *   CHAIN   two chained 1x1 convs of a residual block (net_utils.py:250-266) in one launch, the second running on the first's
+ *           output while it is still on chip:   y  = post( W.x (+ W'.x2) + res )      -- a unit's conv3 (+ fused shortcut), `cout` channels,
+ *                                               y2 = relu( W2.a + bias2 ), a = relu(y*pre_scale+pre_shift) if pre_scale else y
+ *           -- the next unit's pre-activation + conv1 (+ folded BN), `cout2` in {64, 128} channels; w / w2 packed like CONV
+ *           ([cout_pad][(x.c + x2.c)/32][1][32] and [cout2_pad][cout/32][1][32]); NOTE pre_scale / pre_shift act on y here, not on x;
+ *           res (optional, may alias y) must have y's strides; x.c + x2.c >= 64, cout % 64 == 0.  Bit-identical to the two CONV
+ *           launches it replaces.
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
  *   PREDMAP y.base = [n][h][w][3|4] = [argmax(tp)?, softmax(np)[1], hv0, hv1]
@@ -79,6 +86,10 @@ typedef struct hvn_op {
     int32_t act_dtype;   /* 0: fp32 activations / weights; 1: bf16 activations (x, res, y, x2) and packed weights
                             ([cout_pad][ceil(x.c/64)][kh*kw][64] bf16, zero-filled past x.c), fp32 accumulation, fp32 bias /
                             scales; CONV0 (bf16 output), CONV, UPADD, HEAD (bf16 input, fp32 logits) honour it */
+    /* CHAIN only: the second conv's output view, packed weights, bias (or NULL) and channel count */
+    hvn_view y2;
+    const float *w2, *bias2; /* dev */
+    int32_t cout2, _rsv2;
 } hvn_op;
 
 /* -- library ---------------------------------------------------------------------- */

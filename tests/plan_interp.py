@@ -59,6 +59,27 @@ def conv_ref(op, x, res=None, x2=None):
     return y
 
 
+def chain_ref(op, x, res=None, x2=None):
+    """OP_CHAIN from its OWN fields (include/hvn.h): y = post(W.[x | x2] + res); y2 = relu(W2.a + bias2), a = relu(y*pre) or y."""
+    if x2 is not None:
+        s2 = op.extra["stride2"]
+        x = torch.cat([x, x2[:, ::s2, ::s2][:, :x.shape[1], :x.shape[2]]], -1)
+    w = torch.from_numpy(PL.unpack_conv(op.w, op.cout))[:, :, 0]            # [cout, k]
+    y = x @ w.t()
+    if res is not None:
+        y = y + res
+    if op.post is not None:
+        y = F.relu(y * torch.from_numpy(op.post[0]) + torch.from_numpy(op.post[1]))
+    a = y
+    if op.pre is not None:
+        a = F.relu(y * torch.from_numpy(op.pre[0]) + torch.from_numpy(op.pre[1]))
+    w2 = torch.from_numpy(PL.unpack_conv(op.extra["w2"], op.extra["cout2"]))[:, :, 0]
+    y2 = a @ w2.t()
+    if op.extra.get("bias2") is not None:
+        y2 = y2 + torch.from_numpy(op.extra["bias2"])
+    return y, F.relu(y2)
+
+
 def conv0_ref(op, img_u8):
     x = img_u8.float().permute(0, 3, 1, 2)
     w = torch.from_numpy(op.w).permute(3, 2, 0, 1)  # [7,7,3,64] -> [64,3,7,7]
@@ -142,6 +163,12 @@ def run(plan, imgs_u8, taps=None):
                 res = A.view(op.res).clone() if op.res is not None else None
                 x2 = A.view(op.extra["x2"]).clone() if op.extra.get("x2") is not None else None
                 A.view(op.y).copy_(conv_ref(op, A.view(op.x).clone(), res, x2))
+            elif op.kind == PL.OP_CHAIN:
+                res = A.view(op.res).clone() if op.res is not None else None
+                x2 = A.view(op.extra["x2"]).clone() if op.extra.get("x2") is not None else None
+                y, y2 = chain_ref(op, A.view(op.x).clone(), res, x2)
+                A.view(op.y).copy_(y)
+                A.view(op.extra["y2"]).copy_(y2)
             elif op.kind == PL.OP_UPADD:
                 A.view(op.y).copy_(upadd_ref(A.view(op.x), A.view(op.res)))
             elif op.kind == PL.OP_HEAD:

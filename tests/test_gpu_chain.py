@@ -1,0 +1,115 @@
+"""GPU: OP_CHAIN (csrc/hvn_conv_chain.hip) -- a residual unit's conv3 (+ residual / fused shortcut / block-closing BN-ReLU) chained with
+the next unit's pre-activation + conv1 (/root/reference/models/hovernet/net_utils.py:250-266) -- against the torch interpreter of the
+op's own fields, and BIT-EQUAL to the two CONV launches it replaces (same reduction order per output element)."""
+import numpy as np
+import pytest
+import torch
+
+import plan_interp
+from gpu_util import MiniPlan, rand_conv_weight
+from hover_net_amd import plan as PL
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_convs(n, h, w, k1, c, n2, *, res, x2, post, pre, seed, inplace=True):
+    """conv3-like (k1 [+ x2] -> c, + res, [post]) followed by conv1-like ([pre] c -> n2, bn, relu), over a (h, w) grid."""
+    rng = np.random.default_rng(seed)
+    P = MiniPlan()
+    t2 = PL.View(P.buf("t2", h, w, k1))
+    acc = PL.View(P.buf("acc", h, w, c))
+    out = acc if inplace else PL.View(P.buf("out", h, w, c))
+    t1 = PL.View(P.buf("t1", h, w, n2))
+    kw = {}
+    if x2:
+        k1b, s2 = x2
+        xin = PL.View(P.buf("block_in", (h - 1) * s2 + 1, (w - 1) * s2 + 2, k1b))      # one surplus column: the view is wider than the grid
+        kw.update(x2=xin, wt2=rand_conv_weight(rng, c, k1b, 1), stride2=s2)
+    if res:
+        kw["res"] = acc
+    if post:
+        kw["post"] = (rng.uniform(0.5, 1.5, c), rng.normal(0, 0.3, c))
+    P.conv("u.conv3", t2, out, rand_conv_weight(rng, c, k1, 1), **kw)
+    P.conv("v.conv1", out, t1, rand_conv_weight(rng, n2, c, 1), bn=(rng.uniform(0.5, 1.5, n2), rng.normal(0, 0.2, n2)), relu=1,
+           pre=(rng.uniform(0.5, 1.5, c), rng.normal(0, 0.3, c)) if pre else None)
+    return P, (t2, acc, out, t1)
+
+
+def _run(P, n, seed):
+    from hover_net_amd.engine import Engine
+
+    P.pack()
+    eng = Engine(P, max_batch=n)
+    g = torch.Generator().manual_seed(seed)
+    eng.arena.copy_(torch.randn(eng.arena.shape, generator=g))
+    start = eng.arena.cpu().clone()
+    eng.run_raw(n)
+    torch.cuda.synchronize()
+    return eng, start
+
+
+CASES = [
+    # n, h, w, k1, c, n2, res, x2 (k1b, stride2), post, pre
+    (2, 24, 24, 64, 256, 64, True, None, False, True),        # d0 units 1..2 -> next conv1 (exact multiple of the 128-pixel tile)
+    (3, 19, 23, 64, 256, 64, True, None, False, True),        # ragged: tiles straddle samples, tail rows past M
+    (2, 17, 21, 64, 256, 64, False, (64, 1), False, True),    # d0 unit 0: fused shortcut, no residual
+    (2, 15, 18, 64, 256, 128, True, None, True, False),       # d0 last unit: block-closing BN-ReLU, feeds d1 unit 0 (no pre-activation)
+    (2, 13, 11, 128, 512, 128, False, (256, 2), False, True), # d1 unit 0: strided shortcut appended to k (K = 384, 12 k-steps)
+    (1, 16, 16, 128, 512, 128, True, None, False, True),      # d1 units 1..3
+    (1, 9, 10, 32, 64, 64, False, (32, 1), False, True),      # smallest legal shape: K = 32 + 32, one 64-channel chunk
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_chain_matches_reference_and_unfused_launches(case):
+    n, h, w, k1, c, n2, res, x2, post, pre = case
+    # fused
+    P, (t2, acc, out, t1) = _two_convs(n, h, w, k1, c, n2, res=res, x2=x2, post=post, pre=pre, seed=7, inplace=not post)
+    P.fuse_chains()
+    assert [o.kind for o in P.ops] == [PL.OP_CHAIN]
+    eng, start = _run(P, n, seed=11)
+    got = eng.arena.cpu()
+    # torch interpreter on the same arena contents, from the CHAIN op's own fields
+    A = plan_interp.Arena(P, n)
+    A.flat.copy_(start)
+    op = P.ops[0]
+    r = A.view(op.res).clone() if op.res is not None else None
+    xx2 = A.view(op.extra["x2"]).clone() if op.extra.get("x2") is not None else None
+    y, y2 = plan_interp.chain_ref(op, A.view(op.x).clone(), r, xx2)
+    A.view(op.y).copy_(y)
+    A.view(op.extra["y2"]).copy_(y2)
+    want = A.flat
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, scale)
+    # nothing outside the two output views was touched
+    untouched = torch.ones_like(start, dtype=torch.bool)
+    for v in (op.y, op.extra["y2"]):
+        b = v.buf
+        m = untouched[:, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
+        m[:, v.y0:v.y0 + v.h, v.x0:v.x0 + v.w, v.c0:v.c0 + v.c] = False
+    assert torch.equal(got[untouched], start[untouched])
+    # the two separate launches: same bits
+    Q, _ = _two_convs(n, h, w, k1, c, n2, res=res, x2=x2, post=post, pre=pre, seed=7, inplace=not post)
+    assert [o.kind for o in Q.ops] == [PL.OP_CONV, PL.OP_CONV]
+    eng2, start2 = _run(Q, n, seed=11)
+    assert Q.arena_per_sample == P.arena_per_sample and torch.equal(start, start2)
+    assert torch.equal(eng2.arena.cpu(), got)
+
+
+def test_network_with_and_without_chains_is_bit_equal(monkeypatch):
+    from hover_net_amd import net_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+
+    tiles = torch.from_numpy(synth_tiles(2, 270, seed=3)).cuda()
+    outs = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("HVN_CHAIN", chain)
+        net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
+        net.load_state_dict(synth_state_dict("original", 5, seed=2), strict=True)
+        net = net.cuda().eval()
+        eng = net.engine(2)
+        assert any(o.kind == PL.OP_CHAIN for o in eng.plan.ops) == (chain == "1")
+        logits, pred = eng.run(tiles)
+        outs.append({k: v.clone() for k, v in logits.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k

@@ -97,4 +97,4 @@ def test_abi_exports_every_declared_symbol():
     lib = L.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hvn_version() == 101
+    assert lib.hvn_version() == 102

@@ -15,7 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hover_net_amd import lib as L  # noqa: E402
 from hover_net_amd import net_desc, run_desc  # noqa: E402
-from hover_net_amd.plan import OP_CONV, OP_WINO_IN, OP_WINO_OUT  # noqa: E402
+from hover_net_amd.plan import OP_CHAIN, OP_CONV, OP_WINO_IN, OP_WINO_OUT  # noqa: E402
 from hover_net_amd.synth import synth_state_dict, synth_tiles  # noqa: E402
 
 
@@ -39,8 +39,9 @@ def main():
         run_desc.infer_step_device(tiles, net)
     torch.cuda.synchronize()
     eng = net.engine(args.batch)
-    marked = [(o.name, o.kind, eng.ops[i].tile_n if o.kind == OP_CONV else 0, o.extra.get("exec_flops", o.flops()) * args.batch if o.kind == OP_CONV else 0.0)
-              for i, o in enumerate(eng.plan.ops) if o.kind in (OP_CONV, OP_WINO_IN, OP_WINO_OUT)]
+    marked = [(o.name, o.kind, eng.ops[i].tile_n if o.kind == OP_CONV else 0,
+               o.extra.get("exec_flops", o.flops()) * args.batch if o.kind in (OP_CONV, OP_CHAIN) else 0.0)
+              for i, o in enumerate(eng.plan.ops) if o.kind in (OP_CONV, OP_CHAIN, OP_WINO_IN, OP_WINO_OUT)]
     buf = (ctypes.c_double * 4096)()
     rows = []
     for _ in range(args.reps):
@@ -52,7 +53,7 @@ def main():
     ms = np.median(np.stack(rows), 0)
     names = marked if len(marked) == len(ms) else [("launch%d" % i, -1, 0, 0.0) for i in range(len(ms))]
     for (name, kind, tn, fl), t in zip(names, ms):
-        print("%-46s %d %3d %9.1f" % (name, kind, tn, t * 1e3) + ("   %7.1f TFLOP/s" % (fl / t / 1e9) if fl else ""))
+        print("%-62s %d %3d %9.1f" % (name, kind, tn, t * 1e3) + ("   %7.1f TFLOP/s" % (fl / t / 1e9) if fl else ""))
     print("TOTAL variant=%s force=%s slots64=%s cost64=%s launches=%d conv_ms=%.3f" % (
         os.environ.get("HVN_LIB_VARIANT", "-"), os.environ.get("HVN_FORCE_TILE_N", "-"), os.environ.get("HVN_WG_SLOTS_64", "-"),
         os.environ.get("HVN_NARROW_COST", "-"), len(ms), ms.sum()))

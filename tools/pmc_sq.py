@@ -14,9 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hover_net_amd.plan import build_plan  # noqa: E402
 from hover_net_amd.synth import synth_state_dict  # noqa: E402
 
-n = sum(1 for o in build_plan(synth_state_dict("original", 5, seed=0), "original", 5).ops if o.kind == 2)
+n = sum(1 for o in build_plan(synth_state_dict("original", 5, seed=0), "original", 5).ops if o.kind in (2, 8))
 c = sqlite3.connect(sys.argv[1])
-ids = [r[0] for r in c.execute("select dispatch_id, min(start) from counters_collection where (kernel_name like '%igemm%' or kernel_name like '%dense_grouped%') "
+ids = [r[0] for r in c.execute("select dispatch_id, min(start) from counters_collection where (kernel_name like '%igemm%' or kernel_name like '%conv_chain%' or kernel_name like '%dense_grouped%') "
                                "group by dispatch_id order by min(start)")][-n:]
 q = ",".join(str(i) for i in ids)
 tot = dict(c.execute("select counter_name, sum(value) from counters_collection where dispatch_id in (%s) group by counter_name" % q))

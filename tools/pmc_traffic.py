@@ -17,12 +17,12 @@ from hover_net_amd.synth import synth_state_dict  # noqa: E402
 def total(db, counter, n_last):
     c = sqlite3.connect(db)
     rows = list(c.execute("select dispatch_id, sum(value), min(start) from counters_collection "
-                          "where (kernel_name like '%igemm%' or kernel_name like '%dense_grouped%') and counter_name=? group by dispatch_id order by min(start)", (counter,)))
+                          "where (kernel_name like '%igemm%' or kernel_name like '%conv_chain%' or kernel_name like '%dense_grouped%') and counter_name=? group by dispatch_id order by min(start)", (counter,)))
     rows = rows[-n_last:]
     return sum(r[1] for r in rows), len(rows)
 
 
-n = sum(1 for o in build_plan(synth_state_dict("original", 5, seed=0), "original", 5).ops if o.kind == 2)   # conv launches / step
+n = sum(1 for o in build_plan(synth_state_dict("original", 5, seed=0), "original", 5).ops if o.kind in (2, 8))   # conv launches / step
 fetch_kb, nf = total(sys.argv[1], "FETCH_SIZE", n)
 write_kb, nw = total(sys.argv[2], "WRITE_SIZE", n)
 out = {"launches": nf, "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
