@@ -24,7 +24,10 @@
 // W1' chunk [2][N2][32] behind it.  64 KB (N2 = 64) / 80 KB (N2 = 128): two workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "hvn_kernels.h"
 
@@ -204,8 +207,14 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         }
     };
 
+    // diagnosis (HVN_CHAIN_TRACE): cycle stamps of one steady-state chunk (the second, or the only one) of every workgroup
+    unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int c_dbg = p.dbg ? (NC > 1 ? 1 : 0) : -1;
+#define CH_STAMP(i) if (c == c_dbg) ts[i] = __builtin_readcyclecounter()
+    if (p.dbg) ts[0] = __builtin_readcyclecounter();
     load1(0, 0);
     for (int c = 0; c < NC; ++c) {
+        CH_STAMP(1);
         // stage of this chunk's first k-step (loaded during the previous chunk's last one).  FIRST thing of the chunk: the wait
         // for it also drains the previous chunk's y stores (one vmcnt for loads and stores), which have had all of GEMM2 to
         // retire -- nothing else may be in flight yet or the wait would include it.
@@ -219,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
 #pragma unroll
                 for (int j = 0; j < PB2; ++j) rb2[ks][j] = buf_load(rsrc_w2, w2_voff[j], ((2 * c + ks) * 32) * 4);
             __syncthreads();
+            CH_STAMP(2);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
             rres[it] = has_res ? buf_load(rsrc_r, y_voff[it], c * (CH_BN * 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (c + 1 < NC) load1(c + 1, 0);
         mma1((KT - 1) & 1);
+        CH_STAMP(3);
         __syncthreads();               // every wave is done reading the staging buffers: the tile may overwrite them
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
                 ep[row * CH_EP + j * 32 + l31] = acc1[j][r];
             }
         __syncthreads();
+        CH_STAMP(4);
         // ---- epilogue 1: + residual, block-closing BN-ReLU, store y, next unit's pre-activation back into the tile -----
         {
             const int co = c * CH_BN + ecol;
@@ -292,10 +304,14 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) buf_store(vout[it], rsrc_y, y_voff[it], c * (CH_BN * 4));
         }
+        CH_STAMP(5);
         __syncthreads();
+        CH_STAMP(6);
         mma2();
+        CH_STAMP(7);
         __syncthreads();               // tile and W1' chunk are free again
     }
+    if (p.dbg) ts[8] = __builtin_readcyclecounter();
 
     // ---- epilogue 2: t1' = relu(acc2 + b2), 64 output channels at a time through the tile ----------------------------
     unsigned y2_voff[NIT];
@@ -344,6 +360,14 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         for (int it = 0; it < NIT; ++it) buf_store(vout[it], rsrc_y2, y2_voff[it], h * 256);
         if (h + 1 < N2 / 64) __syncthreads();
     }
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[9] = __builtin_readcyclecounter();
+        unsigned long long *d = p.dbg + 10ull * blockIdx.x;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) d[i] = ts[i];
+    }
+#undef CH_STAMP
 }
 
 template <int N2, bool HAS_X2>
@@ -359,7 +383,25 @@ static int launch_chain(const ChainArgs &a, hipStream_t stream)
     }
     const long grid = (a.M + CH_BM - 1) / CH_BM;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    static unsigned long long *dbg_buf = nullptr;
+    static int dbg_on = -1;
+    if (dbg_on < 0) {
+        const char *e = getenv("HVN_CHAIN_TRACE");   // path of a file to dump the per-workgroup stamps of the LAST launch into
+        dbg_on = e ? 1 : 0;
+        if (dbg_on) hipMalloc(&dbg_buf, 10 * 8 * (size_t)(1 << 20));
+    }
+    ChainArgs p = a;
+    p.dbg = (dbg_on && grid <= (1 << 20)) ? dbg_buf : nullptr;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    if (p.dbg) {   // experiment mode only: synchronous dump
+        hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(10 * (size_t)grid);
+        hipMemcpy(h.data(), dbg_buf, 8 * h.size(), hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("HVN_CHAIN_TRACE"), "wb")) {
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

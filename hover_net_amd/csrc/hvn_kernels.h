@@ -59,6 +59,7 @@ struct ChainArgs {
     int N2;
     int N, Ho, Wo;
     long M;
+    unsigned long long *dbg;   // optional (HVN_CHAIN_TRACE): 10 cycle stamps per workgroup, see tools/chain_bench.py
 };
 int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream);
 int hvn_chain_supported(int c, int n2);

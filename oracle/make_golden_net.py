@@ -18,11 +18,12 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
-sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, HERE)
+from refimport import out_dir, ref_import, selected, use_reference  # noqa: E402
 
-import models.hovernet.net_desc as ref_net  # noqa: E402  the reference, unmodified
+use_reference()
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+ref_net = ref_import("models.hovernet.net_desc")  # the reference, unmodified (asserted to live under /root/reference)
 import torch.nn.functional as F  # noqa: E402
 from collections import OrderedDict  # noqa: E402
 from hover_net_amd.synth import synth_state_dict, synth_tiles  # noqa: E402
@@ -33,8 +34,9 @@ CASES = {  # name: (mode, nr_types, weight seed, tile seed, n tiles, stored crop
     "fast6": ("fast", 6, 7, 8, 1, 64),
 }
 torch.set_num_threads(8)
-out_dir = os.path.join(REPO, "tests", "golden")
-for name, (mode, nt, wseed, tseed, n, crop) in CASES.items():
+out_dir = out_dir()
+for name in selected(CASES):
+    mode, nt, wseed, tseed, n, crop = CASES[name]
     net = ref_net.create_model(mode=mode, nr_types=nt, input_ch=3).eval()
     net.load_state_dict(synth_state_dict(mode, nt, seed=wseed), strict=True)
     size = 270 if mode == "original" else 256

@@ -16,16 +16,15 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "cv2_shim"))
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+from refimport import out_dir, ref_import, selected, use_reference  # noqa: E402
 
-import models.hovernet.post_proc as pp  # noqa: E402  the reference, unmodified
+use_reference(first=[os.path.join(HERE, "cv2_shim")])
+pp = ref_import("models.hovernet.post_proc")  # the reference, unmodified (asserted to live under /root/reference)
 from hover_net_amd.synth import synth_pred_maps  # noqa: E402
 
 proc_np_hv = getattr(pp, "__proc_np_hv")
-out_dir = os.path.join(REPO, "tests", "golden")
-os.makedirs(out_dir, exist_ok=True)
+out_dir = out_dir()
 
 
 def run(pred):
