@@ -19,14 +19,17 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "cv2_shim_scipy"))
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+from refimport import ref_import, use_reference  # noqa: E402
+
+use_reference(first=[os.path.join(HERE, "cv2_shim_scipy")])
 sys.modules.setdefault("matplotlib", types.ModuleType("matplotlib"))
 sys.modules.setdefault("matplotlib.pyplot", types.ModuleType("matplotlib.pyplot"))
 
 import cv2  # noqa: E402
-import models.hovernet.post_proc as pp  # noqa: E402  the reference, unmodified
-from metrics.stats_utils import get_fast_pq, remap_label  # noqa: E402  the reference's own metric
+pp = ref_import("models.hovernet.post_proc")  # the reference, unmodified (asserted to live under /root/reference)
+_stats = ref_import("metrics.stats_utils")       # the reference's own metric
+get_fast_pq, remap_label = _stats.get_fast_pq, _stats.remap_label
 
 assert "cv2_shim_scipy" in cv2.__file__
 proc_np_hv = getattr(pp, "__proc_np_hv")

@@ -14,11 +14,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "cv2_shim"))
 sys.path.insert(0, HERE)
-sys.path.insert(0, "/root/reference")
+from refimport import out_dir, ref_import, use_reference  # noqa: E402
 
-import dataloader.augs as ref  # noqa: E402  the reference, unmodified
+use_reference(first=[os.path.join(HERE, "cv2_shim"), HERE])
+ref = ref_import("dataloader.augs")  # the reference, unmodified (asserted to live under /root/reference)
 
 
 class Draws:
@@ -67,5 +67,5 @@ for name, fn, rng_arg, vals in (("hue", ref.add_to_hue, (-8, 8), [-8.0, -3.3, 0.
         res.append(fn([img[k]], d, None, None, range=rng_arg)[0])
         assert d.asked == [("uniform",) + rng_arg] and res[-1].dtype == np.uint8
     out[name + "_val"], out[name + "_out"] = np.array(vals), np.stack(res)
-np.savez_compressed(os.path.join(REPO, "tests", "golden", "augs.npz"), **out)
+np.savez_compressed(os.path.join(out_dir(), "augs.npz"), **out)
 print("wrote tests/golden/augs.npz", {k: v.shape for k, v in out.items()})

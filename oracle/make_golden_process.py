@@ -18,14 +18,14 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "cv2_shim"))
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+from refimport import out_dir, ref_import, selected, use_reference  # noqa: E402
 
-import models.hovernet.post_proc as pp  # noqa: E402  the reference, unmodified
+use_reference(first=[os.path.join(HERE, "cv2_shim")])
+pp = ref_import("models.hovernet.post_proc")  # the reference, unmodified (asserted to live under /root/reference)
 from hover_net_amd.synth import synth_pred_maps  # noqa: E402
 
-out_dir = os.path.join(REPO, "tests", "golden")
+out_dir = out_dir()
 
 
 def flatten(results):
@@ -74,7 +74,8 @@ for p in punched:
     p[..., 1][n / n.std() > 1.3] = 0.1
 cases["punched120t"] = (punched, 5)
 
-for name, (pred, nt) in cases.items():
+for name in selected(cases):
+    pred, nt = cases[name]
     res = [pp.process(p, nr_types=nt, return_centroids=True) for p in pred]
     z = flatten(res)
     np.savez_compressed(os.path.join(out_dir, "proc_%s.npz" % name), pred=pred, nr_types=np.int32(-1 if nt is None else nt), **z)

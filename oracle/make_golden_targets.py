@@ -16,8 +16,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "cv2_shim"))
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+from refimport import out_dir, ref_import, use_reference  # noqa: E402
+
+use_reference(first=[os.path.join(HERE, "cv2_shim")])
 for name in ("torch", "torch.nn", "torch.nn.functional"):
     sys.modules.setdefault(name, types.ModuleType(name))
 sys.modules["torch"].nn = sys.modules["torch.nn"]
@@ -25,7 +27,7 @@ sys.modules["torch.nn"].functional = sys.modules["torch.nn.functional"]
 
 import importlib.util  # noqa: E402
 
-import models.hovernet.targets as ref_targets  # noqa: E402  the reference, unmodified
+ref_targets = ref_import("models.hovernet.targets")  # the reference, unmodified (asserted to live under /root/reference)
 
 spec = importlib.util.spec_from_file_location("targets_np", os.path.join(HERE, "targets_np.py"))
 tn = importlib.util.module_from_spec(spec)
@@ -41,4 +43,4 @@ for k, (size, crop, n_inst, mirror, seed) in enumerate(CASES):
     out["np%d" % k] = t["np_map"].astype(np.uint8)
     out["crop%d" % k] = crop
     print(k, ann.shape, int(ann.max()), float(np.abs(t["hv_map"]).sum()), int(t["np_map"].sum()))
-np.savez_compressed(os.path.join(REPO, "tests", "golden", "targets.npz"), n=len(CASES), **out)
+np.savez_compressed(os.path.join(out_dir(), "targets.npz"), n=len(CASES), **out)

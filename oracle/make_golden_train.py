@@ -19,15 +19,17 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+from refimport import out_dir, ref_import, selected, use_reference  # noqa: E402
+
+use_reference()
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
 
 import torch.nn.functional as F  # noqa: E402
 from collections import OrderedDict  # noqa: E402
 
-import models.hovernet.net_desc as ref_net  # noqa: E402  the reference, unmodified
-import models.hovernet.utils as ref_utils  # noqa: E402
+ref_net = ref_import("models.hovernet.net_desc")   # the reference, unmodified (asserted to live under /root/reference)
+ref_utils = ref_import("models.hovernet.utils")
 from hover_net_amd.synth import synth_state_dict, synth_train_batch  # noqa: E402
 
 _arange = torch.arange
@@ -48,8 +50,9 @@ def sample_idx(numel):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    out_dir = os.path.join(REPO, "tests", "golden")
-    for name, (mode, nt, freeze, wseed, bseed, n) in CASES.items():
+    out_dir = out_dir()
+    for name in selected(CASES):
+        mode, nt, freeze, wseed, bseed, n = CASES[name]
         net = ref_net.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
         net.load_state_dict(synth_state_dict(mode, nt, seed=wseed), strict=True)
         batch = synth_train_batch(n, mode, nt, seed=bseed)

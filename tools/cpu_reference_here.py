@@ -26,6 +26,7 @@ import sys, time, numpy as np
 from concurrent.futures import ProcessPoolExecutor
 sys.path.insert(0, sys.argv[1] + "/oracle/cv2_shim"); sys.path.insert(0, "/root/reference")
 import models.hovernet.post_proc as pp
+assert pp.__file__.startswith('/root/reference/'), pp.__file__
 maps = np.load(sys.argv[2]); workers = int(sys.argv[3]); nt = int(sys.argv[4])
 def run(m):
     inst, info = pp.process(m, nr_types=nt, return_centroids=True)
@@ -48,6 +49,7 @@ def main():
     import torch.nn.functional as F
 
     import models.hovernet.net_desc as nd              # the reference, unmodified
+    assert nd.__file__.startswith("/root/reference/"), nd.__file__   # never the in-tree `models/` shim package
     from hover_net_amd.synth import synth_pred_maps, synth_state_dict, synth_tiles
 
     cores = len(os.sched_getaffinity(0))
