@@ -8,11 +8,13 @@ instance maps + record tables to rank 0] -> D2H of instance maps, records and co
 memory.  The post-processing of step i runs on a side stream under the network of step i+1
 (hover_net_amd/pipeline.py); nothing inside a step waits on the host.
 
-`value` = tiles/s over exactly --steps steps, inputs resident in HBM, results on the host.  Two more rates
-are measured in separate, untimed-by-the-driver legs and reported under `variants` (SURVEY 8d defines the
-metric from pinned host memory to host results): `host_to_host` (tiles start in pinned host memory, H2D
-inside) and `with_dict` (additionally the contour tracing + inst_info_dict assembly of the structured maps on
-the host, i.e. everything `post_proc.process` returns).  `sustained` repeats the timed step for >= 8 s.
+`value` = tiles/s over exactly --steps steps, inputs resident in HBM when the timed region starts, results on the
+host (the bench contract).  SURVEY 8d defines the metric from pinned host memory to host results: that rate is
+measured over the same K steps right after and reported at the TOP LEVEL as `value_host_to_host` (and under
+`variants.host_to_host`); `with_dict` additionally runs the contour tracing + inst_info_dict assembly of the
+structured maps on the host, i.e. everything `post_proc.process` returns; `sustained` repeats the timed step for
+>= 8 s; `variants.cfg3_fast_b64_bf16` is BASELINE cfg 3 (fast mode, 6 types, batch 64, bf16) with its own
+roofline against the bf16 matrix peak.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Tiles are independent units: every rank
 runs the network + instance separation on its own batch (weak scaling, global batch = 32 N) and the results
@@ -114,6 +116,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the host_to_host / with_dict / sustained legs")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the variants.cfg3_fast_b64_bf16 leg (BASELINE cfg 3)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two `rocprofv3 --pmc` child runs of this script); the last committed "
+                         "profiles/*_pmc_traffic.json is quoted instead, and the line says so")
+    ap.add_argument("--traffic-timeout", type=float, default=150.0, help="seconds per PMC child run")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: one untimed step and nothing else (the run rocprofv3 --pmc wraps)")
     ap.add_argument("--sustain-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--quiet-net-output", action="store_true",
@@ -218,6 +226,10 @@ def main():
             dt = float(t.item())
         return dt, out
 
+    if args.pmc_child:              # counters are collected per dispatch by the wrapping rocprofv3: one plan execution is all it needs
+        step()
+        torch.cuda.synchronize(dev)
+        return
     for _ in range(args.warmup):
         step()
     dt, out = timed(step, args.steps)
@@ -251,32 +263,44 @@ def main():
                    "execution": "network on one HIP stream, post-processing + gather + D2H on a side stream under the next network pass"},
     }
 
-    # ---- per-stage split of one batch (rank 0, untimed extra passes, torch events on the launch stream) -------------
+    # ---- per-stage split of one batch (rank 0): each stage ALONE on the launch stream, warmed, median of 5 passes ------
+    # (a stage alone is not a share of the pipelined step: there the post-processing of batch i runs under the network of
+    #  batch i+1; `network` <= `ms_per_step` holds because the step contains one whole network pass)
     if rank == 0:
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        def med_ms(fn, reps=5, warm=2, inner=1):
+            """median over `reps` of (time of `inner` back-to-back calls) / inner: with inner > 1 the host runs ahead of the GPU as
+            it does in the pipelined step (a single pass from an idle stream pays ~0.7 ms of launch gaps over ~180 launches)"""
+            ts = []
+            for r in range(warm + reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(inner):
+                    out_ = fn()
+                e1.record()
+                e1.synchronize()
+                if r >= warm:
+                    ts.append(e0.elapsed_time(e1) / inner)
+            return sorted(ts)[len(ts) // 2], out_
+
         torch.cuda.synchronize(dev)
-        ev[0].record()
-        pred = run_desc.infer_step_device(tiles[0], net)
-        ev[1].record()
-        inst, rec, counts = post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True)
-        ev[2].record()
-        host = [t.cpu() for t in (inst, rec, counts)]
-        ev[3].record()
-        torch.cuda.synchronize(dev)
+        net_ms, pred = med_ms(lambda: run_desc.infer_step_device(tiles[0], net), inner=4)
+        pp_ms, (inst, rec, counts) = med_ms(lambda: post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True))
+        d2h_ms, host = med_ms(lambda: [t.cpu() for t in (inst, rec, counts)])
         t1 = time.perf_counter()
         rec_h, inst_h = host[1].numpy(), host[0].numpy()
         dicts = [post_proc.records_to_dict(rec_h[i].view(post_proc._REC_DTYPE).reshape(-1), nt, inst_h[i]) for i in range(inst_h.shape[0])]
         dict_ms = 1e3 * (time.perf_counter() - t1)
-        result["config"]["stage_ms"] = {"network": ev[0].elapsed_time(ev[1]), "postproc_structured": ev[1].elapsed_time(ev[2]),
-                                        "d2h_results": ev[2].elapsed_time(ev[3]), "host_contours_and_dict": dict_ms,
-                                        "instances_in_dicts": sum(len(d) for d in dicts)}
+        result["config"]["stage_ms"] = {"network": net_ms, "postproc_structured": pp_ms, "d2h_results": d2h_ms,
+                                        "host_contours_and_dict": dict_ms, "instances_in_dicts": sum(len(d) for d in dicts),
+                                        "how": "each stage alone on the launch stream, median of 5 warmed measurements (network: 4 back-to-back passes per measurement)"}
 
     # ---- variants (untimed by the driver; same K steps each) ---------------------------------------------------------
     if not args.no_variants:
         variants = {}
         dt_h, _ = timed(lambda: step(tiles_host), args.steps)
-        variants["host_to_host"] = {"value": tiles_per_step_global * args.steps / dt_h, "unit": "tiles/s",
-                                    "what": "tiles start in pinned host memory (H2D inside the step), results end in pinned host memory"}
+        variants["host_to_host"] = {"value": tiles_per_step_global * args.steps / dt_h, "unit": "tiles/s", "ms_per_step": 1e3 * dt_h / args.steps,
+                                    "what": "SURVEY 8d's definition: tiles start in pinned host memory (H2D inside the step), results end in pinned host memory"}
+        result["value_host_to_host"] = variants["host_to_host"]["value"]
         if world == 1:
             prev = [None]
 
@@ -292,7 +316,21 @@ def main():
                         post_proc.records_to_dict(rh[i].view(post_proc._REC_DTYPE).reshape(-1), nt, ih[i])
                 return o
 
-            dt_d, _ = timed(step_dict, args.steps)
+            def steps_dict_then_flush():
+                # K GPU steps carry K-1 host halves (each under the NEXT step's GPU work); the last step's host half runs here,
+                # inside the timed region, so that exactly K dictionaries sets are built per K steps
+                calls[0] += 1
+                o = step_dict()
+                if calls[0] % args.steps == 0 and prev[0] is not None:
+                    done, prev[0] = prev[0], None
+                    done[1].synchronize()
+                    ih, rh = done[0][0].numpy().copy(), done[0][1].numpy().copy()
+                    for i in range(ih.shape[0]):
+                        post_proc.records_to_dict(rh[i].view(post_proc._REC_DTYPE).reshape(-1), nt, ih[i])
+                return o
+
+            calls = [0]
+            dt_d, _ = timed(steps_dict_then_flush, args.steps)
             variants["with_dict"] = {"value": tiles_per_step_global * args.steps / dt_d, "unit": "tiles/s",
                                      "what": "host_to_host + contour tracing and inst_info_dict assembly on the host (one thread), "
                                              "overlapped with the next step's GPU work"}
@@ -315,43 +353,122 @@ def main():
         result["variants"] = variants
 
     # ---- roofline of the dominant kernel (rank 0) ---------------------------------------------------------------------
-    if rank == 0 and not args.no_roofline:
-        eng = net.engine(args.batch)
+    def roofline_of(net_, tiles0, batch, dtype, n_prof=5):
+        eng = net_.engine(batch)
         assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: HVN_SPLIT=1 HVN_LANES=0"
-        n_prof = 5
-        algo_flops = sum(o.flops() for o in eng.plan.ops if o.kind in (2, 8)) * args.batch
-        exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in eng.plan.ops if o.kind in (2, 8)) * args.batch
+        convs = [o for o in eng.plan.ops if o.kind in (2, 8)]          # CONV + CHAIN (two chained 1x1 convs) launches
+        algo_flops = sum(o.flops() for o in convs) * batch
+        exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in convs) * batch
         torch.cuda.synchronize(dev)
         ms_list, launches = [], 0
         for _ in range(n_prof):
             L.lib().hvn_profile_enable(1)
-            run_desc.infer_step_device(tiles[0], net)           # same engine, same single launch stream as the timed steps
+            run_desc.infer_step_device(tiles0, net_)            # same engine, same single launch stream as the timed steps
             ms_list.append(L.lib().hvn_profile_conv_ms())
             launches = L.lib().hvn_profile_conv_launches()
             L.lib().hvn_profile_enable(0)
         ms = sorted(ms_list)[len(ms_list) // 2]
-        n_conv = sum(1 for o in eng.plan.ops if o.kind in (2, 8))     # CONV + CHAIN (two chained 1x1 convs) launches
-        peak = PEAK_FP32_MATRIX_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+        n_conv = len(convs)
+        peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
         achieved = exec_flops / (ms * 1e-3) / 1e12
-        traffic, tsrc = None, None
-        for name in ("r02_pmc_traffic.json",):
-            tpath = os.path.join(REPO, "profiles", name)
-            if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5 and args.dtype == "fp32":
-                traffic, tsrc = json.load(open(tpath))["hbm_bytes_per_step"] / max(1, n_conv), name
-        result["roofline"] = {
-            "bound": "mfma", "kernel": "hvn_conv_igemm_f32" if args.dtype == "fp32" else "hvn_conv_igemm_bf16",
-            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": traffic,
-            "traffic_unit": "HBM bytes per conv launch, mean over the step's launches (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                            "separate passes; profiles/%s)" % tsrc if traffic is not None else None,
+        return {
+            "bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)" if dtype == "fp32" else "hvn_conv_igemm_bf16",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
             "flops_per_launch": exec_flops / max(1, n_conv), "avg_launch_ms": ms / max(1, launches),
             "timed_launches_per_step": launches, "conv_launches_per_step": n_conv,
             "conv_ms_per_step": ms, "executed_gflop_per_step": exec_flops / 1e9,
             "algorithmic_gflop_per_step": algo_flops / 1e9, "algorithmic_speedup": algo_flops / exec_flops,
             "note": "achieved = MFMA FLOPs executed by the conv launches of one step (Winograd-domain GEMMs counted as issued; "
-                    "SURVEY 8d's 392.17 GFLOP/tile direct-convolution figure is `algorithmic_gflop_per_step` / batch) / summed "
-                    "HIP-event time of those launches incl. the Winograd transform launches, median of %d passes, single stream" % n_prof}
+                    "SURVEY 8d's direct-convolution figure is `algorithmic_gflop_per_step` / batch) / summed HIP-event time of those "
+                    "launches incl. the Winograd transform launches, median of %d passes, single stream" % n_prof}
+
+    def measure_traffic(n_conv):
+        """HBM bytes per conv launch, measured NOW: two `rocprofv3 --pmc` child runs of this script (FETCH_SIZE and WRITE_SIZE need
+        separate passes: MI355X_MICROARCH.md, PMC slots), reduced like tools/pmc_traffic.py (FETCH_SIZE x2, the guide's gfx950 correction)."""
+        import shutil
+        import subprocess
+        import tempfile
+
+        exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+        if exe is None:
+            return None, "rocprofv3 not found"
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import pmc_traffic
+
+        tmp = tempfile.mkdtemp(prefix="hvn_pmc_", dir="/tmp")
+        dbs = {}
+        tile_file = os.path.join(tmp, "tiles.json")       # the children run THIS engine's measured column-tile choices (no autotune under the counters)
+        json.dump([int(o.tile_n) for o in net.engine(args.batch).ops], open(tile_file, "w"))
+        try:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(args.batch),
+                       "--mode", args.mode, "--nr-types", str(args.nr_types), "--dtype", args.dtype]
+                env = dict(os.environ, TMPDIR="/tmp", HVN_TILE_FILE=tile_file)
+                for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(k, None)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=args.traffic_timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                found = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+                if r.returncode != 0 or not found:
+                    return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-300:])
+                dbs[counter] = found[0]
+            red = pmc_traffic.reduce(dbs["FETCH_SIZE"], dbs["WRITE_SIZE"], n_conv)
+            if red["launches"] != n_conv:
+                return None, "expected %d conv dispatches under the counters, saw %d" % (n_conv, red["launches"])
+            return red, None
+        except subprocess.TimeoutExpired:
+            return None, "PMC child run exceeded %.0f s" % args.traffic_timeout
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    if rank == 0 and not args.no_roofline:
+        roof = roofline_of(net, tiles[0], args.batch, args.dtype)
+        n_conv = roof["conv_launches_per_step"]
+        red, why = (None, "--no-traffic") if (args.no_traffic or world > 1) else measure_traffic(n_conv)
+        if red is not None:
+            roof["traffic"] = red["hbm_bytes_per_step"] / max(1, n_conv)
+            roof["traffic_hbm_bytes_per_step"] = red["hbm_bytes_per_step"]
+            roof["traffic_unit"] = ("HBM bytes per conv launch, mean over the step's %d launches, MEASURED IN THIS RUN: two `rocprofv3 --pmc` child "
+                                    "passes of this script (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" % n_conv)
+        else:
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+                tpath = os.path.join(REPO, "profiles", name)
+                if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5 and args.dtype == "fp32":
+                    roof["traffic"] = json.load(open(tpath))["hbm_bytes_per_step"] / max(1, n_conv)
+                    roof["traffic_unit"] = "HBM bytes per conv launch QUOTED from profiles/%s (not measured in this run: %s)" % (name, why)
+                    break
+            else:
+                roof["traffic_unit"] = "not measured (%s)" % why
+        result["roofline"] = roof
         result["config"]["network_share_of_step"] = result["config"]["stage_ms"]["network"] / ms_per_step if sub == 1 else None
+
+    # ---- BASELINE cfg 3 as a driver-visible leg: fast mode, 6 types, batch 64, bf16 (rank 0, N = 1) --------------------
+    if rank == 0 and world == 1 and not args.no_variants and not args.no_cfg3 and not (args.mode == "fast" and args.dtype == "bf16"):
+        nt3, b3 = 6, 64
+        net3 = net_desc.create_model(mode="fast", nr_types=nt3, input_ch=3)
+        net3.load_state_dict(synth_state_dict("fast", nt3, seed=0), strict=True)
+        net3.max_batch, net3.compute_dtype = b3, "bf16"
+        net3 = net3.to(dev).eval()
+        tiles3 = torch.from_numpy(synth_tiles(b3, 256, seed=1)).to(dev)
+        out3 = net3.engine(b3).plan.geo["out"]
+        structured3 = torch.from_numpy(synth_pred_maps(b3, out3, out3, nt3, seed=100, k_lo=2, k_hi=8)[0]).to(dev)
+        pipe3 = TilePipeline(net3, nr_types=nt3, return_centroids=True)
+
+        def step3():
+            return pipe3.submit(tiles3, extra_maps=structured3, to_host=True)
+
+        for _ in range(2):
+            step3()
+        k3 = max(5, args.steps // 2)
+        dt3, out3_ = timed(step3, k3)
+        roof3 = roofline_of(net3, tiles3, b3, "bf16", n_prof=3)
+        result.setdefault("variants", {})["cfg3_fast_b64_bf16"] = {
+            "value": b3 * k3 / dt3, "unit": "tiles/s", "steps": k3, "ms_per_step": 1e3 * dt3 / k3, "dtype": "bf16",
+            "workload": "PanNuke 'fast' mode (256x256 -> 164x164, 6 types), batch 64 resident in HBM, bf16 activations / weights with fp32 "
+                        "accumulation and fp32 logits; same step as the headline (network + epilogue + instance separation + table of the network "
+                        "output and of a structured batch + D2H), random-init checkpoint, no output biasing",
+            "instances_last_step": int(out3_[2].sum().item()), "roofline": roof3}
+        del pipe3, net3
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same tiles ------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -359,17 +476,18 @@ def main():
         from oracle import postproc as O
 
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        # torch-CPU does not scale to every hardware thread of a big host: pick the thread count that
-        # runs one mid-size conv fastest, and report it as `cores`
-        import torch.nn.functional as F
-        xx, ww = torch.randn(2, 256, 66, 66), torch.randn(256, 256, 3, 3)
+        # torch-CPU does not scale to every hardware thread of a big host: the thread count is calibrated on the REAL work (the oracle
+        # network on one tile) and reported as `cores`
+        xcal = tiles_host[0][:1].permute(0, 3, 1, 2).float()
         best = (1e9, 1)
-        for th in sorted({t for t in (8, 16, 32, 64, 96, 128, cores) if t <= cores}):
+        for th in sorted({t for t in (8, 16, 24, 32, 48, 64, 96, cores) if t <= cores}):
             torch.set_num_threads(th)
-            F.conv2d(xx, ww, padding=1)
             t1 = time.perf_counter()
-            F.conv2d(xx, ww, padding=1)
-            best = min(best, (time.perf_counter() - t1, th))
+            net_torch.forward(sd, xcal, args.mode)
+            t_th = time.perf_counter() - t1
+            best = min(best, (t_th, th))
+            if t_th > 2.5 * best[0]:
+                break
         cores = best[1]
         torch.set_num_threads(cores)
         cpu_tiles = tiles_host[0]

@@ -106,7 +106,16 @@ class Engine:
         self._bind()
         self._sub_ops = {}
         self.tile_choice = {}
-        if dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
+        tile_file = os.environ.get("HVN_TILE_FILE")          # a list of per-op column tiles written by another engine of the same plan
+        if tile_file and dtype == "fp32":                   # (bench.py hands its measured choices to the PMC child runs)
+            import json
+            tiles = json.load(open(tile_file))
+            if len(tiles) != len(self.ops):
+                raise ValueError("HVN_TILE_FILE holds %d entries for a plan of %d ops" % (len(tiles), len(self.ops)))
+            for o, op, tn in zip(self.ops, plan.ops, tiles):
+                if op.kind == PL.OP_CONV and op.tile_n == 128 and tn in (64, 128):
+                    o.tile_n = tn
+        elif dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
             self.autotune_tiles()
 
     # ---------------------------------------------------------------------------------
