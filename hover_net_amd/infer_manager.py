@@ -173,6 +173,9 @@ class InferManager:
         self.rounds = []                                   # files per caching round (inspected by the tests)
         while pending:
             budget = int(psutil.virtual_memory().available * mem_usage) if "ram_budget_bytes" not in run_args else int(run_args["ram_budget_bytes"])
+            # every rank must cut the list into the SAME rounds (the collectives inside `process` are matched by round): the
+            # ranks sample their free RAM at different moments, so they agree on the smallest reading
+            budget = infer_tile.agree_min(budget, self._collective_device())
             paths, images = [], []
             while pending:
                 img = read_image(pending[0])
@@ -192,6 +195,13 @@ class InferManager:
                 self._write(output_dir, name, img, pred_inst, inst_info, raw_map, draw_dot, save_qupath)
                 done.append(name)
         return done
+
+    def _collective_device(self):
+        try:
+            net = self.model.module if hasattr(self.model, "module") and not hasattr(self.model, "engine") else self.model
+            return next(net.parameters()).device
+        except (AttributeError, StopIteration, TypeError):
+            return None
 
     def _write(self, output_dir, name, img, pred_inst, inst_info, raw_map, draw_dot, save_qupath):
         """proc_callback, infer/tile.py:169-208."""
@@ -292,4 +302,8 @@ class WsiManager(InferManager):
             except Exception:                                 # noqa: BLE001  (the reference logs and moves on to the next slide)
                 logging.exception("Crash")
                 status[name] = "crash"
+                if _world > 1:
+                    # swallow-and-continue is only safe in one process: a rank that moves on to the next slide while the others
+                    # wait in this slide's exchange / gather deadlocks the job -- fail the rank (and with it the launcher)
+                    raise
         return status

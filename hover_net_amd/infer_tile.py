@@ -123,6 +123,19 @@ def _dist():
     return None, 0, 1
 
 
+def agree_min(value, device=None):
+    """The minimum of an integer over the ranks (all_reduce MIN): every rank then takes the same decision from it, e.g. the RAM
+    budget that cuts a file list into caching rounds -- ranks that cut differently would run mismatched collectives."""
+    dist, _rank, world = _dist()
+    if world == 1:
+        return int(value)
+    dev = torch.device(device) if (device is not None and dist.get_backend() == "nccl") else (
+        torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def gather_shards(local, n_items):
     """local: this rank's [n_local, ...] slice (shard_range order) -> the full [n_items, ...] on
     EVERY rank with one all_gather (shards padded to equal length)."""
@@ -139,6 +152,31 @@ def gather_shards(local, n_items):
         lo, hi = shard_range(n_items, r, world)
         parts.append(out[r * per:r * per + (hi - lo)])
     return torch.cat(parts, 0)
+
+
+def route_to_owners(local, n_items, owner):
+    """local: this rank's [n_local, ...] rows for the items of `shard_range(n_items, rank, world)`; owner: int array [n_items],
+    the rank that consumes each item.  Returns (idx, rows): the global indices this rank owns, ascending, and their rows --
+    ONE `all_to_all_single` with uneven splits (every rank derives all split sizes from `owner`, nothing is negotiated).
+    Each row crosses the fabric at most once and lands only where it is used: 1 / world of what the all_gather of
+    `gather_shards` delivers to every rank."""
+    dist, rank, world = _dist()
+    owner = np.asarray(owner, np.int64)
+    assert owner.shape == (n_items,) and (n_items == 0 or (0 <= owner.min() and owner.max() < world))
+    mine_idx = np.flatnonzero(owner == rank)
+    if world == 1:
+        return mine_idx, local
+    lo, hi = shard_range(n_items, rank, world)
+    assert local.shape[0] == hi - lo, (local.shape, lo, hi)
+    dest = owner[lo:hi]
+    order = np.argsort(dest, kind="stable")                     # grouped by destination, index order kept inside a group
+    in_splits = np.bincount(dest, minlength=world).tolist()
+    out_splits = [int(np.count_nonzero(owner[slice(*shard_range(n_items, s, world))] == rank)) for s in range(world)]
+    send = local[torch.as_tensor(order, device=local.device)].contiguous() if len(order) else local[:0].contiguous()
+    recv = torch.empty((sum(out_splits),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    row = int(np.prod(local.shape[1:], dtype=np.int64))
+    dist.all_to_all_single(recv.view(-1), send.view(-1), [c * row for c in out_splits], [c * row for c in in_splits])
+    return mine_idx, recv
 
 
 def gather_to_rank0(tensors, dst=0):
@@ -200,17 +238,21 @@ def unpack_arrays(buf):
     return out
 
 
-def gather_items_to_rank0(mine, dst=0):
+def gather_items_to_rank0(mine, dst=0, device=None):
     """mine: {item index: [numpy arrays]} held by this rank (every index owned by exactly one rank).  Returns the union of all
     ranks' items on rank `dst`, None elsewhere.  Two collectives: an all_gather of the byte counts, then one `dist.gather` of
-    the packed uint8 buffers padded to the longest (RCCL over xGMI on the GPU box -- the buffers are staged through HBM --,
-    gloo in the CPU tests).  This replaces the pickling all_gather_object of round 1 (VERDICT r1 weak #7)."""
+    the packed uint8 buffers padded to the longest (RCCL over xGMI on the GPU box -- the buffers are staged through HBM on
+    `device`, the caller's model device --, gloo in the CPU tests).  Nothing is pickled."""
     dist, rank, world = _dist()
     if world == 1:
         return mine
     keys = sorted(mine)
     payload = pack_arrays([np.asarray(keys, np.int64)] + [np.asarray([len(mine[k]) for k in keys], np.int64)] + [a for k in keys for a in mine[k]])
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    # the staging device of the collective: the caller's model device (one process per GPU: never "whatever device is current")
+    if dist.get_backend() == "nccl":
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, torch.tensor([payload.size], dtype=torch.int64, device=dev))
     longest = int(sizes.max().item())
@@ -253,9 +295,10 @@ def arrays_to_result(arrs, nr_types, with_info=True, shift_xy=None):
     return np.array(inst_h), post_proc.records_to_dict(rec_h, nr_types, contours_flat=(np.array(pts), np.array(offs)), shift_xy=shift_xy)
 
 
-def run_sharded(items, step_fn, batch_size):
+def run_sharded(items, step_fn, batch_size, gather=True):
     """Apply `step_fn(batch) -> tensor [b, ...]` to this rank's contiguous share of `items`
-    ([P, ...] tensor) in batches and return the result for ALL items on every rank."""
+    ([P, ...] tensor) in batches.  gather=True: the result for ALL items on every rank (one all_gather);
+    gather=False: this rank's rows only (`route_to_owners` then sends each row to the one rank that needs it)."""
     _, rank, world = _dist()
     lo, hi = shard_range(items.shape[0], rank, world)
     outs = []
@@ -266,7 +309,7 @@ def run_sharded(items, step_fn, batch_size):
     else:  # more ranks than items: contribute an empty slice of the right trailing shape
         probe = step_fn(items[:1])
         local = probe[:0].clone()
-    return gather_shards(local, items.shape[0])
+    return gather_shards(local, items.shape[0]) if gather else local
 
 
 # --------------------------------------------------------------------------------------------
@@ -300,8 +343,8 @@ def process_images(images, model, nr_types=None, batch_size=32, return_centroids
 def _process_image_group(images, model, nr_types, batch_size, return_centroids, return_raw):
     """One group of `process_images`.
 
-    Pipeline per call: host patch extraction -> sharded HIP network (`run_desc.infer_step_device`)
-    -> one all_gather of the per-patch maps -> per-image stitch on the GPU -> on-GPU instance
+    Pipeline per call: patch extraction -> sharded HIP network (`run_desc.infer_step_device`)
+    -> one all_to_all of the per-patch maps to the images' owners (`route_to_owners`) -> per-image stitch on the GPU -> on-GPU instance
     separation + instance table (`post_proc.process_batch_device`) for the images this rank owns
     -> tensor gather of instance maps / record tables / contours to rank 0 (`gather_items_to_rank0`)."""
     from . import post_proc, run_desc
@@ -320,12 +363,17 @@ def _process_image_group(images, model, nr_types, batch_size, return_centroids, 
             patches.append(torch.from_numpy(extract_patches(padded, info, win)))
         infos.append(info)
     all_patches = torch.cat(patches, 0)
-    pred = run_sharded(all_patches, lambda b: run_desc.infer_step_device(b.to(dev), model), batch_size)
     _, rank, world = _dist()
+    # network: contiguous patch shards; then every per-patch map goes to the ONE rank that stitches its image (image i -> rank
+    # i % world) with a single all_to_all -- not to every rank
+    local = run_sharded(all_patches, lambda b: run_desc.infer_step_device(b.to(dev), model), batch_size, gather=False)
+    counts = [info.shape[0] for info in infos]
+    owner = np.repeat(np.arange(len(images)) % world, counts)
+    _idx, pred = route_to_owners(local, all_patches.shape[0], owner)
     mine = {}
     k = 0
     for i, img in enumerate(images):
-        n = infos[i].shape[0]
+        n = counts[i]
         if i % world == rank:
             full = stitch(pred[k:k + n], infos[i], img.shape).contiguous()
             inst, rec, _ = post_proc.process_batch_device(full.unsqueeze(0), nr_types, return_centroids)
@@ -334,8 +382,8 @@ def _process_image_group(images, model, nr_types, batch_size, return_centroids, 
             mine[i] = result_to_arrays(inst_h, rec_h, nr_types)
             if return_raw:
                 mine[i].append(full.cpu().numpy())
-        k += n
-    every = gather_items_to_rank0(mine)          # the instance maps + record tables + contours travel as tensors to rank 0
+            k += n
+    every = gather_items_to_rank0(mine, device=dev)          # the instance maps + record tables + contours travel as tensors to rank 0
     if every is None:                            # not rank 0: keeps only what it computed itself
         every = mine
     out = []

@@ -13,12 +13,15 @@ Different by design:
   * `pred_map` ([H,W,3|4] float32, 25.6 GB for a 40k x 40k slide) lives in HBM (288 GB per GPU)
     instead of a disk memmap written by a helper process (wsi.py:520-534, 235-258); patch outputs
     are scattered into it with one indexed write per chunk;
-  * chunks are sharded over the ranks (one process per GPU: a chunk is read, cut into patches and predicted by ONE rank;
-    one RCCL all-reduce of the HBM-resident map at the end of stage 1) instead of `nn.DataParallel`;
+  * several GPUs (one process each) OWN the map by rows: the slide's patch rows are dealt evenly into `world` contiguous
+    row slabs (`row_slabs`); a rank predicts exactly the patches of its slab (its share of every chunk: it reads only the
+    rows of the chunk it needs) into a local tensor of slab + halo rows -- 1 / world of the map, not a copy of it --, and
+    the only exchange of stage 1 is the halo: the rows a rank's stage-2 tiles reach into its neighbours' slabs, one
+    `all_to_all_single` of row blocks (`exchange_halo`), instead of an all-reduce of `world` full maps;
   * a tile (2048 x 2048 + margins) is post-processed on the GPU (`post_proc.process_batch_device`:
-    per-component parallel watershed) instead of a 16-process CPU pool; tiles are dealt round-robin
-    to the ranks, instance maps / record tables / contours travel to rank 0 as tensors, and rank 0 applies the merge
-    callbacks in tile order;
+    per-component parallel watershed) instead of a 16-process CPU pool, by the rank whose slab holds the tile's top row;
+    instance maps / record tables / contours travel to rank 0 as tensors, and rank 0 applies the merge callbacks in
+    tile order;
   * the slide backend is any object with `.shape` and `.read_region((x, y), (w, h))`
     (`ArraySlide` wraps a numpy array / memmap; OpenSlide is not required).
 """
@@ -138,6 +141,88 @@ class TiledSlide:
         return self.tile[(np.arange(0, self.shape[0], scale) % th)][:, (np.arange(0, self.shape[1], scale) % tw)]
 
 
+# --------------------------------------------------------------------------------------------
+# row ownership of the prediction map (multi-GPU)
+def row_slabs(n_rows, world, pin, pout):
+    """[world + 1] row boundaries: rank r owns map rows [b[r], b[r+1]).  The patch rows of the slide (output rows
+    o + j * pout, o = (pin - pout) // 2: `get_patch_top_left_info`) are dealt evenly and contiguously; interior boundaries
+    lie ON the patch-output grid, so no patch output straddles two owners."""
+    o = (int(pin) - int(pout)) // 2
+    n_prow = int(np.floor((n_rows - (int(pin) - int(pout))) / int(pout)) + 1)
+    cut = [(r * n_prow) // world for r in range(world + 1)]
+    b = [0] + [min(n_rows, o + c * int(pout)) for c in cut[1:-1]] + [int(n_rows)]
+    return np.asarray(b, np.int64)
+
+
+class SlabMap:
+    """The rows [row0, row0 + t.shape[0]) of the [H, W, C] prediction map, resident on this rank."""
+
+    def __init__(self, t, row0=0):
+        self.t, self.row0 = t, int(row0)
+
+    @property
+    def rows(self):
+        return self.row0, self.row0 + int(self.t.shape[0])
+
+    def window(self, tl, br):
+        lo, hi = self.rows
+        y0, y1 = int(tl[0]), min(int(br[0]), hi)
+        if y0 < lo:
+            raise IndexError("rows [%d, %d) asked of a slab holding [%d, %d)" % (y0, y1, lo, hi))
+        return self.t[y0 - lo:y1 - lo, int(tl[1]):int(br[1])]
+
+
+def tile_owner(tiles, bounds):
+    """Rank that post-processes each tile: the owner of its top row."""
+    if tiles.shape[0] == 0:
+        return np.zeros(0, np.int64)
+    return np.clip(np.searchsorted(bounds, tiles[:, 0, 0], side="right") - 1, 0, len(bounds) - 2)
+
+
+def needed_rows(tile_lists, bounds, n_rows):
+    """[world, 2]: the row range each rank must hold = its slab + what its tiles (all three phases) reach beyond it."""
+    world = len(bounds) - 1
+    need = np.stack([bounds[:-1], bounds[1:]], 1).astype(np.int64)
+    for tiles in tile_lists:
+        own = tile_owner(tiles, bounds)
+        for r in range(world):
+            t = tiles[own == r]
+            if t.shape[0]:
+                need[r, 0] = min(need[r, 0], int(t[:, 0, 0].min()))
+                need[r, 1] = max(need[r, 1], min(int(n_rows), int(t[:, 1, 0].max())))
+    return need
+
+
+def exchange_halo(local, need, bounds):
+    """local: SlabMap over rows need[rank] whose own slab rows are final.  Fills the rest from the owners: rank s sends rank t
+    the rows of need[t] that lie in slab[s] -- every rank derives every block size from (need, bounds), so ONE all_to_all_single of
+    contiguous row blocks does it (xGMI is point to point: each block crosses one link once)."""
+    dist, rank, world = infer_tile._dist()
+    if world == 1:
+        return local
+    row = int(np.prod(local.t.shape[1:], dtype=np.int64))
+
+    def block(holder, asker):      # rows of `holder`'s slab that `asker` needs
+        if holder == asker:
+            return 0, 0
+        lo, hi = max(int(need[asker, 0]), int(bounds[holder])), min(int(need[asker, 1]), int(bounds[holder + 1]))
+        return (lo, hi) if hi > lo else (0, 0)
+
+    send_blocks = [block(rank, t) for t in range(world)]
+    recv_blocks = [block(s, rank) for s in range(world)]
+    parts = [local.t[lo - local.row0:hi - local.row0].reshape(-1) for lo, hi in send_blocks if hi > lo]
+    send = torch.cat(parts) if parts else local.t.new_zeros(0)
+    recv = local.t.new_empty(sum(hi - lo for lo, hi in recv_blocks) * row)
+    dist.all_to_all_single(recv, send, [(hi - lo) * row for lo, hi in recv_blocks], [(hi - lo) * row for lo, hi in send_blocks])
+    off = 0
+    for lo, hi in recv_blocks:
+        if hi > lo:
+            n = (hi - lo) * row
+            local.t[lo - local.row0:hi - local.row0] = recv[off:off + n].view((hi - lo,) + tuple(local.t.shape[1:]))
+            off += n
+    return local
+
+
 def remove_inst(inst_map, ids):
     if len(ids):
         inst_map[np.isin(inst_map, np.asarray(list(ids)))] = 0
@@ -152,12 +237,23 @@ class WsiMerger:
         self.inst_map = np.zeros(tuple(proc_shape), np.int32)
         self.inst_info = {}
         self._flag = np.zeros(1 << 16, np.uint8)       # scratch lookup table over instance ids, all zero between calls
+        self._ids = []                                 # max-heap (negated) of the ids inserted so far, lazily pruned
 
     def _max_id(self):
-        # every new key is `local id + current maximum`, i.e. larger than all keys before it: the dict's insertion order is
-        # ascending, so after any removals its LAST key is still the maximum (the reference takes max() over a million keys
-        # per tile, wsi.py:574/621)
-        return next(reversed(self.inst_info)) if self.inst_info else 0
+        """max(self.inst_info), the reference's id offset (wsi.py:574/621: `max(wsi_inst_info.keys())` over up to a million
+        keys per tile).  Kept exact without assuming anything about the order in which ids arrive: a heap of all inserted ids,
+        popped while its top has been removed from the dict -- amortised O(log n) per inserted id."""
+        import heapq
+
+        while self._ids and -self._ids[0] not in self.inst_info:
+            heapq.heappop(self._ids)
+        return -self._ids[0] if self._ids else 0
+
+    def _insert(self, key, entry):
+        import heapq
+
+        self.inst_info[key] = entry
+        heapq.heappush(self._ids, -key)
 
     def _table(self, size):
         if self._flag.shape[0] < size:
@@ -195,7 +291,7 @@ class WsiMerger:
                 e["bbox"] = e["bbox"] + top_left        # (sic) the reference adds (x, y) to the (row, col) box
                 e["contour"] = e["contour"] + top_left
                 e["centroid"] = e["centroid"] + top_left
-            self.inst_info[i + off] = e
+            self._insert(i + off, e)
         pred_inst = pred_inst.copy()
         pred_inst[pred_inst > 0] += off
         self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = pred_inst
@@ -226,7 +322,7 @@ class WsiMerger:
                 e["bbox"] = e["bbox"] + top_left
                 e["contour"] = e["contour"] + top_left
                 e["centroid"] = e["centroid"] + top_left
-            self.inst_info[i + off] = e
+            self._insert(i + off, e)
         pred_inst[pred_inst > 0] += off
         self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = roi + pred_inst
 
@@ -244,21 +340,37 @@ class WsiInference:
         self.tile_shape = np.array([tile_shape, tile_shape], np.int64)
         self.ambiguous_size = ambiguous_size
         self.device = next(net.parameters()).device
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)      # one process per GPU: ctypes HIP launches and collectives use the current device
         self.out_ch = 3 if nr_types is None else 4
 
     # -- stage 1: raw prediction into the HBM-resident map ----------------------------------------
-    def raw_prediction(self, slide, mask):
-        """Chunks are the unit of rank sharding: rank r reads and predicts chunks r, r + world, ... (every patch belongs to the
-        FIRST chunk that selects it, so no patch is computed twice and no chunk is read by two ranks); each rank scatters
-        its patch outputs into its own HBM-resident map and ONE all-reduce (SUM; every pixel is written by exactly one rank,
-        the others contribute 0.0) over RCCL makes the map complete on every rank for stage 2."""
+    def tile_lists(self, shape, mask):
+        """The three phases' tile boxes after the mask test -- the same on every rank (pure geometry + mask)."""
+        grid, boundary, cross = get_tile_info(shape, self.tile_shape, self.ambiguous_size)
+        return [select_valid(t, mask, shape, has_output_info=False) for t in (grid, boundary, cross)]
+
+    def raw_prediction(self, slide, mask, as_slab=False):
+        """The reference's chunk loop (wsi.py:329-383; every patch belongs to the FIRST chunk that selects it), restricted on each
+        rank to the patch rows of its row slab (`row_slabs`): a rank reads, of every chunk that crosses its slab, only the rows
+        it needs, predicts those patches and scatters them into its LOCAL tensor (slab + halo rows, 1 / world of the map).  The
+        halo rows -- what its stage-2 tiles reach into the neighbours' slabs -- then arrive in one `all_to_all_single`.
+        Returns the whole map as a tensor (one rank), or a `SlabMap` (as_slab=True; always on several ranks)."""
         shape = np.array(slide.shape[:2])
-        pred_map = torch.zeros((int(shape[0]), int(shape[1]), self.out_ch), dtype=torch.float32, device=self.device)
+        H, W = int(shape[0]), int(shape[1])
+        dist, rank, world = infer_tile._dist()
+        bounds = row_slabs(H, world, self.pin[0], self.pout[0])
+        need = needed_rows(self.tile_lists(shape, mask), bounds, H) if world > 1 else np.array([[0, H]])
+        lo, hi = int(need[rank, 0]), int(need[rank, 1])
+        local = SlabMap(torch.zeros((hi - lo, W, self.out_ch), dtype=torch.float32, device=self.device), lo)
+        self.map_rows_resident = hi - lo                       # inspected by the tests / tools: per-rank share of the map
         chunk_info, patch_info = get_chunk_patch_info(shape, self.chunk_shape, self.pin, self.pout)
         between = lambda x, a, b: (a <= x) & (x <= b)  # noqa: E731
         h = int(self.pout[0])
+        off = (self.pin - self.pout) // 2
         ar = torch.arange(h, device=self.device)
-        dist, rank, world = infer_tile._dist()
+        out_top = patch_info[:, 0, 0, 0] + off[0]               # output top row of every patch in the slide
+        in_slab = (out_top >= bounds[rank]) & (out_top < bounds[rank + 1])
         taken = np.zeros(patch_info.shape[0], bool)
         self.stage1_patches = 0
         for ci in range(chunk_info.shape[0]):
@@ -266,17 +378,22 @@ class WsiInference:
             start, end = chunk[0, 0], chunk[0, 1] - self.pin
             sel = between(patch_info[:, 0, 0, 0], start[0], end[0]) & between(patch_info[:, 0, 0, 1], start[1], end[1]) & ~taken
             taken |= sel
-            if ci % world != rank:
+            sel &= in_slab
+            if not sel.any():
                 continue
             plist = select_valid(np.array(patch_info[sel]), mask, shape)
             if plist.shape[0] == 0:
                 continue
             self.stage1_patches += int(plist.shape[0])
-            region = slide.read_region(chunk[0][0][::-1], (chunk[0][1] - chunk[0][0])[::-1])
-            rel = plist[:, 0, 0] - chunk[0, 0]                    # patch input top-left inside the chunk
+            # this rank's rows of the chunk: from its first patch's input top to its last patch's input bottom, full chunk width
+            y0 = int(plist[:, 0, 0, 0].min())
+            y1 = int(plist[:, 0, 1, 0].max())
+            x0, x1 = int(chunk[0][0][1]), int(chunk[0][1][1])
+            region = slide.read_region((x0, y0), (x1 - x0, y1 - y0))
+            rel = plist[:, 0, 0] - np.array([y0, x0])           # patch input top-left inside the region
             win = int(self.pin[0])
             if self.device.type == "cuda":
-                # the chunk goes up once (300 MB for 10000^2); the overlapping 270^2 crops (11x the bytes) are gathered on
+                # the region goes up once (300 MB for 10000^2); the overlapping 270^2 crops (11x the bytes) are gathered on
                 # the GPU (hvn_extract_patches; every crop is in bounds, so its reflect rule never fires)
                 region_dev = torch.from_numpy(np.ascontiguousarray(region[..., :3])).to(self.device)
                 patches = infer_tile.extract_patches_device(region_dev, rel.astype(np.int32), win, 0)
@@ -287,13 +404,13 @@ class WsiInference:
             out = torch.cat(outs, 0)
             # output top-left in the slide = input top-left + diff // 2 (the placement rule of _assemble_and_flush,
             # wsi.py:235-258; patch_info[:, 1] is offset by the FULL diff in the reference and only feeds the mask test)
-            otl = torch.from_numpy((plist[:, 0, 0] + (self.pin - self.pout) // 2).astype(np.int64)).to(self.device)
-            rows = (otl[:, 0, None] + ar)[:, :, None].expand(-1, h, h)
+            otl = torch.from_numpy((plist[:, 0, 0] + off).astype(np.int64)).to(self.device)
+            rows = (otl[:, 0, None] + ar - lo)[:, :, None].expand(-1, h, h)
             cols = (otl[:, 1, None] + ar)[:, None, :].expand(-1, h, h)
-            pred_map[rows, cols] = out.to(pred_map.device)        # one scatter per chunk
+            local.t[rows, cols] = out.to(local.t.device)          # one scatter per chunk
         if world > 1:
-            dist.all_reduce(pred_map, op=dist.ReduceOp.SUM)
-        return pred_map
+            exchange_halo(local, need, bounds)
+        return local if (as_slab or world > 1) else local.t
 
     def _step(self, batch):
         return run_desc.infer_step_device(batch.to(self.device), self.model)
@@ -303,17 +420,22 @@ class WsiInference:
         """Yields (tile index, pred_inst numpy, inst_info dict with the tile origin already added) in tile order on rank 0
         (nothing on the other ranks).
 
+        `pred_map`: the whole map (tensor) or this rank's `SlabMap`; a tile is worked by the rank owning its top row.
         Three overlapped stages per rank: (a) the GPU instance separation + instance table of tile i+1 and its D2H into pinned
         memory are in flight (`_launch_tile`) while (b) a worker thread traces the contours of tile i on the host cores
         (C++, multi-threaded, no GIL) and (c) the caller merges tile i-1.  One rank: results are yielded as they complete, so
-        the sequential merge runs under the GPU work of later tiles.  Several ranks: tiles are dealt round-robin, every rank
-        runs the same pipeline over its share, then instance maps / record tables / contour arrays travel to rank 0 as
+        the sequential merge runs under the GPU work of later tiles.  Several ranks: every rank
+        runs the same pipeline over the tiles whose rows it holds, then instance maps / record tables / contour arrays travel to rank 0 as
         tensors (`infer_tile.gather_items_to_rank0`) and rank 0 assembles the dicts."""
         import collections
         from concurrent.futures import ThreadPoolExecutor
 
         _, rank, world = infer_tile._dist()
-        idxs = [i for i in range(tiles.shape[0]) if i % world == rank]
+        if not isinstance(pred_map, SlabMap):
+            pred_map = SlabMap(pred_map, 0)
+        bounds = row_slabs(int(self._shape[0]), world, self.pin[0], self.pout[0])
+        own = tile_owner(tiles, bounds)
+        idxs = [i for i in range(tiles.shape[0]) if own[i] == rank]    # the rank that holds the tile's rows (slab + halo)
         tm = getattr(self, "timing", None)
 
         def shift_of(i):
@@ -347,7 +469,7 @@ class WsiInference:
 
             for i in idxs:
                 tl, br = tiles[i][0], tiles[i][1]
-                inflight.append((i, self._launch_tile(pred_map[tl[0]:br[0], tl[1]:br[1]])))
+                inflight.append((i, self._launch_tile(pred_map.window(tl, br))))
                 if len(inflight) >= 2:
                     finish()
                 yield from drain(False)
@@ -355,7 +477,7 @@ class WsiInference:
                 finish()
             yield from drain(True)
         if world > 1:
-            every = infer_tile.gather_items_to_rank0(mine)
+            every = infer_tile.gather_items_to_rank0(mine, device=self.device)
             if every is not None:
                 for i in range(tiles.shape[0]):
                     yield (i,) + infer_tile.arrays_to_result(every[i], self.nr_types, shift_xy=shift_of(i))
@@ -420,25 +542,28 @@ class WsiInference:
             mask = tissue_mask.simple_get_mask(slide.thumbnail(32))
         if mask is None:
             mask = np.ones((max(1, int(shape[0]) // 32), max(1, int(shape[1]) // 32)), np.uint8)
-        pred_map = self.raw_prediction(slide, mask)
-        return self.stitch_instances(pred_map, mask)
+        pred_map = self.raw_prediction(slide, mask, as_slab=True)
+        return self.stitch_instances(pred_map, mask, shape=shape)
 
-    def stitch_instances(self, pred_map, mask=None):
-        """Stage 2 alone: three-phase tile post-processing + merge of an HBM-resident prediction map."""
-        shape = np.array(pred_map.shape[:2])
+    def stitch_instances(self, pred_map, mask=None, shape=None):
+        """Stage 2 alone: three-phase tile post-processing + merge of an HBM-resident prediction map (a tensor holding the whole
+        map, or this rank's `SlabMap` + the slide `shape`)."""
+        if shape is None:
+            assert not isinstance(pred_map, SlabMap), "a SlabMap does not know the slide's height: pass shape"
+            shape = pred_map.shape[:2]
+        shape = np.array([int(shape[0]), int(shape[1])])
+        self._shape = shape
         if mask is None:
             mask = np.ones((max(1, int(shape[0]) // 32), max(1, int(shape[1]) // 32)), np.uint8)
-        grid, boundary, cross = get_tile_info(shape, self.tile_shape, self.ambiguous_size)
-        merger = WsiMerger(shape)
-        for phase, tiles in enumerate((grid, boundary, cross)):
-            tiles = select_valid(tiles, mask, shape, has_output_info=False)
-            cb = merger.normal if phase == 0 else merger.fixing
+        rank = infer_tile._dist()[1]
+        merger = WsiMerger(shape) if rank == 0 else None
+        for phase, tiles in enumerate(self.tile_lists(shape, mask)):
             # the merge is sequential by definition (wsi.py:569-677) and runs on rank 0, under the GPU work of later tiles
             for i, inst_h, info in self._results_in_order(pred_map, tiles):
                 t0 = time.perf_counter()
-                cb(inst_h, info, tiles[i][0], tiles[i][1], shifted=True)
+                (merger.normal if phase == 0 else merger.fixing)(inst_h, info, tiles[i][0], tiles[i][1], shifted=True)
                 if getattr(self, "timing", None) is not None:
                     self.timing["merge_s"] = self.timing.get("merge_s", 0.0) + (time.perf_counter() - t0)
-        if infer_tile._dist()[1] != 0:
+        if rank != 0:
             return None, None
         return merger.inst_map, merger.inst_info

@@ -145,12 +145,12 @@ def broadcast_module_state(net, src=0):
             off += t.numel()
 
 
-def _same_on_all_ranks(value, what):
+def _same_on_all_ranks(value, what, device=None):
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = (device if device is not None else "cuda") if dist.get_backend() == "nccl" else "cpu"      # THIS rank's GPU, never "whatever is current"
     t = torch.tensor([float(value), -float(value)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if t[0].item() != -t[1].item():
@@ -167,6 +167,10 @@ def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device=None, 
     rank, world = _dist_info()
     if device is None:                      # one process per GPU: the launcher's LOCAL_RANK names it
         device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cuda"
+    if torch.cuda.is_available() and torch.device(device).type == "cuda":
+        # one process per GPU: collectives that allocate on "the current device" and the ctypes HIP launches (issued on the current
+        # device's streams) must all see THIS rank's GPU
+        torch.cuda.set_device(torch.device(device))
     history, prev_state, net = [], None, None
     for pi, phase in enumerate(config["phase_list"]):
         info = phase["run_info"]["net"]
@@ -194,7 +198,7 @@ def run_phases(config, make_loaders, log_dir=None, nr_epochs=None, device=None, 
         run_info = {"net": {"desc": net, "optimizer": optimizer, "lr_scheduler": scheduler, "extra_info": info["extra_info"]}}
         loaders = make_loaders(pi, phase["batch_size"])
         if hasattr(loaders["train"], "__len__"):
-            _same_on_all_ranks(len(loaders["train"]), "phase %d: number of training batches per epoch" % pi)
+            _same_on_all_ranks(len(loaders["train"]), "phase %d: number of training batches per epoch" % pi, device)
         train_bs = int(phase["batch_size"]["train"])
         train_loader = _DropRagged(loaders["train"], train_bs) if world > 1 else loaders["train"]
         # ---- the wiring of opt.py:96-140 on run_engine.RunEngine --------------------------------------------------------------
