@@ -16,6 +16,7 @@
 // heap (in LDS when the tile's heap fits, else in HBM scratch); parallelism comes from the
 // tiles of the batch.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <float.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -74,6 +75,8 @@ struct TileStat {
     int heap_top;    // bump pointer into the HBM heap plane (oversized components)
     int tie;         // a component saw two equal-valued age-0 heap items: replay the tile globally
     int max_area;    // largest component bounding box of the tile
+    int dbg[8];      // HVN_WS_STATS: components replayed by 0 small LDS window, 1 bitmap window, 2 HBM window; 3 handed to the one-lane
+                     // heap by a mixed-label marker tie, 4 by a full frontier; 5 component heap replays, 6 whole-tile replays
 };
 
 struct PPBuf {
@@ -90,6 +93,7 @@ struct PPBuf {
     // watershed scratch
     unsigned long long *heap;  // 2 x u64 per item, n*P items
     int no_wave;               // HVN_WS_WAVE=0: every component on the one-lane binary heap (A/B and tests)
+    int no_bitmap;             // HVN_WS_BITMAP=0: windows beyond the LDS keep keys + labels in HBM scratch (the round-2 form, A/B)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -692,7 +696,11 @@ __device__ __forceinline__ bool ws_window_wave(PPBuf &b, int n, int root, int y0
     int nf = 0;
     for (int base = 0; base < A2; base += 64) {   // the markers, in any order: their keys decide
         const int i = base + lane;
-        const bool m = i < A2 && out[i] > 0;
+        // only marker pixels with an unlabelled 4-neighbour enter the frontier: popping an interior marker pixel labels nothing,
+        // pushes nothing and advances no age, so leaving it out is exact -- and keeps the frontier to the marker BORDERS
+        // (a marker pixel is never on the window's border row / column, so i +- 1 and i +- bw2 stay inside the window)
+        bool m = i < A2 && out[i] > 0;
+        if (m) m = out[i - bw2] == 0 || out[i - 1] == 0 || out[i + 1] == 0 || out[i + bw2] == 0;
         const u64 mask = __ballot(m);
         if (nf + __popcll(mask) > cap) return true;   // (uniform) no room for the markers: binary-heap path
         if (m) {
@@ -730,8 +738,24 @@ __device__ __forceinline__ bool ws_window_wave(PPBuf &b, int n, int root, int y0
         const bool mine = bk == gk && ba == ga && cnt > 0;
         const u64 win = __ballot(mine);
         if (ga == 0u && (__popcll(win) > 1 || __any(mine && cnt > 1))) {
-            tie = true;
-            break;
+            // Marker tie: several age-0 items share the minimal value.  Their order in the reference is an artefact of its
+            // binary heap's layout -- but if they all carry the SAME label the order cannot change any label: until the next
+            // foreign item pops, only items of that label pop and push (a contiguous block of ages), the set of pixels they
+            // label is a reachability closure that does not depend on the order, and against every foreign item the block's
+            // ages compare the same way whichever order was taken (checked on ~1900 tie-heavy random cases against the exact
+            // heap model, tests/test_oracle_postproc.py).  Only a tie between DIFFERENT labels is ambiguous.
+            unsigned lmin = 0xffffffffu, lmax = 0u;
+            for (int s = lane; s < nf; s += 64)
+                if (fk[s] == gk && fa[s] == 0u) {
+                    const unsigned l = (unsigned)out[fi[s]];
+                    lmin = l < lmin ? l : lmin;
+                    lmax = l > lmax ? l : lmax;
+                }
+            if (wave_min_u32(lmin) != ~wave_min_u32(~lmax)) {
+                if (lane == 0) atomicAdd(&b.stat[n].dbg[3], 1);
+                tie = true;
+                break;
+            }
         }
         const int wl = __ffsll((long long)win) - 1;
         const int gs = __builtin_amdgcn_readlane(bs, wl);
@@ -772,6 +796,259 @@ __device__ __forceinline__ bool ws_window_wave(PPBuf &b, int n, int root, int y0
                 b.inst[g0 + (long)(y0 + ry - 1) * b.W + (x0 + t - ry * bw2 - 1)] = v;
             }
         }
+    __syncthreads();
+    return tie;
+}
+
+// Windows beyond the LDS (a clump of many nuclei, a blob that fills the tile): the same wave-cooperative replay on a COMPACT
+// state.  Per pixel the flood only ever asks "in the component and still unlabelled?" -- one bit -- so the window lives in LDS as
+// a bitmap (a 164 x 164 tile: 3.4 KB; up to ~0.5 Mpixel windows fit), every frontier item carries its label (no label read per
+// pop), labels are written straight to the instance map when a pixel is pushed (fire-and-forget stores), and the only HBM
+// (L2-resident scratch) access a pop waits for is the value key of the up to four pixels it pushes.  Was: keys AND labels of the
+// window in HBM scratch, three dependent L2 round trips per pop.
+// Such windows have frontiers of thousands of items (every border pixel of hundreds of noise markers), too many to scan per pop:
+// the frontier is a 64-ary TOURNAMENT -- slots in blocks of 64, each block's minimum (key, age, slot) cached; a pop reads the
+// cached minima (one or two per lane), takes the wave minimum, re-derives the one block it emptied a slot of (64 lanes, one slot
+// each), and a push compares its item with one cached minimum.  Freed slots are recycled through a stack, so nothing moves.
+// Exactness is that of any exact-minimum queue (see ws_window_wave); for marker ties every block also caches how many of its
+// items equal its minimum and their label range, so "one label or several?" never needs a scan either.
+struct WsBlk {
+    unsigned long long k;   // minimum value key of the block's live items (~0: block empty)
+    unsigned a, s;          // its age, its slot
+    unsigned c, l0, l1;     // items equal to the minimum (meaningful at age 0: marker ties), their smallest / largest label
+    unsigned pad;
+};
+
+__device__ __forceinline__ bool ws_window_wave_bitmap(PPBuf &b, int n, int root, int y0, int x0, int bh, int bw, unsigned long long *kv, int lds_bytes)
+{
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds_w[];
+    const int lane = threadIdx.x;
+    const long g0 = (long)n * b.P;
+    const int bw2 = bw + 2, A2 = bw2 * (bh + 2);
+    const int nw = (A2 + 63) >> 6;
+    u64 *um = (u64 *)ws_lds_w;            // bit t: window pixel t belongs to the component and has no label yet
+    u64 *mm = um + nw;                    // bit t: marker pixel (used while the frontier is seeded)
+    constexpr int NPEND = 256;            // labels waiting to be written to the instance map (see flush below)
+    const int cap = ((lds_bytes - 16 * nw - 8 * NPEND) / (24 * 64 + (int)sizeof(WsBlk))) * 64;     // slots, whole blocks
+    unsigned *pend_i = (unsigned *)(mm + nw), *pend_l = pend_i + NPEND;
+    WsBlk *blk = (WsBlk *)(pend_l + NPEND);
+    u64 *fk = (u64 *)(blk + cap / 64);
+    unsigned *fa = (unsigned *)(fk + cap), *fi = fa + cap, *fl = fi + cap, *fs = fl + cap;
+    for (int base = 0; base < A2; base += 64) {
+        const int t = base + lane;
+        bool unl = false, mrk = false;
+        if (t < A2) {
+            const int ry = t / bw2;
+            const int yy = ry - 1, xx = t - ry * bw2 - 1;
+            if ((unsigned)yy < (unsigned)bh && (unsigned)xx < (unsigned)bw) {
+                const long gi = g0 + (long)(y0 + yy) * b.W + (x0 + xx);
+                u64 k = 0;
+                if (b.broot[gi] == root) {
+                    const int o = b.mk[gi];
+                    k = ws_key(b.blur[gi]);
+                    b.inst[gi] = o;       // marker label, or 0 until the flood reaches the pixel
+                    unl = o == 0;
+                    mrk = o > 0;
+                }
+                kv[yy * bw + xx] = k;     // keys of the bh x bw interior only: a window that IS the tile still fits the tile's scratch plane
+            }
+        }
+        const u64 bu = __ballot(unl), bm = __ballot(mrk);
+        if (lane == 0) {
+            um[base >> 6] = bu;
+            mm[base >> 6] = bm;
+        }
+    }
+    for (int s = lane; s < cap; s += 64) {   // every slot starts dead
+        fk[s] = ~0ull;
+        fa[s] = ~0u;
+    }
+    __threadfence_block();
+    __syncthreads();
+    auto bit = [](const u64 *w, int t) { return (w[t >> 6] >> (t & 63)) & 1ull; };
+    int top = 0;                          // slots ever used
+    for (int base = 0; base < A2; base += 64) {   // marker pixels with an unlabelled neighbour (see ws_window_wave)
+        const int t = base + lane;
+        bool m = t < A2 && bit(mm, t);
+        if (m) m = bit(um, t - bw2) || bit(um, t - 1) || bit(um, t + 1) || bit(um, t + bw2);
+        const u64 mask = __ballot(m);
+        if (top + __popcll(mask) + 4 > cap) {           // (uniform) no room: binary-heap path
+            if (lane == 0) atomicAdd(&b.stat[n].dbg[4], 1);
+            return true;
+        }
+        if (m) {
+            const int s = top + __popcll(mask & ((1ull << lane) - 1ull));
+            const int ry = t / bw2;
+            fk[s] = kv[(ry - 1) * bw + (t - ry * bw2 - 1)];
+            fa[s] = 0u;
+            fi[s] = (unsigned)t;
+            fl[s] = (unsigned)b.mk[g0 + (long)(y0 + ry - 1) * b.W + (x0 + t - ry * bw2 - 1)];
+        }
+        top += __popcll(mask);
+    }
+    __syncthreads();
+    // the cached minimum of block j from its 64 slots, one per lane
+    auto rebuild = [&](int j) {
+        const int s = 64 * j + lane;
+        const u64 k = fk[s];
+        const unsigned a = fa[s];
+        const u64 gk = wave_min_u64(k);
+        const unsigned am = wave_min_u32(k == gk ? a : 0xffffffffu);
+        const bool hit = k == gk && a == am && gk != ~0ull;
+        const u64 hm = __ballot(hit);
+        unsigned l0 = 0, l1 = 0;
+        if (hm && am == 0u) {
+            const unsigned l = hit ? fl[s] : 0u;
+            l0 = wave_min_u32(hit ? l : 0xffffffffu);
+            l1 = ~wave_min_u32(hit ? ~l : 0xffffffffu);
+        }
+        if (lane == 0) {
+            WsBlk w;
+            w.k = gk;
+            w.a = am;
+            w.s = hm ? (unsigned)(64 * j + __ffsll((long long)hm) - 1) : 0u;
+            w.c = (unsigned)__popcll(hm);
+            w.l0 = l0;
+            w.l1 = l1;
+            w.pad = 0;
+            blk[j] = w;
+        }
+    };
+    for (int j = 0; j < cap / 64; ++j) {
+        if (64 * j < top) rebuild(j);
+        else if (lane == 0) {
+            WsBlk w = {~0ull, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+            blk[j] = w;
+        }
+    }
+    __syncthreads();
+    // Labels reach the instance map through a small LDS queue, flushed by all lanes every ~60 pops: gfx9 counts loads and stores in
+    // ONE vmcnt, so a store per pop would make the next pop's key load wait for the store's round trip as well.
+    int npend = 0;
+    auto flush = [&]() {
+        for (int e = lane; e < npend; e += 64) {
+            const int q = (int)pend_i[e];
+            const int ry = q / bw2;
+            b.inst[g0 + (long)(y0 + ry - 1) * b.W + (x0 + q - ry * bw2 - 1)] = (int)pend_l[e];
+        }
+        npend = 0;
+    };
+    int live = top, nfree = 0;
+    unsigned age = 0;
+    bool tie = false;
+    while (live > 0) {
+        if (npend + 4 > NPEND) {
+            flush();
+            __syncthreads();
+        }
+        if (top + 4 > cap && nfree < 4) {
+            if (lane == 0) atomicAdd(&b.stat[n].dbg[4], 1);
+            tie = true;
+            break;
+        }
+        const int nb = (top + 63) >> 6;
+        u64 bk = ~0ull;
+        unsigned ba = 0xffffffffu;
+        int bj = 0;
+        for (int j = lane; j < nb; j += 64) {
+            const u64 k = blk[j].k;
+            const unsigned a = blk[j].a;
+            if (k < bk || (k == bk && a < ba)) {
+                bk = k;
+                ba = a;
+                bj = j;
+            }
+        }
+        const u64 gk = wave_min_u64(bk);
+        const unsigned ga = wave_min_u32(bk == gk ? ba : 0xffffffffu);
+        const u64 win = __ballot(bk == gk && ba == ga);
+        if (ga == 0u) {                  // markers at the top: one of them alone, several of ONE label (harmless: ws_window_wave), or a real tie?
+            unsigned cs = 0, l0 = 0xffffffffu, l1 = 0u;
+            for (int j = lane; j < nb; j += 64)
+                if (blk[j].k == gk && blk[j].a == 0u) {
+                    cs += blk[j].c;
+                    l0 = blk[j].l0 < l0 ? blk[j].l0 : l0;
+                    l1 = blk[j].l1 > l1 ? blk[j].l1 : l1;
+                }
+            const u64 has = __ballot(cs > 0);
+            if ((__popcll(has) > 1 || __any(cs > 1)) && wave_min_u32(l0) != ~wave_min_u32(~l1)) {
+                if (lane == 0) atomicAdd(&b.stat[n].dbg[3], 1);
+                tie = true;
+                break;
+            }
+        }
+        const int jb = __builtin_amdgcn_readlane(bj, __ffsll((long long)win) - 1);
+        const int gs = (int)blk[jb].s;
+        const int idx = (int)fi[gs];
+        const unsigned lab = fl[gs];
+        if (lane == 0) {                 // the slot dies and goes on the free stack
+            fk[gs] = ~0ull;
+            fa[gs] = 0xffffffffu;
+            fs[nfree] = (unsigned)gs;
+        }
+        ++nfree;
+        --live;
+        __syncthreads();
+        rebuild(jb);
+        bool unl = false;
+        int q = 0;
+        if (lane < 4) {                  // skimage's neighbour order: up, left, right, down
+            q = idx + (lane == 0 ? -bw2 : lane == 1 ? -1 : lane == 2 ? 1 : bw2);
+            unl = bit(um, q) != 0;
+        }
+        const u64 umk = __ballot(unl);
+        const int np = __popcll(umk);
+        int slot = 0;
+        u64 key = 0;
+        unsigned pa = 0;
+        if (unl) {
+            const int r = __popcll(umk & ((1ull << lane) - 1ull));
+            atomicAnd(&um[q >> 6], ~(1ull << (q & 63)));
+            const int ry = q / bw2;
+            pend_i[npend + r] = (unsigned)q;                                                  // labelled at push time
+            pend_l[npend + r] = lab;
+            slot = r < nfree ? (int)fs[nfree - 1 - r] : top + (r - nfree);
+            key = kv[(ry - 1) * bw + (q - ry * bw2 - 1)];
+            pa = age + 1u + (unsigned)r;
+            fk[slot] = key;
+            fa[slot] = pa;
+            fi[slot] = (unsigned)q;
+            fl[slot] = lab;
+        }
+        const int reuse = np < nfree ? np : nfree;
+        nfree -= reuse;
+        top += np - reuse;
+        live += np;
+        age += (unsigned)np;
+        npend += np;
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 4; ++l)      // a pushed item may undercut its block's cached minimum (one at a time: two may share a block)
+            if ((umk >> l) & 1ull) {
+                const int sl = __builtin_amdgcn_readlane(slot, l);
+                const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, l);
+                const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), l);
+                const u64 kk = ((u64)khi << 32) | klo;
+                const unsigned aa = (unsigned)__builtin_amdgcn_readlane((int)pa, l);
+                const int j = sl >> 6;
+                const u64 ck = blk[j].k;
+                const unsigned ca = blk[j].a;
+                if ((kk < ck || (kk == ck && aa < ca)) && lane == 0) {
+                    WsBlk w;
+                    w.k = kk;
+                    w.a = aa;
+                    w.s = (unsigned)sl;
+                    w.c = 1u;
+                    w.l0 = w.l1 = lab;
+                    w.pad = 0;
+                    blk[j] = w;
+                }
+                __syncthreads();
+            }
+    }
+    __syncthreads();
+    flush();
     __syncthreads();
     return tie;
 }
@@ -836,24 +1113,37 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
     // reference's tie order and keep the binary heap, as do windows beyond the LDS
     // (a marker tie has no defined order in the unsorted frontier: that component alone is redone below on the binary heap,
     // whose layout the reference's tie order follows, incl. the swap proof of a harmless two-way tie)
+    long scratch_off = -1;       // scratch a failed wave attempt took: the binary-heap replay of the same component re-uses it
     if (root >= 0 && !b.no_wave) {
         const int A2 = (bh + 2) * (bw + 2);
         if ((long)28 * A2 <= lds_bytes) {
+            if (threadIdx.x == 0) atomicAdd(&b.stat[n].dbg[0], 1);
             if (!ws_window_wave<false>(b, n, root, y0, x0, bh, bw, nullptr, nullptr, A2)) return false;
         } else if (lds_bytes >= WS_LDS_BYTES) {
-            // window beyond the LDS (a clump of many nuclei, a tile-filling blob): its value keys and labels live in HBM
-            // scratch (planes that are dead by now; a window is a few 100 KB, i.e. L2-resident), the frontier keeps all of the LDS
-            if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, A2);
+            // window beyond the LDS (a clump of many nuclei, a tile-filling blob)
+            const bool bitmap = (long)16 * ((A2 + 63) >> 6) + 20 * 2048 <= lds_bytes && !b.no_bitmap;
+            const int need = bitmap ? bh * bw : A2;       // scratch entries (dead planes of this tile; a window is L2-resident)
+            if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, need);
             __syncthreads();
             const long off = *s_flag;
             __syncthreads();
-            if (off + A2 <= b.P) {
+            if (off + need <= b.P) {
                 const long g0s = (long)n * b.P;
-                if (!ws_window_wave<true>(b, n, root, y0, x0, bh, bw, (u64 *)(b.dist + g0s) + off, (int *)(b.overall + g0s) + off, lds_bytes / 16))
-                    return false;
+                if (need >= bh * bw) scratch_off = off;
+                if (bitmap) {
+                    // bitmap window + labelled frontier in LDS, value keys of the interior in HBM scratch
+                    if (threadIdx.x == 0) atomicAdd(&b.stat[n].dbg[1], 1);
+                    if (!ws_window_wave_bitmap(b, n, root, y0, x0, bh, bw, (u64 *)(b.dist + g0s) + off, lds_bytes)) return false;
+                } else {
+                    // keys and labels in HBM scratch, the frontier keeps all of the LDS
+                    if (threadIdx.x == 0) atomicAdd(&b.stat[n].dbg[2], 1);
+                    if (!ws_window_wave<true>(b, n, root, y0, x0, bh, bw, (u64 *)(b.dist + g0s) + off, (int *)(b.overall + g0s) + off, lds_bytes / 16))
+                        return false;
+                }
             }
         }
     }
+    if (threadIdx.x == 0) atomicAdd(&b.stat[n].dbg[root >= 0 ? 5 : 6], 1);
     const long g0 = (long)n * b.P;
     const int A = bh * bw;
     double *val;
@@ -871,10 +1161,13 @@ __device__ bool ws_window(PPBuf &b, int n, int root, int y0, int x0, int bh, int
         // oversized window: values (and, beyond ~34k pixels, labels) stay in HBM scratch (dist / overall / heap planes are
         // dead by now); the top `cap` slots of the heap -- where every pop's sift-down runs -- and the label window live
         // in LDS, the deeper heap levels in HBM
-        if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, A);
-        __syncthreads();
-        const long off = *s_flag;
-        __syncthreads();
+        long off = scratch_off;
+        if (off < 0) {
+            if (threadIdx.x == 0) *s_flag = atomicAdd(&b.stat[n].heap_top, A);
+            __syncthreads();
+            off = *s_flag;
+            __syncthreads();
+        }
         if (off + A > b.P) return true;  // scratch exhausted (overlapping boxes): leave it to the whole-tile replay
         val = b.dist + g0 + off;
         heap_far = (HItem *)(b.heap + 2 * g0) + off;
@@ -952,7 +1245,11 @@ __global__ __launch_bounds__(64) void ws_component(PPBuf b, int cls, int lds_byt
     const int n = blockIdx.y;
     const long g0 = (long)n * b.P;
     const int ncomp = b.stat[n].n_comp;
-    for (int k = blockIdx.x; k < ncomp; k += gridDim.x) {
+    // Component k of tile n is worked by block (k + 5 n) mod gridDim.x.  Workgroups go to XCD (linear id mod 8) and gridDim.x is a
+    // multiple of 8: without the rotation the first (often the only large) component of EVERY tile lands on the same XCD -- 64
+    // tile-filling blobs then share 32 CUs and one 4 MB L2 (measured: 4.4 us per pop instead of 1 us).
+    const int bx = (int)((blockIdx.x + gridDim.x - (5u * (unsigned)n) % gridDim.x) % gridDim.x);
+    for (int k = bx; k < ncomp; k += gridDim.x) {
         const int root = b.par[g0 + k];
         const int y0 = b.par2[g0 + root], y1 = ((const int32_t *)b.hraw)[g0 + root];
         const int x0 = ((const int32_t *)b.vraw)[g0 + root], x1 = b.cnt[g0 + root];
@@ -1022,6 +1319,7 @@ __global__ void pp_stat_init(TileStat *s, int n)
     s[i].heap_top = 0;
     s[i].tie = 0;
     s[i].max_area = 0;
+    for (int k = 0; k < 8; ++k) s[i].dbg[k] = 0;
 }
 
 static thread_local char pp_err[256] = "";
@@ -1061,14 +1359,17 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
     hipLaunchKernelGGL(pp_marker_labels, grid, blk, 0, s, b);
     // taps first: the watershed stage recycles dead planes
     if (tap_marker) hipMemcpyAsync(tap_marker, b.mk, (size_t)n * b.P * 4, hipMemcpyDeviceToDevice, s);
-    static int ws_mode = -1, ws_wave = 1;  // HVN_WS_GLOBAL=1 forces the whole-tile replay everywhere (tests)
+    static int ws_mode = -1, ws_wave = 1, ws_bitmap = 1;  // HVN_WS_GLOBAL=1 forces the whole-tile replay everywhere (tests)
     if (ws_mode < 0) {
         const char *e = getenv("HVN_WS_GLOBAL");
         ws_mode = (e && atoi(e)) ? 1 : 0;
         e = getenv("HVN_WS_WAVE");
         ws_wave = e ? atoi(e) : 1;
+        e = getenv("HVN_WS_BITMAP");
+        ws_bitmap = e ? atoi(e) : 1;
     }
     b.no_wave = ws_wave ? 0 : 1;
+    b.no_bitmap = ws_bitmap ? 0 : 1;
     hipLaunchKernelGGL(ws_init, grid, blk, 0, s, b);
     hipLaunchKernelGGL(ws_bbox, grid, blk, 0, s, b);
     hipLaunchKernelGGL(ws_list, grid, blk, 0, s, b);
@@ -1086,6 +1387,20 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
         hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_LDS_BYTES, s, b, 1, WS_LDS_BYTES);
     }
     hipLaunchKernelGGL(ws_fallback, dim3(n), dim3(64), WS_LDS_BYTES, s, b, ws_mode);
+    if (getenv("HVN_WS_STATS")) {   // diagnosis: which replay each component took (synchronous)
+        hipStreamSynchronize(s);
+        std::vector<TileStat> hs(n);
+        hipMemcpy(hs.data(), b.stat, sizeof(TileStat) * (size_t)n, hipMemcpyDeviceToHost);
+        long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}, comps = 0, tiles_tie = 0;
+        for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < 8; ++k) tot[k] += hs[i].dbg[k];
+            comps += hs[i].n_comp;
+            tiles_tie += hs[i].tie != 0;
+        }
+        fprintf(stderr, "[ws] %d tiles, %ld components: small-window %ld, bitmap-window %ld | handed over: mixed-label tie %ld, full frontier %ld | "
+                        "component heap replays %ld, whole-tile replays %ld (tiles flagged %ld)\n",
+                n, comps, tot[0], tot[1], tot[3], tot[4], tot[5], tot[6], tiles_tie);
+    }
     const size_t NP = (size_t)n * b.P;
     if (tap_blb) hipMemcpyAsync(tap_blb, b.blb, NP * 4, hipMemcpyDeviceToDevice, s);
     if (tap_dist) hipMemcpyAsync(tap_dist, b.blur, NP * 8, hipMemcpyDeviceToDevice, s);

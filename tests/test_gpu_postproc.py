@@ -59,6 +59,54 @@ def test_full_batch_32_tiles_and_properties():
     assert ((inst > 0) <= (pred[..., 1] >= 0.5)).all()
 
 
+def _smooth_noise_maps(n, hw, seed, it=6):
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def smooth(a):
+        for _ in range(it):
+            a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5.0
+        return a
+
+    f = np.stack([smooth(rng.normal(0, 1, (n, hw, hw)).transpose(1, 2, 0)).transpose(2, 0, 1) for _ in range(3)], -1)
+    f = f / f.std()
+    f[..., 0] = 0.5 + 0.5 * f[..., 0]
+    return f.astype(np.float32)
+
+
+def test_tie_heavy_maps_match_oracle():
+    """Marker ties at nearly every pop: dense touching nuclei with h / v quantised to 2..16 grey levels, and quantised smooth
+    noise (irregular blobs, markers from noise).  The wave flood decides same-label ties itself and hands only mixed-label
+    ties to the exact replay (hvn_postproc.hip ws_window_wave): every map must equal the oracle's exact heap, label for label."""
+    from hover_net_amd.synth import synth_pred_maps
+    from oracle import postproc as O
+
+    maps = []
+    for k, levels in enumerate((2, 3, 4, 8, 16)):
+        q = synth_pred_maps(8, 80, 80, None, seed=200 + k, k_lo=5, k_hi=40, noise=0.0)[0]
+        q[..., 1:] = np.round(q[..., 1:] * levels) / levels
+        maps.append(q)
+    for k, levels in enumerate((2, 4, 8)):
+        f = _smooth_noise_maps(4, 80, 300 + k)
+        f[..., 1:] = np.round(f[..., 1:] * levels) / levels
+        maps.append(f)
+    pred = np.concatenate(maps, 0)
+    got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
+    want = O.proc_batch(pred)
+    bad = [i for i in range(pred.shape[0]) if not np.array_equal(got[i], want[i])]
+    assert not bad, "maps %s differ from the exact replay" % bad
+    assert int(want.max()) > 3
+
+
+def test_tile_filling_noise_blobs_match_oracle():
+    """What a random-init network emits: blobs that fill the tile, hundreds of noise markers inside (windows beyond the LDS)."""
+    from oracle import postproc as O
+
+    pred = _smooth_noise_maps(3, 164, 400, it=3)
+    pred[..., 0] += 0.25                                   # most of the tile above the 0.5 threshold: one big component
+    got = _pp().separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
+    np.testing.assert_array_equal(got, O.proc_batch(pred))
+
+
 def test_large_tile_uses_hbm_heap():
     from hover_net_amd.synth import synth_pred_maps
     from oracle import postproc as O

@@ -72,3 +72,125 @@ def test_fill_holes_matches_scipy():
     for p in (0.4, 0.6, 0.7):
         b = rng.uniform(size=(41, 33)) < p
         np.testing.assert_array_equal(O.fill_holes(b.astype(np.int32)), ndimage.binary_fill_holes(b).astype(np.uint8))
+
+
+# ---- marker ties: what the wave-cooperative GPU flood may and may not decide on its own (csrc/hvn_postproc.hip ws_window_wave) ------------
+def ref_flood(val, out0, mask):
+    """SURVEY App. B exact model (skimage binary heap)."""
+    H, W = val.shape
+    Wp = W + 2
+    v = np.zeros((H + 2, Wp)); v[1:-1, 1:-1] = val
+    m = np.zeros((H + 2, Wp), bool); m[1:-1, 1:-1] = mask
+    o = np.zeros((H + 2, Wp), np.int64); o[1:-1, 1:-1] = out0 * mask
+    v, m, o = v.ravel(), m.ravel(), o.ravel()
+    heap = []
+    def smaller(a, b):
+        return a[0] < b[0] if a[0] != b[0] else a[1] < b[1]
+    def push(it):
+        heap.append(it); c = len(heap) - 1
+        while c > 0:
+            p = (c + 1) // 2 - 1
+            if smaller(heap[c], heap[p]): heap[c], heap[p] = heap[p], heap[c]; c = p
+            else: break
+    def pop():
+        top = heap[0]; last = heap.pop()
+        n = len(heap)
+        if n:
+            heap[0] = last; i = 0
+            while True:
+                l, r = 2 * i + 1, 2 * i + 2; s = i
+                if l < n:
+                    if smaller(heap[l], heap[i]): s = l
+                    if r < n and smaller(heap[r], heap[s]): s = r
+                else: break
+                if s == i: break
+                heap[i], heap[s] = heap[s], heap[i]; i = s
+        return top
+    for idx in np.flatnonzero(o): push((v[idx], 0, idx))
+    age = 0
+    while heap:
+        val_, a, idx = pop()
+        for d in (-Wp, -1, 1, Wp):
+            n = idx + d
+            if not m[n] or o[n] != 0: continue
+            age += 1; o[n] = o[idx]; push((v[n], age, n))
+    return o.reshape(H + 2, Wp)[1:-1, 1:-1]
+
+def wave_flood(val, out0, mask, rng):
+    """Unsorted-frontier model: exact min by (value, age); age-0 ties: if all tied have the same label pick a RANDOM one, else report.
+    Interior marker pixels (no unlabeled neighbour at start) are not queued."""
+    H, W = val.shape
+    o = np.full((H + 2, W + 2), -1, np.int64); o[1:-1, 1:-1] = np.where(mask, out0, -1)
+    v = np.zeros((H + 2, W + 2)); v[1:-1, 1:-1] = val
+    front = []
+    for y in range(1, H + 1):
+        for x in range(1, W + 1):
+            if o[y, x] > 0 and (o[y-1, x] == 0 or o[y, x-1] == 0 or o[y, x+1] == 0 or o[y+1, x] == 0):
+                front.append([v[y, x], 0, y, x])
+    age = 0
+    mixed = False
+    while front:
+        mk = min((f[0], f[1]) for f in front)
+        cand = [i for i, f in enumerate(front) if (f[0], f[1]) == mk]
+        if len(cand) > 1:
+            labs = {o[front[i][2], front[i][3]] for i in cand}
+            if len(labs) > 1: mixed = True
+            pick = cand[rng.integers(len(cand))]
+        else: pick = cand[0]
+        _, _, y, x = front.pop(pick)
+        for dy, dx in ((-1, 0), (0, -1), (0, 1), (1, 0)):
+            if o[y+dy, x+dx] == 0:
+                age += 1; o[y+dy, x+dx] = o[y, x]; front.append([v[y+dy, x+dx], age, y+dy, x+dx])
+    r = o[1:-1, 1:-1].copy(); r[r < 0] = 0
+    return r, mixed
+
+
+
+def test_same_label_marker_ties_are_harmless():
+    """The GPU flood keeps an UNSORTED frontier and extracts the exact (value, age) minimum; the only thing it cannot know is the
+    reference heap's order among equal-valued age-0 items (marker pixels).  Claim it relies on: when all tied items carry the same
+    label, ANY order gives the reference's labels (and marker pixels without an unlabelled neighbour need not be queued at all).
+    Checked against the exact binary-heap model of SURVEY Appendix B on tie-heavy random windows (2..10 grey levels), picking a
+    RANDOM item at every same-label tie; windows where items of different labels tie are the ones the GPU path hands to the exact
+    replay, and are skipped here."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(11)
+    n_same = n_mixed = 0
+    for case in range(500):
+        H, W = rng.integers(6, 16), rng.integers(6, 16)
+        levels = int(rng.choice([2, 3, 4, 6, 10]))
+        f = rng.normal(size=(H, W))
+        for _ in range(int(rng.integers(0, 3))):
+            f = (f + np.roll(f, 1, 0) + np.roll(f, -1, 0) + np.roll(f, 1, 1) + np.roll(f, -1, 1)) / 5
+        val = np.round((f - f.min()) / (np.ptp(f) + 1e-9) * (levels - 1)) / (levels - 1)
+        mask = rng.random((H, W)) < rng.choice([0.6, 0.8, 0.95, 1.0])
+        seeds = (rng.random((H, W)) < rng.choice([0.03, 0.08, 0.2])) & mask
+        if rng.random() < 0.5:
+            seeds = ndimage.binary_dilation(seeds) & mask
+        lab, k = ndimage.label(seeds)
+        if k == 0:
+            continue
+        got, mixed = wave_flood(val, lab, mask, rng)
+        if mixed:
+            n_mixed += 1
+            continue
+        n_same += 1
+        np.testing.assert_array_equal(got, ref_flood(val, lab, mask), err_msg="case %d" % case)
+    assert n_same > 60 and n_mixed > 60       # both kinds occur: the rule is exercised and so is the hand-over
+
+
+def test_exact_heap_model_equals_the_oracle_flood():
+    """The python model above IS the flood of the C oracle (and so of skimage): same labels on tie-heavy windows."""
+    if not hasattr(O, "watershed"):
+        pytest.skip("oracle exposes no stand-alone watershed")
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        H, W = int(rng.integers(6, 20)), int(rng.integers(6, 20))
+        val = np.round(rng.random((H, W)) * 3) / 3
+        mask = rng.random((H, W)) < 0.9
+        from scipy import ndimage
+        lab, k = ndimage.label((rng.random((H, W)) < 0.08) & mask)
+        if k == 0:
+            continue
+        np.testing.assert_array_equal(ref_flood(val, lab, mask), O.watershed(val, lab.astype(np.int32), mask))
