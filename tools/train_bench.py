@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """Training-step timing on one MI355X (BASELINE cfg 5 shapes, single GPU): phase 0 (freeze, batch 16) and phase 1
 (all layers, batch 4) of opt.py:23-142, CoNSeP 'original' mode with 5 types, synthetic batch, FusedAdam.
-Prints one JSON line per phase: ms per step split into forward / loss+backward / optimizer, steps/s, and the
-direct-convolution (algorithmic) conv FLOPs per step (forward + data-gradient + weight-gradient; the 5x5 convs execute 6x fewer as Winograd) over the step time.
+Prints one JSON line per phase: ms per step split into forward / loss+backward / optimizer, steps/s, and the MFMA work of the step
+counted the way bench.py counts it: `executed_gflop` = what the matrix pipe issues (the 5x5 convs run as Winograd F(4x4,5x5) in all
+three passes: 64 products per 4x4 tile instead of 400; data gradients of strided convs as the dense dilated convolution they execute),
+`algorithmic_gflop` = the direct-convolution figure (never a roofline number).  `mfma_frac_of_step` = executed / WHOLE step time /
+157.3 TFLOP/s is a lower bound of the conv kernels' fraction (the step also holds BatchNorm, losses, Adam, packing); the fraction over
+the conv kernels' own time comes from the rocprofv3 kernel summary of the same command (tools/train_roofline.py).
 usage: python tools/train_bench.py [--steps 10] [--warmup 3] [--phase 0|1|both]"""
 import argparse
 import json
@@ -18,18 +22,34 @@ from hover_net_amd.synth import synth_state_dict, synth_train_batch  # noqa: E40
 from hover_net_amd.train_engine import TrainEngine  # noqa: E402
 
 
-def conv_flops(plan, n):
-    f = 0.0
+PEAK_FP32_MATRIX_TFLOPS = 157.3
+
+
+def conv_flops(eng, n):
+    """(algorithmic forward, algorithmic backward, executed forward, executed backward) FLOPs of one step."""
+    plan = eng.plan
+
+    def tiles(h, w):
+        return -(-h // 4) * -(-w // 4)
+
+    af = ab = ef = eb = 0.0
     for op in plan.fwd:
         if op.kind == "conv":
-            f += 2.0 * n * op.y.h * op.y.w * op.y.c * (op.x.c // op.groups) * op.kh * op.kw
-    b = 0.0
+            d = 2.0 * n * op.y.h * op.y.w * op.y.c * (op.x.c // op.groups) * op.kh * op.kw
+            af += d
+            wino = eng._is_wino(plan.convs[op.wkey]) and op.stride == 1 and op.res is None
+            ef += 2.0 * n * 64 * tiles(op.y.h, op.y.w) * op.y.c * op.x.c if wino else d
     for op in plan.bwd:
         if op.kind == "wgrad":
-            b += 2.0 * n * op.dy.h * op.dy.w * op.dy.c * (op.x.c // op.groups) * op.kh * op.kw
+            d = 2.0 * n * op.dy.h * op.dy.w * op.dy.c * (op.x.c // op.groups) * op.kh * op.kw
+            ab += d
+            wino = op.wkey in eng._du_off and op.stride == 1
+            eb += 2.0 * n * 64 * tiles(op.dy.h, op.dy.w) * op.dy.c * op.x.c if wino else d
         elif op.kind == "dgrad":
-            b += 2.0 * n * op.dx.h * op.dx.w * op.dx.c * op.dy.c * op.kh * op.kw      # as executed (dense, dilated)
-    return f, b
+            d = 2.0 * n * op.dx.h * op.dx.w * op.dx.c * op.dy.c * op.kh * op.kw      # as executed (dense, dilated)
+            ab += d
+            eb += 2.0 * n * 64 * tiles(op.dx.h, op.dx.w) * op.dx.c * op.dy.c if eng._is_wino(plan.convs[op.wkey]) else d
+    return af, ab, ef, eb
 
 
 def main():
@@ -66,11 +86,19 @@ def main():
                 tb += ev[1].elapsed_time(ev[2])
                 to += ev[2].elapsed_time(ev[3])
         k = args.steps
-        ff, fb = conv_flops(eng.plan, bs)
+        af, ab, ef, eb = conv_flops(eng, bs)
         ms = (tf + tb + to) / k
+        slab_mb = eng.gslab.numel() * 4 / 1e6
         print(json.dumps({"phase": phase, "freeze": freeze, "batch": bs, "ms_per_step": ms, "forward_ms": tf / k, "loss_backward_ms": tb / k,
                           "optimizer_ms": to / k, "steps_per_s": 1000.0 / ms, "tiles_per_s": bs * 1000.0 / ms,
-                          "conv_gflop_forward": ff / 1e9, "conv_gflop_backward": fb / 1e9, "conv_tflops": (ff + fb) / ms / 1e9,
+                          "executed_gflop_forward": ef / 1e9, "executed_gflop_backward": eb / 1e9,
+                          "algorithmic_gflop_forward": af / 1e9, "algorithmic_gflop_backward": ab / 1e9,
+                          "algorithmic_speedup": (af + ab) / (ef + eb),
+                          "mfma_frac_of_step": (ef + eb) / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS,
+                          "mfma_frac_note": "executed MFMA FLOPs / whole step time / 157.3 TFLOP/s: a LOWER bound of the conv kernels' fraction",
+                          "gradient_slab_mb": slab_mb,
+                          "allreduce": "not measurable on one GPU: N > 1 all-reduces the gradient slab (%.0f MB fp32) in two buckets + 64 doubles of "
+                                       "loss partial sums per step; no RCCL run exists for it (one-GPU box)" % slab_mb,
                           "loss": eng.loss_terms()["overall_loss"], "arena_gb": eng.arena.numel() * 4 / 1e9, "grad_gb": eng.gmem.numel() * 4 / 1e9}))
         del eng, net, opt
         torch.cuda.empty_cache()

@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Roofline fraction of the training step's MFMA kernels from a rocprofv3 --kernel-trace results.db of
+`python tools/train_bench.py --phase P --steps K --warmup W` and the JSON line that run printed:
+    frac = executed MFMA FLOPs per step (train_bench's count) / (time of the MFMA kernels per step) / 157.3 TFLOP/s
+MFMA kernels = hvn_conv_igemm_f32 (forward convs, data gradients, Winograd-domain products), hvn_conv_wgrad_f32, hvn_conv0_mfma,
+hvn_conv0_wgrad_mfma, hvn_dense_grouped*; the Winograd transform launches are counted into the time (they exist only to feed them).
+usage: python tools/train_roofline.py <results.db> <train_bench.jsonl> <steps + warmup of that run>"""
+import json
+import sqlite3
+import sys
+
+db, line, passes = sys.argv[1], json.loads(open(sys.argv[2]).readline()), int(sys.argv[3])
+c = sqlite3.connect(db)
+rows = list(c.execute("select name, count(*), sum(duration) from kernels group by name"))
+mfma = ("hvn_conv_igemm_f32", "hvn_conv_wgrad_f32", "hvn_conv0_mfma", "hvn_conv0_wgrad_mfma", "hvn_dense_grouped", "hvn_conv_chain")
+feed = ("hvn_wino_in", "hvn_wino_out", "hvn_wino_dy", "hvn_wino_dw", "hvn_pack_w")
+t_mfma = sum(r[2] for r in rows if any(k in r[0] for k in mfma)) / 1e6 / passes
+t_feed = sum(r[2] for r in rows if any(k in r[0] for k in feed)) / 1e6 / passes
+t_all = sum(r[2] for r in rows) / 1e6 / passes
+ex = line["executed_gflop_forward"] + line["executed_gflop_backward"]
+print(json.dumps({"phase": line["phase"], "batch": line["batch"], "kernel_ms_per_step": t_all, "mfma_kernel_ms_per_step": t_mfma,
+                  "winograd_transform_and_pack_ms_per_step": t_feed, "executed_gflop_per_step": ex,
+                  "achieved_tflops": ex / (t_mfma + t_feed), "peak": 157.3, "frac": ex / (t_mfma + t_feed) / 157.3,
+                  "frac_mfma_kernels_only": ex / t_mfma / 157.3,
+                  "note": "frac = executed MFMA FLOPs / (MFMA kernels + Winograd transforms + weight packing) / 157.3 TFLOP/s; rocprofv3 --kernel-trace durations"}))
