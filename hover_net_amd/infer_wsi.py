@@ -327,6 +327,102 @@ class WsiMerger:
         self.inst_map[tile_tl[0]:tile_br[0], tile_tl[1]:tile_br[1]] = roi + pred_inst
 
 
+class DeviceMerger:
+    """`WsiMerger` with the instance map in HBM: the same callbacks in the same tile order, each tile's array work done by
+    `hvn_wsi_merge_normal` / `hvn_wsi_merge_fixing` (csrc/hvn_wsi_merge.hip) on a side stream.  What stays on the host is the
+    dictionary: per fix-up tile the list of removed ids and the "touching" flags of the new ids come back (a few hundred bytes),
+    which also yields the next tile's id offset -- the one true sequential dependency of wsi.py:569-677."""
+
+    def __init__(self, proc_shape, device):
+        import ctypes
+
+        from . import lib as L
+
+        self._L, self._ct = L, ctypes
+        self.device = torch.device(device)
+        self.inst_map = torch.zeros((int(proc_shape[0]), int(proc_shape[1])), dtype=torch.int32, device=self.device)
+        self.inst_info = {}
+        self._ids = []
+        self.stream = torch.cuda.Stream(self.device, priority=-1)
+        self.cap = 1 << 20
+        self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
+        self.epoch = 0
+        self.removed_cap = 1 << 16
+        self.removed = torch.zeros(self.removed_cap, dtype=torch.int32, device=self.device)
+        self.counters = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.touching = torch.zeros(1 << 16, dtype=torch.uint8, device=self.device)
+        self._h_counters = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        self._h_removed = torch.zeros(self.removed_cap, dtype=torch.int32, pin_memory=True)
+        self._h_touching = torch.zeros(1 << 16, dtype=torch.uint8, pin_memory=True)
+
+    _max_id = WsiMerger._max_id
+    _insert = WsiMerger._insert
+
+    def _pred(self, pred_inst, ready):
+        """The tile's local-id map on the device: the post-processing output itself (`ready` = its event), or an upload of the host
+        array a remote rank sent."""
+        if torch.is_tensor(pred_inst) and pred_inst.is_cuda:
+            if ready is not None:
+                self.stream.wait_event(ready)
+            return pred_inst.contiguous()
+        return torch.from_numpy(np.ascontiguousarray(pred_inst, np.int32)).to(self.device, non_blocking=True)
+
+    def normal(self, pred_inst, info, tile_tl, tile_br, ready=None):
+        if len(info) == 0:
+            return
+        off = self._max_id()
+        for i, e in info.items():
+            self._insert(i + off, e)
+        with torch.cuda.stream(self.stream):
+            p = self._pred(pred_inst, ready)
+            h, w = int(p.shape[0]), int(p.shape[1])
+            self._L.check(self._L.lib().hvn_wsi_merge_normal(self.inst_map.data_ptr(), self.inst_map.shape[1], int(tile_tl[0]), int(tile_tl[1]), h, w,
+                                                             p.data_ptr(), int(off), self._ct.c_void_p(self.stream.cuda_stream)), "hvn_wsi_merge_normal")
+            p.record_stream(self.stream)
+
+    def fixing(self, pred_inst, info, tile_tl, tile_br, ready=None, n_local=None):
+        if len(info) == 0:
+            return
+        off = self._max_id()                                     # before any removal (wsi.py:621-624)
+        if n_local is None:                                      # the tile's largest label: new ids WITHOUT a dict entry are written / dropped too
+            n_local = int(pred_inst.max())
+        n_local = int(max(n_local, max(info)))
+        if off + 1 >= self.cap:                                  # the id tables index every id in the map
+            self.cap = max(2 * self.cap, off + 2)
+            self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
+        if n_local + 1 > self.touching.shape[0]:
+            self.touching = torch.zeros(2 * (n_local + 1), dtype=torch.uint8, device=self.device)
+            self._h_touching = torch.zeros(2 * (n_local + 1), dtype=torch.uint8, pin_memory=True)
+        self.epoch += 1
+        with torch.cuda.stream(self.stream):
+            p = self._pred(pred_inst, ready)
+            h, w = int(p.shape[0]), int(p.shape[1])
+            self._L.check(self._L.lib().hvn_wsi_merge_fixing(
+                self.inst_map.data_ptr(), self.inst_map.shape[1], int(tile_tl[0]), int(tile_tl[1]), h, w, p.data_ptr(), n_local, int(off), self.epoch,
+                self.flags.data_ptr(), self.cap, self.removed.data_ptr(), self.removed_cap, self.counters.data_ptr(), self.touching.data_ptr(),
+                self._ct.c_void_p(self.stream.cuda_stream)), "hvn_wsi_merge_fixing")
+            p.record_stream(self.stream)
+            self._h_counters.copy_(self.counters, non_blocking=True)
+            self._h_removed[:4096].copy_(self.removed[:4096], non_blocking=True)
+            self._h_touching[:n_local + 1].copy_(self.touching[:n_local + 1], non_blocking=True)
+        self.stream.synchronize()
+        n_rem = int(self._h_counters[0])
+        if n_rem > self.removed_cap:
+            raise RuntimeError("%d instances removed by one fix-up tile: beyond the list of %d" % (n_rem, self.removed_cap))
+        rem = self._h_removed[:n_rem].numpy() if n_rem <= 4096 else self.removed[:n_rem].cpu().numpy()
+        for i in rem.tolist():
+            self.inst_info.pop(i, None)
+        touching = self._h_touching.numpy()
+        pred_min = int(self._h_counters[3])                      # np.unique(pred_inst)[1:] (wsi.py:646): a tile without background loses its smallest id
+        for i, e in info.items():                                # ascending local id, like `for inst_id in inner_inst_list`
+            if not touching[i] and not (pred_min > 0 and i == pred_min):
+                self._insert(i + off, e)
+
+    def result(self):
+        self.stream.synchronize()
+        return self.inst_map.cpu().numpy(), self.inst_info
+
+
 # --------------------------------------------------------------------------------------------
 class WsiInference:
     def __init__(self, model, nr_types=None, batch_size=32, chunk_shape=10000, tile_shape=2048, ambiguous_size=128,
@@ -453,6 +549,7 @@ class WsiInference:
             return out
 
         inflight, futs, mine = collections.deque(), collections.deque(), {}
+        self._dev_results = {}                                     # tile index -> (device local-id map, ready event), one rank only
         with ThreadPoolExecutor(1) as pool:
             def drain(block):
                 while futs and (block or futs[0][1].done()):
@@ -465,6 +562,9 @@ class WsiInference:
             def finish():
                 i, wait = inflight.popleft()
                 inst_h, rec_h, release = wait()
+                if world == 1 and hasattr(wait, "device_result"):
+                    nz = np.flatnonzero(rec_h["area"]) if rec_h.size else np.zeros(0, np.int64)
+                    self._dev_results[i] = wait.device_result + (int(nz[-1]) + 1 if nz.size else 0,)      # + the tile's largest label
                 futs.append((i, pool.submit(host_half, i, inst_h, rec_h, release)))
 
             for i in idxs:
@@ -503,6 +603,7 @@ class WsiInference:
                 tm["gpu_launch_to_ready_s"] = tm.get("gpu_launch_to_ready_s", 0.0) + (time.perf_counter() - t0)
             return slot["inst"].numpy(), slot["rec"].numpy().view(post_proc._REC_DTYPE).reshape(-1), slot["free"].set
 
+        wait.device_result = (inst[0], slot["event"])              # for the on-device merge: the local-id map stays in HBM
         return wait
 
     def _pinned_slot(self, inst_shape, rec_shape):
@@ -555,15 +656,34 @@ class WsiInference:
         self._shape = shape
         if mask is None:
             mask = np.ones((max(1, int(shape[0]) // 32), max(1, int(shape[1]) // 32)), np.uint8)
+        import os
+
         rank = infer_tile._dist()[1]
-        merger = WsiMerger(shape) if rank == 0 else None
+        on_device = self.device.type == "cuda" and os.environ.get("HVN_WSI_HOST_MERGE", "0") == "0"
+        merger = None if rank != 0 else (DeviceMerger(shape, self.device) if on_device else WsiMerger(shape))
         for phase, tiles in enumerate(self.tile_lists(shape, mask)):
             # the merge is sequential by definition (wsi.py:569-677) and runs on rank 0, under the GPU work of later tiles
             for i, inst_h, info in self._results_in_order(pred_map, tiles):
                 t0 = time.perf_counter()
-                (merger.normal if phase == 0 else merger.fixing)(inst_h, info, tiles[i][0], tiles[i][1], shifted=True)
+                if on_device:
+                    dev, ready, n_local = self._dev_results.pop(i, (None, None, None))
+                    src = inst_h if dev is None else dev           # remote ranks' tiles arrive as host arrays and are uploaded
+                    if phase == 0:
+                        merger.normal(src, info, tiles[i][0], tiles[i][1], ready=ready)
+                    else:
+                        merger.fixing(src, info, tiles[i][0], tiles[i][1], ready=ready, n_local=int(inst_h.max()) if n_local is None else n_local)
+                else:
+                    (merger.normal if phase == 0 else merger.fixing)(inst_h, info, tiles[i][0], tiles[i][1], shifted=True)
                 if getattr(self, "timing", None) is not None:
                     self.timing["merge_s"] = self.timing.get("merge_s", 0.0) + (time.perf_counter() - t0)
+        if rank != 0:
+            return None, None
+        if on_device:
+            t0 = time.perf_counter()
+            out = merger.result()
+            if getattr(self, "timing", None) is not None:
+                self.timing["map_d2h_s"] = time.perf_counter() - t0
+            return out
         if rank != 0:
             return None, None
         return merger.inst_map, merger.inst_info

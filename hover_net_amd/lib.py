@@ -16,7 +16,7 @@ VARIANTS = {
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("hvn_conv.hip", "hvn_conv_chain.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip",
+SOURCES = ("hvn_conv.hip", "hvn_conv_chain.hip", "hvn_conv_bf16.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_targets.hip", "hvn_wsi_merge.hip",
            "hvn_augment.hip", "hvn_train_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fvisibility=hidden", "-Wno-unused-value", "-pthread")
@@ -61,6 +61,7 @@ EXPORTS = (
     "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
     "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
     "hvn_extract_patches", "hvn_gen_targets", "hvn_gen_targets_workspace_bytes", "hvn_augment_shape", "hvn_augment_input",
+    "hvn_wsi_merge_normal", "hvn_wsi_merge_fixing",
 )
 
 
@@ -146,6 +147,11 @@ def lib():
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_augment_input.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p]
+        L.hvn_wsi_merge_normal.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int32, ctypes.c_void_p]
+        L.hvn_wsi_merge_fixing.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                           ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_train_last_error.restype = ctypes.c_char_p
         L.hvn_run_train_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.hvn_loss_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -146,6 +146,21 @@ HVN_API int hvn_instance_table(const int32_t *inst, const float *pred, int n, in
                                int nr_types, hvn_inst_rec *records, int32_t *counts, int max_inst,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* -- whole-slide merge: infer/wsi.py:569-599 post_proc_normal_tile_callback, :602-677 post_proc_fixing_tile_callback and :51-60
+ * _remove_inst on a DEVICE-resident int32 instance map [H][map_w] (tiles strictly in the reference's order: the id offset is the
+ * running maximum id and the fix-up windows overlap).  pred_inst: dev int32 [h][w] local ids of the tile at (y0, x0).
+ * normal:  window = pred_inst (+ off where > 0).
+ * fixing:  old ids wholly inside the window (np.unique(roi)[1:] minus np.unique(edge)[1:] -- "[1:]" drops the smallest value as the
+ *          reference does) are zeroed and listed in `removed` (count in counters[0]; counters[1] / [2] = smallest value on the window
+ *          edge / in the window, counters[3] = smallest value of pred_inst: np.unique(pred_inst)[1:] drops it too); touching[i] = 1 for new ids i <= n_local that overlap a kept old instance (they are dropped); the
+ *          other new ids are written with + off.  id_flags: dev int32 [2][cap] epoch-stamped tables (zeroed once; cap > every id in
+ *          the map), epoch > 0 and increasing from call to call; removed: dev [removed_cap]; counters: dev [4]; touching: dev [n_local + 1]. */
+HVN_API int hvn_wsi_merge_normal(int32_t *inst_map, int64_t map_w, int y0, int x0, int h, int w, const int32_t *pred_inst, int32_t off,
+                                 void *stream);
+HVN_API int hvn_wsi_merge_fixing(int32_t *inst_map, int64_t map_w, int y0, int x0, int h, int w, const int32_t *pred_inst, int32_t n_local,
+                                 int32_t off, int32_t epoch, int32_t *id_flags, int64_t cap, int32_t *removed, int32_t removed_cap,
+                                 int32_t *counters, uint8_t *touching, void *stream);
+
 /* -- contours: cv2.findContours(crop, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] of process() (post_proc.py:132-143)
  * HOST function (O(perimeter) per instance over its bbox crop): inst = host int32 [h][w]; recs = host records
  * (slots with area 0 are skipped); pts = host int32 [max_pts][2] as (x, y) in map coordinates;
