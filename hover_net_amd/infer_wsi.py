@@ -549,6 +549,7 @@ class WsiInference:
             return out
 
         inflight, futs, mine = collections.deque(), collections.deque(), {}
+        depth = 4 if self.device.type == "cuda" else 2          # tiles in flight: one per post-processing lane + one being handed over
         self._dev_results = {}                                     # tile index -> (device local-id map, ready event), one rank only
         with ThreadPoolExecutor(1) as pool:
             def drain(block):
@@ -570,7 +571,7 @@ class WsiInference:
             for i in idxs:
                 tl, br = tiles[i][0], tiles[i][1]
                 inflight.append((i, self._launch_tile(pred_map.window(tl, br))))
-                if len(inflight) >= 2:
+                if len(inflight) >= depth:
                     finish()
                 yield from drain(False)
             while inflight:
@@ -590,11 +591,25 @@ class WsiInference:
             inst_h, rec_h = self._postproc_tile(tile_map)
             return lambda: (inst_h, rec_h, lambda: None)
         t0 = time.perf_counter()
-        inst, rec, _ = post_proc.process_batch_device(tile_map.contiguous().unsqueeze(0), self.nr_types, True)
-        slot = self._pinned_slot(inst[0].shape, rec[0].shape)
-        slot["inst"].copy_(inst[0], non_blocking=True)
-        slot["rec"].copy_(rec[0], non_blocking=True)
-        slot["event"].record(torch.cuda.current_stream(self.device))
+        # tiles alternate between a few post-processing lanes (own stream + own workspace): one tile's ~30 launches over 4-5
+        # Mpixel leave most of the chip idle, two or three tiles in flight fill it
+        lanes = self.__dict__.setdefault("_pp_lanes", [])
+        if not lanes:
+            import os
+            for _ in range(max(1, int(os.environ.get("HVN_WSI_LANES", "3")))):
+                lanes.append((torch.cuda.Stream(self.device), post_proc.PostProc(self.device)))
+            self._pp_next = 0
+        stream, pp = lanes[self._pp_next % len(lanes)]
+        self._pp_next += 1
+        stream.wait_stream(torch.cuda.current_stream(self.device))         # the prediction map is complete on the caller's stream
+        with torch.cuda.stream(stream):
+            tile = tile_map.contiguous().unsqueeze(0)
+            inst = pp.separate(tile)
+            rec, _ = pp.table(inst, tile, self.nr_types)
+            slot = self._pinned_slot(inst[0].shape, rec[0].shape)
+            slot["inst"].copy_(inst[0], non_blocking=True)
+            slot["rec"].copy_(rec[0], non_blocking=True)
+            slot["event"].record(stream)
         tm = getattr(self, "timing", None)
 
         def wait():
@@ -607,20 +622,20 @@ class WsiInference:
         return wait
 
     def _pinned_slot(self, inst_shape, rec_shape):
-        """A free pinned (instance map, record table) pair for this tile shape; four per shape, waiting for the oldest when
+        """A free pinned (instance map, record table) pair for this tile shape; six per shape, waiting for the oldest when
         all are in use (hipHostMalloc is slow, so the slots are kept)."""
         import threading
 
         pools = self.__dict__.setdefault("_slots", {})
         key = (tuple(inst_shape), tuple(rec_shape))
         ring = pools.setdefault(key, {"slots": [], "next": 0})
-        if len(ring["slots"]) < 4:
+        if len(ring["slots"]) < 6:
             slot = {"inst": torch.empty(inst_shape, dtype=torch.int32, pin_memory=True),
                     "rec": torch.empty(rec_shape, dtype=torch.uint8, pin_memory=True),
                     "event": torch.cuda.Event(), "free": threading.Event()}
             ring["slots"].append(slot)
         else:
-            slot = ring["slots"][ring["next"] % 4]
+            slot = ring["slots"][ring["next"] % 6]
             ring["next"] += 1
             slot["free"].wait()
         slot["free"].clear()
