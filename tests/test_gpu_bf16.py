@@ -126,31 +126,36 @@ def test_bf16_batch_invariance_and_dtype_switch():
     assert float((a[..., 0] - c[..., 0]).abs().max()) < 2e-2 and not torch.equal(a, c)
 
 
-def test_bf16_sized_map_perturbation_keeps_the_segmentation():
-    """Declared cfg-3 tolerance, second half: what matters downstream of the bf16 network is the instance map.  The
-    prediction maps of structured synthetic tiles are perturbed by the network's measured bf16 error scale -- every channel
-    rounded to bf16 (8 mantissa bits: relative 2^-9, i.e. up to 2e-3 on p ~ 0.9 and 4e-3 on |h|, |v| ~ 1) plus smooth noise of
-    +-1e-2 on p_nuc / +-3e-2 on h, v (twice the mean logit error measured above) -- and post-processed on the GPU:
-    mean panoptic quality against the unperturbed fp32 result must stay >= 0.985 (no tile below 0.93; measured 0.9906 / 0.9547) (metrics/stats_utils.py:178 get_fast_pq semantics:
-    IoU > 0.5 pairing, DQ x SQ), restated in tests/pq_util.py."""
-    from hover_net_amd.post_proc import PostProc
-    from hover_net_amd.synth import synth_pred_maps
+def test_bf16_trained_like_network_keeps_the_segmentation():
+    """Declared cfg-3 tolerance, second half: what matters downstream of the bf16 network is the instance map.
+    Network against network: a 'fast'-mode HoVer-Net is FITTED here with the repository's own trainer (tests/fit_util.py: 240
+    steps of run_desc.train_step on painted H&E-like tiles, targets from gen_targets_device) until it segments held-out tiles
+    (panoptic quality against the painted truth > 0.8); the same weights then run in fp32 and in bf16 over held-out tiles,
+    both prediction maps go through the on-GPU instance separation, and the bf16 segmentation is scored against the fp32 one
+    with the reference's metric (metrics/stats_utils.py:178 get_fast_pq, restated in tests/pq_util.py and pinned to it in
+    tests/test_oracle_metrics.py):  mean PQ >= 0.99, no tile below 0.95  (measured 1.0000 / 1.0000: identical instance maps;
+    max |p_bf16 - p_fp32| 0.012, max |hv| difference 0.033)."""
+    import fit_util
+    from hover_net_amd import post_proc, run_desc
+    from pq_util import pq
 
-    from pq_util import pq           # the reference's get_fast_pq restated; pinned to it in tests/test_oracle_metrics.py
-
-    pred = synth_pred_maps(16, 164, 164, 6, seed=77)[0]
-    rng = np.random.default_rng(5)
-    noisy = pred.copy()
-    from scipy import ndimage
-    for ch, amp in ((1, 1e-2), (2, 3e-2), (3, 3e-2)):        # 2x the measured MEAN logit error of the bf16 network (1.5e-2)
-        n = ndimage.uniform_filter(rng.uniform(-1, 1, pred.shape[:3]), size=(1, 3, 3)) * 3 * amp
-        noisy[..., ch] += np.clip(n, -amp, amp).astype(np.float32)
-    noisy = torch.from_numpy(noisy).to(torch.bfloat16).float().numpy()
-    noisy[..., 0] = pred[..., 0]
-    pp = PostProc("cuda")
-    a = pp.separate(torch.from_numpy(pred).to("cuda")).cpu().numpy()
-    b = pp.separate(torch.from_numpy(noisy).to("cuda")).cpu().numpy()
-    scores = [pq(x, y) for x, y in zip(a, b)]
-    assert sum(len(np.unique(x)) - 1 for x in a) > 300
-    print("bf16-sized perturbation: PQ mean %.4f min %.4f" % (float(np.mean(scores)), min(scores)))
-    assert min(scores) >= 0.93 and float(np.mean(scores)) >= 0.985, (min(scores), float(np.mean(scores)))
+    net, curve = fit_util.fit("fast", None, steps=240, lr=1e-3, seed=0)
+    assert curve[-1] < 0.3 * curve[5], "the fit did not converge: %s" % curve[::40]
+    imgs, anns = fit_util.painted_tiles(24, 256, seed=999)
+    o = (256 - 164) // 2
+    truth = anns[:, o:o + 164, o:o + 164]
+    tiles = torch.from_numpy(imgs).cuda()
+    seg = {}
+    for dt in ("fp32", "bf16"):
+        net.compute_dtype = dt
+        pred = run_desc.infer_step_device(tiles, net).clone()
+        inst, _, _ = post_proc.process_batch_device(pred, None, False)
+        seg[dt] = (pred.cpu().numpy(), inst.cpu().numpy())
+    (pm32, i32), (pm16, i16) = seg["fp32"], seg["bf16"]
+    assert not np.array_equal(pm32, pm16)                                  # two different arithmetic paths did run
+    assert float(np.abs(pm16[..., 0] - pm32[..., 0]).max()) < 4e-2 and float(np.abs(pm16[..., 1:] - pm32[..., 1:]).max()) < 1e-1
+    vs_truth = [pq(truth[k], i32[k]) for k in range(len(i32))]
+    assert np.mean(vs_truth) > 0.8, "the fitted network does not segment: PQ vs truth %.3f" % np.mean(vs_truth)
+    q = [pq(i32[k], i16[k]) for k in range(len(i32))]
+    print("bf16 vs fp32 segmentation: mean PQ %.4f, worst tile %.4f; fp32 vs painted truth %.4f" % (np.mean(q), np.min(q), np.mean(vs_truth)))
+    assert np.mean(q) >= 0.99 and np.min(q) >= 0.95, (np.mean(q), np.min(q))
