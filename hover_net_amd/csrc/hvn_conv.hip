@@ -75,7 +75,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP'
 #endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, int ABL = 0, bool GROUPED = false, bool HAS_PRE = true, bool HAS_X2 = false>
-__global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64) ? 3 : 2) void hvn_conv_igemm_f32(ConvArgs p)
+__global__ __launch_bounds__(256, (HVN_SWZ && BN <= 64 && BM <= 128) ? 3 : 2) void hvn_conv_igemm_f32(ConvArgs p)
 {
     // EXPERIMENT (off by default, HVN_STAGGER=1|2|3): two workgroups share a CU, i.e. two waves share each SIMD's matrix pipe; giving
     // one of them a raised issue priority (told apart by LDS base or wave slot) or a delayed start was meant to keep one
@@ -703,6 +703,13 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
         if (!a.pre_s && !getenv("HVN_NO_RAWSTORE"))
             return padded ? launch_conv<128, 64, 4, 1, true, 0, false, false>(a, stream) : launch_conv<128, 64, 4, 1, false, 0, false, false>(a, stream);
         return padded ? launch_conv<128, 64, 4, 1, true>(a, stream) : launch_conv<128, 64, 4, 1, false>(a, stream);
+    case 320:
+        // 256 x 64 tiles for the 64-channel layers (d0's 3x3 convs, u1.conva's Winograd products): a wave owns 64 x 64 like in the
+        // 128 x 128 tile, so a k-step carries 64 MFMAs per wave instead of 32 between two barriers (tile_n = 64 | 0x100; chosen per
+        // launch shape by Engine.autotune_tiles; same k order per output element, same bits)
+        if (!a.pre_s && !getenv("HVN_NO_RAWSTORE"))
+            return padded ? launch_conv<256, 64, 4, 1, true, 0, false, false>(a, stream) : launch_conv<256, 64, 4, 1, false, 0, false, false>(a, stream);
+        return padded ? launch_conv<256, 64, 4, 1, true>(a, stream) : launch_conv<256, 64, 4, 1, false>(a, stream);
     case 32:
         // dense-unit conv2: patch-staged kernel (no per-tap restaging); HVN_NO_DENSE_KERNEL=1 falls back to the generic grouped path
         if (a.groups == 4 && a.Cin == 128 && a.Cout == 32 && a.stride == 1 && !padded && !a.pre_s && !a.res && !a.post_s && a.nbatch <= 1 &&

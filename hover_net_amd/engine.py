@@ -113,7 +113,7 @@ class Engine:
             if len(tiles) != len(self.ops):
                 raise ValueError("HVN_TILE_FILE holds %d entries for a plan of %d ops" % (len(tiles), len(self.ops)))
             for o, op, tn in zip(self.ops, plan.ops, tiles):
-                if op.kind == PL.OP_CONV and op.tile_n == 128 and tn in (64, 128):
+                if op.kind == PL.OP_CONV and ((op.tile_n == 128 and tn in (64, 128)) or (op.tile_n == 64 and tn in (64, 320))):
                     o.tile_n = tn
         elif dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
             self.autotune_tiles()
@@ -241,18 +241,20 @@ class Engine:
             return best
 
         for i, op in enumerate(self.plan.ops):
-            if op.kind != PL.OP_CONV or op.tile_n != 128:
+            if op.kind != PL.OP_CONV or op.tile_n not in (128, 64) or int(op.extra.get("groups", 1)) != 1:
                 continue
             x2 = op.extra.get("x2")
             key = (op.kh, op.kw, op.stride, op.x.c, op.cout, op.y.h, op.y.w, op.x.h, op.x.w, op.res is not None, op.pre is not None,
                    op.post is not None, int(op.extra.get("nbatch", 1)), x2.c if x2 is not None else 0)
+            # 128-channel-wide plans: 128 x 128 or 128 x 64 tiles; 64-wide ones: 128 x 64 or 256 x 64 (tile_n 320 = 64 | 0x100)
+            cands = (128, 64) if op.tile_n == 128 else (64, 320)
             if key not in self.tile_choice:
                 o = self.ops[i]
                 t = {}
-                for tn in (128, 64):
+                for tn in cands:
                     o.tile_n = tn
                     t[tn] = time_op(i)
-                self.tile_choice[key] = (64 if t[64] < margin * t[128] else 128, t[128], t[64])
+                self.tile_choice[key] = (cands[1] if t[cands[1]] < margin * t[cands[0]] else cands[0], t[cands[0]], t[cands[1]])
             self.ops[i].tile_n = self.tile_choice[key][0]
         torch.cuda.synchronize(self.device)
 

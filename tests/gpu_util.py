@@ -20,7 +20,7 @@ def rand_conv_weight(rng, cout, cin_g, k):
 
 
 def run_conv_case(n, xbuf_shape, xview, ybuf_shape, yview, wt, *, stride=1, pad=(0, 0), groups=1, bn=False, relu=0, pre=False,
-                  res=False, post=False, seed=0, inplace_res=False, dtype="fp32"):
+                  res=False, post=False, seed=0, inplace_res=False, dtype="fp32", force_tile=None):
     """Builds one CONV op over strided views, runs it on the GPU and with the torch
     interpreter.  xview / yview = (y0, x0, h, w, c0, c).  Returns (got, want) NHWC tensors of the
     WHOLE output buffer (so writes outside the view would be caught)."""
@@ -64,6 +64,8 @@ def run_conv_case(n, xbuf_shape, xview, ybuf_shape, yview, wt, *, stride=1, pad=
         eng.arena.copy_(torch.randn(eng.arena.shape, generator=g))
         A = plan_interp.Arena(P, n)
         A.flat.copy_(eng.arena.cpu())
+    if force_tile is not None:
+        eng.ops[0].tile_n = force_tile
     eng.run_raw(n)
     torch.cuda.synchronize()
     r = A.view(op.res).clone() if op.res is not None else None

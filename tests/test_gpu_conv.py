@@ -189,3 +189,18 @@ def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn, m, k):
     A.view(x).copy_(xin)
     v = plan_interp.wino_in_ref(P.ops[0], A.view(x).clone())
     _check(eng.buffer(P.ops[0].y, n).cpu().reshape(v.shape), v, tol=1e-4)
+
+
+@pytest.mark.parametrize("k,pad,pre", [(3, (1, 1), False), (1, (0, 0), True), (5, (2, 2), False)])
+def test_256x64_tile_equals_128x64_tile(k, pad, pre):
+    """The 256 x 64 workgroup tile of the 64-channel layers (tile_n = 64 | 0x100, picked per shape by Engine.autotune_tiles) walks k
+    in the same order per output element as the 128 x 64 tile: same bits, and the torch interpreter's values."""
+    from gpu_util import rand_conv_weight, run_conv_case
+    n, s = 3, 21                                  # 3 * 21 * 21 = 1323 pixels: 5.2 tiles of 256, ragged, straddling samples
+    wt = rand_conv_weight(np.random.default_rng(3), 64, 64, k)
+    kw = dict(n=n, xbuf_shape=(s, s, 64), xview=(0, 0, s, s, 0, 64), ybuf_shape=(s, s, 64), yview=(0, 0, s, s, 0, 64), wt=wt, pad=pad,
+              bn=True, relu=1, pre=pre, res=not pre, seed=5)
+    got64, want = run_conv_case(force_tile=64, **kw)
+    got256, _ = run_conv_case(force_tile=320, **kw)
+    assert torch.equal(got64, got256)
+    assert float((got256 - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
