@@ -235,10 +235,10 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         if (op->stride > 1 && op->_rsv > 1) {         // explicit F(m x m, r x r): stride = m, _rsv = r
             a.m = op->stride; a.r = op->_rsv;
         } else {                                     // legacy encoding by the number of positions: 5x5 filters
-            a.m = n2 == 36 ? 2 : n2 == 64 ? 4 : 0; a.r = 5;
+            a.m = n2 == 36 ? 2 : n2 == 64 ? 4 : n2 == 100 ? 6 : 0; a.r = 5;
         }
-        if (!a.m || (a.m + a.r - 1) * (a.m + a.r - 1) != n2 || !((a.m == 2 && a.r == 5) || (a.m == 4 && (a.r == 5 || a.r == 3))))
-            return fail(HVN_E_ARG, "winograd transform: %s%ld transform positions do not match F(2,5) / F(4,5) / F(4,3)", "", (long)n2);
+        if (!a.m || (a.m + a.r - 1) * (a.m + a.r - 1) != n2 || !((a.m == 2 && a.r == 5) || ((a.m == 4 || a.m == 6) && (a.r == 5 || a.r == 3))))
+            return fail(HVN_E_ARG, "winograd transform: %s%ld transform positions do not match F(2,5) / F(4,5) / F(4,3) / F(6,3) / F(6,5)", "", (long)n2);
         if (!a.x || !a.y || !a.mat || a.ty <= 0 || a.tx <= 0 || (a.C & 3)) return fail(HVN_E_ARG, "winograd transform: bad descriptor%s", "");
         if (!aligned16(a.x) || !aligned16(a.y) || ((a.xsn | a.xsy | a.xsx | a.ysn | a.ysy | a.ysx) & 3))
             return fail(HVN_E_ARG, "winograd transform: views not 16-byte aligned%s", "");

@@ -327,6 +327,7 @@ int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream)
 template <int VW> struct WVec;
 template <> struct WVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 template <> struct WVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct WVec<1> { typedef float T __attribute__((ext_vector_type(1))); };
 
 template <int MO, int R, int VW>
 __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
@@ -391,6 +392,12 @@ int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream)
     } else if (a.m == 4 && a.r == 5) {
         const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
         hipLaunchKernelGGL((hvn_wino_in<4, 5, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 6 && a.r == 3) {      // F(6x6, 3x3): the same 8 x 8 transform tile as F(4x4, 5x5), 64 products per 36 outputs
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
+        hipLaunchKernelGGL((hvn_wino_in<6, 3, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 6 && a.r == 5) {      // F(6x6, 5x5): 10 x 10 tile, one channel per thread (100 products per 36 outputs)
+        const long total = (long)a.N * a.ty * a.tx * a.C;
+        hipLaunchKernelGGL((hvn_wino_in<6, 5, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
     } else
         return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -460,6 +467,12 @@ int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream)
     } else if (a.m == 4 && a.r == 5) {
         const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
         hipLaunchKernelGGL((hvn_wino_out<4, 5, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 6 && a.r == 3) {      // F(6x6, 3x3): the same 8 x 8 transform tile as F(4x4, 5x5), 64 products per 36 outputs
+        const long total = (long)a.N * a.ty * a.tx * (a.C / 2);
+        hipLaunchKernelGGL((hvn_wino_out<6, 3, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    } else if (a.m == 6 && a.r == 5) {      // F(6x6, 5x5): 10 x 10 tile, one channel per thread (100 products per 36 outputs)
+        const long total = (long)a.N * a.ty * a.tx * a.C;
+        hipLaunchKernelGGL((hvn_wino_out<6, 5, 1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
     } else
         return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;

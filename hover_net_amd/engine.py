@@ -247,6 +247,8 @@ class Engine:
             key = (op.kh, op.kw, op.stride, op.x.c, op.cout, op.y.h, op.y.w, op.x.h, op.x.w, op.res is not None, op.pre is not None,
                    op.post is not None, int(op.extra.get("nbatch", 1)), x2.c if x2 is not None else 0)
             # 128-channel-wide plans: 128 x 128 or 128 x 64 tiles; 64-wide ones: 128 x 64 or 256 x 64 (tile_n 320 = 64 | 0x100)
+            if op.tile_n == 64 and x2 is not None:
+                continue                                   # the fused-shortcut instantiations exist for 128 x 128 and 128 x 64 tiles only
             cands = (128, 64) if op.tile_n == 128 else (64, 320)
             if key not in self.tile_choice:
                 o = self.ops[i]

@@ -235,7 +235,7 @@ class Plan:
         from . import winograd as WG
 
         cout, cin, kh, kw = wt.shape
-        assert kh == kw and (kh, m) in ((5, 2), (5, 4), (3, 4)) and x.c == cin and y.c == cout
+        assert kh == kw and (kh, m) in ((5, 2), (5, 4), (5, 6), (3, 4), (3, 6)) and x.c == cin and y.c == cout
         r = kh
         assert y.h == x.h + pad[0] + pad[1] - (r - 1)
         at, _g, bt = WG.mats(m, r)
@@ -349,7 +349,8 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     if winograd is None:
         winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
     wino_m = 4 if winograd is True else int(winograd)
-    wino3 = int(os.environ.get("HVN_WINOGRAD3", "128"))      # minimum channel count for F(4x4,3x3) in the encoder; 0 = off
+    wino3 = int(os.environ.get("HVN_WINOGRAD3", "128"))      # minimum channel count for the Winograd form of the encoder's 3x3 convs; 0 = off
+    wino3_m = int(os.environ.get("HVN_WINOGRAD3_M", "4"))     # its output tile: F(4x4,3x3) or F(6x6,3x3)
     P = Plan(mode, nr_types)
     g = P.geo
     k = g["k"]
@@ -383,7 +384,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
             if st == 1 and winograd and wino3 and c1 >= wino3:
                 # stride-1 3x3 with K >= 128 (d1, d2, d3): Winograd F(4x4,3x3), 2.25 instead of 9 multiplies per output;
                 # below that the transform-domain tensors make the layer HBM-bound (d0: K = 64); measured 453 (off) / 484 (K >= 256) / 497 (K >= 128) tiles/s
-                P.conv_winograd(p + "conv2", t1, t2, W(p + "conv2.weight"), pad=_tf_same(t1.h, 3, 1), bn=BN(p + "conv2/bn"), relu=1, m=4)
+                P.conv_winograd(p + "conv2", t1, t2, W(p + "conv2.weight"), pad=_tf_same(t1.h, 3, 1), bn=BN(p + "conv2/bn"), relu=1, m=wino3_m)
             else:
                 P.conv(p + "conv2", t1, t2, W(p + "conv2.weight"), stride=st, pad=_tf_same(t1.h, 3, st),
                        bn=BN(p + "conv2/bn"), relu=1)
@@ -422,7 +423,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
                 # the u3 input is the same for every branch: its transform runs once, before the branch lanes fork
                 # (5x5: F(wino_m, 5); the 'fast' mode's 3x3: F(4, 3))
                 P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"),
-                                m=wino_m if k == 5 else 4)
+                                m=wino_m if k == 5 else wino3_m)
             else:
                 P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
             c = cmid
@@ -443,7 +444,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         u1 = View(P.buf(pb + "u1", g["out"], g["out"], 64))
         if winograd and (k == 5 or wino3):
             P.conv_winograd(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
-                            bn=BN(pb + "u0.bn"), relu=1, m=wino_m if k == 5 else 4)
+                            bn=BN(pb + "u0.bn"), relu=1, m=wino_m if k == 5 else wino3_m)
         else:
             P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
                    bn=BN(pb + "u0.bn"), relu=1)

@@ -146,11 +146,11 @@ def test_conv1x1_fused_shortcut_second_input(stride2, cin2, cout):
     _check(got, want)
 
 
-@pytest.mark.parametrize("m,k", [(2, 5), (4, 5), (4, 3)])
+@pytest.mark.parametrize("m,k", [(2, 5), (4, 5), (4, 3), (6, 3), (6, 5)])
 @pytest.mark.parametrize("cin,cout,s,pad,bn", [(64, 128, 14, (0, 0), False), (256, 64, 12, (2, 2), True), (1024, 256, 10, (0, 0), False),
                                                (64, 32, 17, (0, 0), True), (512, 512, 33, (1, 1), True)])
 def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn, m, k):
-    """WINO_IN -> batched GEMM -> WINO_OUT (F(m x m, k x k): F(2,5), F(4,5), F(4,3)) against a direct fp32
+    """WINO_IN -> batched GEMM -> WINO_OUT (F(m x m, k x k): F(2,5), F(4,5), F(4,3), F(6,3), F(6,5)) against a direct fp32
     convolution, writing into a channel window of a wider buffer like the dense-block concat; output extents that
     are not a multiple of m exercise the partial last tile."""
     import plan_interp
@@ -182,13 +182,14 @@ def test_winograd_5x5_matches_direct(cin, cout, s, pad, bn, m, k):
     if bn:
         want = F.relu(want * torch.from_numpy(kw["bn"][0]).float() + torch.from_numpy(kw["bn"][1]).float())
     got = eng.buffer(PL.View(ybuf), n).cpu()
-    _check(got[..., 32:], want, tol=5e-4)
+    # F(6x6, 5x5) (optional, HVN_WINOGRAD=6): ten interpolation points, ~15x the fp32 error of F(4x4, 5x5) (hover_net_amd/winograd.py)
+    _check(got[..., 32:], want, tol=4e-3 if (m, k) == (6, 5) else 5e-4)
     assert torch.equal(got[..., :32], before[..., :32])      # the neighbouring channels are untouched
     # and the interpreter's transform-domain tensors agree stage by stage
     A = plan_interp.Arena(P, n)
     A.view(x).copy_(xin)
     v = plan_interp.wino_in_ref(P.ops[0], A.view(x).clone())
-    _check(eng.buffer(P.ops[0].y, n).cpu().reshape(v.shape), v, tol=1e-4)
+    _check(eng.buffer(P.ops[0].y, n).cpu().reshape(v.shape), v, tol=2e-3 if (m, k) == (6, 5) else 1e-4)
 
 
 @pytest.mark.parametrize("k,pad,pre", [(3, (1, 1), False), (1, (0, 0), True), (5, (2, 2), False)])
