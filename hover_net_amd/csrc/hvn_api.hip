@@ -230,6 +230,13 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.N = batch; a.H = in ? op->x.h : op->y.h; a.W = in ? op->x.w : op->y.w; a.C = in ? op->x.c : op->y.c;
         a.ty = op->kh; a.tx = op->kw; a.pad = op->pad_t; a.relu = op->relu;
         a.accum = (!in && op->res.base != nullptr) ? 1 : 0;
+        a.lo = nullptr; a.lsn = a.lsy = a.lsx = 0;
+        if (in && op->res.base) {       // WINO_IN with res: the input is nearest2x(res) + x, formed on the fly (UPADD fused into the transform)
+            a.lo = (const float *)op->res.base;
+            a.lsn = op->res.sn; a.lsy = op->res.sy; a.lsx = op->res.sx;
+            if (op->res.h * 2 != op->x.h || op->res.w * 2 != op->x.w || op->res.c != op->x.c || !aligned16(a.lo) || ((a.lsn | a.lsy | a.lsx) & 3))
+                return fail(HVN_E_ARG, "wino_in: the half-resolution input must be x.h/2 x x.w/2 x x.c and 16-byte aligned%s", "");
+        }
         if (a.accum && op->res.base != op->y.base) return fail(HVN_E_ARG, "wino_out: res must alias y (accumulate in place)%s", "");
         const int n2 = in ? op->y.h : op->x.h;       // transform positions (m + r - 1)^2
         if (op->stride > 1 && op->_rsv > 1) {         // explicit F(m x m, r x r): stride = m, _rsv = r

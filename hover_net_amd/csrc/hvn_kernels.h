@@ -125,6 +125,8 @@ struct WinoArgs {
     int m;                // output tile edge: 2 or 4
     int r;                // filter edge: 5 or 3 (n = m + r - 1)
     int accum;            // WINO_OUT: y += result (data gradients accumulate)
+    const float *lo;      // WINO_IN, optional: the input is nearest2x(lo) + x (net_utils.py:284-294 UpSample2x + the skip add), formed on
+    long lsn, lsy, lsx;   // the fly: lo is the half-resolution view, x the full-resolution skip; nullptr = plain input
 };
 int hvn_launch_wino_in(const WinoArgs &a, hipStream_t stream);
 int hvn_launch_wino_out(const WinoArgs &a, hipStream_t stream);

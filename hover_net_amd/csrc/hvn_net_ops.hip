@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
 #pragma unroll
     for (int k = 0; k < NW * NW; ++k) bt[k] = p.mat[k];  // wave-uniform -> scalar loads
     const float *src = p.x + (long)n * p.xsn + cv * VW;
+    const float *lo = p.lo ? p.lo + (long)n * p.lsn + cv * VW : nullptr;      // fused UpSample2x + skip add: input = lo[y/2][x/2] + x[y][x]
     // tmp[a][j] = sum_i BT[a][i] d[i][j], column by column
     VT tmp[NW][NW];
 #pragma unroll
@@ -356,9 +357,10 @@ __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
 #pragma unroll
         for (int r = 0; r < NW; ++r) {
             const int yy = y0 + r, xx = x0 + j;
-            d[r] = ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                       ? *(const VT *)(src + (long)yy * p.xsy + (long)xx * p.xsx)
-                       : (VT)(0.f);
+            const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            VT v = in ? *(const VT *)(src + (long)yy * p.xsy + (long)xx * p.xsx) : (VT)(0.f);
+            if (lo && in) v = *(const VT *)(lo + (long)(yy >> 1) * p.lsy + (long)(xx >> 1) * p.lsx) + v;      // the sum hvn_upadd forms: same bits
+            d[r] = v;
         }
 #pragma unroll
         for (int a = 0; a < NW; ++a) {

@@ -314,6 +314,30 @@ class Plan:
         self.ops = out
         self.reindex()
 
+    def fuse_upadd_into_winograd(self):
+        """An UPADD (UpSample2x + skip add, net_utils.py:284-294 / net_desc.py:133-143) whose output is read ONLY by Winograd input
+        transforms disappears into them: WINO_IN then forms nearest2x(lo) + skip on the fly (`res` = the half-resolution view, `x` =
+        the skip) -- the up-sampled tensor is never written or re-read and one launch per decoder stage goes away.  The sum is the one
+        `hvn_upadd` forms, so the transform-domain tensor has the same bits."""
+        users = {}
+        for op in self.ops:
+            for v in (op.x, op.res, op.extra.get("x2")):
+                if v is not None:
+                    users.setdefault(id(v.buf), []).append(op)
+        keep = []
+        for op in self.ops:
+            if op.kind == OP_UPADD:
+                readers = users.get(id(op.y.buf), [])
+                whole = lambda v: (v.y0, v.x0, v.h, v.w, v.c0, v.c) == (0, 0, op.y.buf.h, op.y.buf.w, 0, op.y.buf.c)   # noqa: E731
+                if readers and all(r.kind == OP_WINO_IN and r.res is None and r.x.buf is op.y.buf and whole(r.x) for r in readers) and whole(op.y):
+                    for r in readers:
+                        r.x, r.res = op.res, op.x            # x = the skip (full resolution), res = the tensor to up-sample
+                        r.extra["upadd"] = op.name
+                    continue
+            keep.append(op)
+        self.ops = keep
+        self.reindex()
+
     # -- memory planning --------------------------------------------------------
     def pack(self, align=64):
         """Greedy interval packing of the per-sample activation arena (floats)."""
@@ -460,6 +484,11 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         P.add(Op(OP_PREDMAP, "infer_step.epilogue", y=View(pm), extra={"branches": list(arch.branch_names(nr_types))}))
     if chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
+    if os.environ.get("HVN_FUSE_UPADD", "0") != "0":
+        # measured (profiles/r03_upadd_fusion_ab.txt): parity-green and bit-equal, one launch and one tensor less per decoder stage, but
+        # SLOWER -- the transform (64 register-resident tile values per thread) pays more for the second, quarter-rate address stream
+        # than the up-sampled tensor's write + re-read cost: 61.15 vs 60.54 ms per step.  Off by default.
+        P.fuse_upadd_into_winograd()
     # launch lanes: the decoder branches are independent between the shared u3 input and the
     # epilogue, so the engine may run them on concurrent streams (small dense-unit launches of one
     # branch then fill the chip together with the others')

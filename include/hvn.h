@@ -61,6 +61,8 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           (net_desc.py:45,52,59 conva), F(4,3) for the encoder's 3x3 convs (net_utils.py:186-196), n = m + r - 1:
  *           x = input view (zero padding pad_t/pad_l), y = V as [n*n][tiles][c] per sample (y.w = tiles),
  *           kh x kw = tile grid, w = B^T (n x n), stride = m, _rsv = r (both 0: r = 5 and m from y.h = 36 | 64),
+ *           res (optional): a half-resolution view; the transformed input is then nearest2x(res) + x, i.e. the UpSample2x + skip add
+ *           of net_utils.py:284-294 / net_desc.py:133-143 formed on the fly (x = the skip), bit-identical to UPADD followed by WINO_IN,
  *   WINO_OUT y = A^T M A (+bias)(relu): x = M as [n*n][tiles][cout] per sample, w = A^T (m x n), kh x kw = tile grid
  *           covering y (a partial last tile's surplus outputs are dropped); res = y: accumulate (y += ...),
  *   CHAIN   two chained 1x1 convs of a residual block (net_utils.py:250-266) in one launch, the second running on the first's

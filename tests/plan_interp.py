@@ -154,7 +154,10 @@ def run(plan, imgs_u8, taps=None):
             if op.kind == PL.OP_CONV0:
                 A.view(op.y).copy_(conv0_ref(op, imgs_u8))
             elif op.kind == PL.OP_WINO_IN:
-                A.view(op.y).copy_(wino_in_ref(op, A.view(op.x).clone()))
+                xin = A.view(op.x).clone()
+                if op.res is not None:            # UPADD fused into the transform: input = nearest2x(res) + x
+                    xin = upadd_ref(A.view(op.res), xin)
+                A.view(op.y).copy_(wino_in_ref(op, xin))
             elif op.kind == PL.OP_CONV and op.extra.get("nbatch"):
                 A.tensor(op.y.buf).copy_(wino_gemm_ref(op, A.tensor(op.x.buf).clone()))
             elif op.kind == PL.OP_WINO_OUT:

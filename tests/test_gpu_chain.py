@@ -121,3 +121,26 @@ def test_network_with_and_without_chains_is_bit_equal(monkeypatch):
         outs.append({k: v.clone() for k, v in logits.items()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_network_with_and_without_upadd_fusion_is_bit_equal(monkeypatch):
+    """UPADD fused into the Winograd input transform (Plan.fuse_upadd_into_winograd, HVN_FUSE_UPADD=1 -- measured slower, so not the
+    default: nearest2x(lo) + skip formed on the fly) gives the bits of the separate UPADD launch followed by WINO_IN, in both decoder
+    geometries."""
+    from hover_net_amd import net_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+
+    for mode, nt, size in (("original", 5, 270), ("fast", None, 256)):
+        tiles = torch.from_numpy(synth_tiles(2, size, seed=4)).cuda()
+        outs = []
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("HVN_FUSE_UPADD", fuse)
+            net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
+            net.load_state_dict(synth_state_dict(mode, nt, seed=2), strict=True)
+            net = net.cuda().eval()
+            eng = net.engine(2)
+            assert any(o.kind == PL.OP_UPADD for o in eng.plan.ops) == (fuse == "0")
+            logits, _ = eng.run(tiles)
+            outs.append({k: v.clone() for k, v in logits.items()})
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (mode, k)
