@@ -21,6 +21,12 @@ extern "C" {
 
 int hvn_version(void) { return 102; }   // 1.02: + CHAIN op (two chained 1x1 convs), hvn_op grew y2 / w2 / bias2 / cout2
 
+#ifndef HVN_BUILD_ID
+#define HVN_BUILD_ID "unstamped"
+#endif
+static const char hvn_build_tag[] = "hvn-build-id:" HVN_BUILD_ID;     // findable in the file's bytes without loading it
+const char *hvn_build_id(void) { return hvn_build_tag + 13; }   // hash of the sources this binary was compiled from (hover_net_amd/lib.py:source_id)
+
 const char *hvn_last_error(void) { return g_err; }
 
 int hvn_device_ok(void)

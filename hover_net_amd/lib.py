@@ -56,7 +56,7 @@ class hvn_inst_rec(ctypes.Structure):
 
 
 EXPORTS = (
-    "hvn_version", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
+    "hvn_version", "hvn_build_id", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_profile_conv_ms_list", "hvn_postproc_workspace_bytes", "hvn_postproc",
     "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
     "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
@@ -69,31 +69,57 @@ class HvnError(RuntimeError):
     pass
 
 
-def build(verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU (seconds)."""
+def source_id():
+    """16 hex digits over every source the library is built from (kernels, headers, flags).  Compiled into the library
+    (`hvn_build_id()`), so that a binary which does not match the sources next to it is detected at LOAD time -- the `.so` files are
+    git-ignored yet travel to the GPU box, and a stale one would otherwise pass for the current kernels."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + ["hvn_kernels.h"]:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "hvn.h"), "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def _built_id(path):
+    """The id compiled into an existing library (read from the file's bytes: dlopen would pin the old mapping in this process)."""
+    if not os.path.exists(path):
+        return None
+    data = open(path, "rb").read()
+    i = data.find(b"hvn-build-id:")
+    if i < 0:
+        return None
+    j = data.find(b"\0", i)
+    return data[i + 13:j].decode(errors="replace")
+
+
+def _compile(out, extra, verbose):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "hvn_kernels.h"), os.path.join(os.path.dirname(_HERE), "include", "hvn.h")]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    cmd = ["hipcc", *HIPCC_FLAGS, *srcs, "-o", LIB_PATH]
+    sid = source_id() + ("" if not extra else "+" + "".join(extra))
+    cmd = ["hipcc", *HIPCC_FLAGS, *extra, '-DHVN_BUILD_ID="%s"' % sid, *srcs, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
+
+
+def build(verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU (under a minute).  Rebuilds whenever the id compiled into the existing
+    library differs from the id of the sources (not by mtime)."""
+    if _built_id(LIB_PATH) == source_id():
+        return LIB_PATH
+    return _compile(LIB_PATH, (), verbose)
 
 
 def build_variant(name, verbose=False):
     """`libhvn_hip_<name>.so`: the library compiled with VARIANTS[name]'s extra flags."""
     out = os.path.join(_HERE, "libhvn_hip_%s.so" % name)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "hvn_kernels.h"), os.path.join(os.path.dirname(_HERE), "include", "hvn.h")]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    if _built_id(out) == source_id() + "+" + "".join(VARIANTS[name]):
         return out
-    cmd = ["hipcc", *HIPCC_FLAGS, *VARIANTS[name], *srcs, "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return out
+    return _compile(out, tuple(VARIANTS[name]), verbose)
 
 
 def lib_path():
@@ -117,6 +143,11 @@ def lib():
             raise HvnError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the HoVer-Net hot path)" % os.path.basename(path))
         L = ctypes.CDLL(path)
+        L.hvn_build_id.restype = ctypes.c_char_p
+        built = L.hvn_build_id().decode()
+        if os.path.isdir(CSRC) and not os.environ.get("HVN_LIB_VARIANT") and built != source_id():
+            raise HvnError("%s was built from other sources (library %s, sources %s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % (os.path.basename(path), built, source_id()))
         L.hvn_last_error.restype = ctypes.c_char_p
         L.hvn_profile_conv_ms.restype = ctypes.c_double
         L.hvn_profile_conv_ms_list.argtypes = [ctypes.c_void_p, ctypes.c_int]

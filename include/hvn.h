@@ -96,6 +96,7 @@ typedef struct hvn_op {
 
 /* -- library ---------------------------------------------------------------------- */
 HVN_API int         hvn_version(void);
+HVN_API const char *hvn_build_id(void);   /* id of the sources the binary was compiled from; the Python binding refuses a stale library */
 HVN_API const char *hvn_last_error(void);
 HVN_API int         hvn_device_ok(void);  /* 1 if a gfx950 device is current */
 
