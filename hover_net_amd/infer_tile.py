@@ -123,6 +123,19 @@ def _dist():
     return None, 0, 1
 
 
+def a2a_single(recv, send, out_splits, in_splits):
+    """`dist.all_to_all_single` with uneven splits.  RCCL takes the device tensors as they are; under gloo (the CPU tests, and the
+    2-ranks-on-one-GPU test that runs the REAL kernels with only the transport substituted) device tensors are staged through the
+    host."""
+    dist, _rank, _world = _dist()
+    if send.is_cuda and dist.get_backend() != "nccl":
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu(), out_splits, in_splits)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, out_splits, in_splits)
+
+
 def agree_min(value, device=None):
     """The minimum of an integer over the ranks (all_reduce MIN): every rank then takes the same decision from it, e.g. the RAM
     budget that cuts a file list into caching rounds -- ranks that cut differently would run mismatched collectives."""
@@ -175,7 +188,7 @@ def route_to_owners(local, n_items, owner):
     send = local[torch.as_tensor(order, device=local.device)].contiguous() if len(order) else local[:0].contiguous()
     recv = torch.empty((sum(out_splits),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     row = int(np.prod(local.shape[1:], dtype=np.int64))
-    dist.all_to_all_single(recv.view(-1), send.view(-1), [c * row for c in out_splits], [c * row for c in in_splits])
+    a2a_single(recv.view(-1), send.view(-1), [c * row for c in out_splits], [c * row for c in in_splits])
     return mine_idx, recv
 
 
@@ -194,10 +207,13 @@ def gather_to_rank0(tensors, dst=0):
             out.append(None)
             continue
         t = t.contiguous()
+        dev = t.device
+        if t.is_cuda and dist.get_backend() != "nccl":      # gloo: staged through the host (see a2a_single)
+            t = t.cpu()
         if rank == dst:
             full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             dist.gather(t, list(full.chunk(world, 0)), dst=dst)
-            out.append(full)
+            out.append(full.to(dev))
         else:
             dist.gather(t, None, dst=dst)
     return tuple(out) if rank == dst else None

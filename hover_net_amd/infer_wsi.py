@@ -213,7 +213,7 @@ def exchange_halo(local, need, bounds):
     parts = [local.t[lo - local.row0:hi - local.row0].reshape(-1) for lo, hi in send_blocks if hi > lo]
     send = torch.cat(parts) if parts else local.t.new_zeros(0)
     recv = local.t.new_empty(sum(hi - lo for lo, hi in recv_blocks) * row)
-    dist.all_to_all_single(recv, send, [(hi - lo) * row for lo, hi in recv_blocks], [(hi - lo) * row for lo, hi in send_blocks])
+    infer_tile.a2a_single(recv, send, [(hi - lo) * row for lo, hi in recv_blocks], [(hi - lo) * row for lo, hi in send_blocks])
     off = 0
     for lo, hi in recv_blocks:
         if hi > lo:

@@ -1,0 +1,79 @@
+"""GPU: the multi-rank tile and whole-slide paths with the REAL kernels -- two processes (one rank each) share the box's single GPU and talk
+over gloo, so everything but the transport is what an 8-GPU RCCL run executes: row-slab ownership of the prediction map, the halo
+exchange, tile ownership by rows, per-patch maps routed to the stitching owner, the fan-in to rank 0, the on-device merge with uploaded
+remote tiles.  Rank 0's results must equal the single-process run bit for bit.  (RCCL itself cannot run here: one GPU per box.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _net():
+    from hover_net_amd import net_desc
+    from hover_net_amd.synth import synth_state_dict
+
+    net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
+    net.load_state_dict(synth_state_dict("original", 5, seed=81), strict=True)
+    sd = net.state_dict()
+    sd["decoder.np.u0.conv.bias"] = torch.tensor([-0.4, 0.4])       # random-init output near the nucleus threshold: blobs to separate
+    net.load_state_dict(sd, strict=True)
+    return net.to("cuda").eval()
+
+
+def _slide():
+    from hover_net_amd import infer_wsi
+
+    rng = np.random.default_rng(82)
+    return infer_wsi.ArraySlide(rng.integers(0, 256, (1150, 1010, 3), dtype=np.uint8))
+
+
+def _images():
+    rng = np.random.default_rng(7)
+    return [rng.integers(0, 256, s, dtype=np.uint8) for s in ((300, 283, 3), (270, 270, 3), (401, 333, 3))]
+
+
+def _work():
+    from hover_net_amd import infer_tile, infer_wsi
+
+    net = _net()
+    wsi = infer_wsi.WsiInference(net, nr_types=5, batch_size=16, chunk_shape=700, tile_shape=512, ambiguous_size=64)
+    inst, info = wsi.run(_slide(), mask=None)
+    tiles = infer_tile.process_images(_images(), net, nr_types=5, batch_size=8)
+    return (inst, None if info is None else sorted(info), wsi.map_rows_resident,
+            [None if t is None else (t[0], sorted(t[1])) for t in tiles])
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _work()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    inst1, keys1, rows1, tiles1 = _work()                           # the same work in this process, one rank
+    inst0, keys0, rows0, tiles0 = out[0]
+    assert out[1][0] is None and out[1][1] is None                  # results live on rank 0
+    assert np.array_equal(inst0, inst1) and keys0 == keys1 and len(keys1) > 20
+    assert rows0 < inst1.shape[0] and out[1][2] < inst1.shape[0] and rows1 == inst1.shape[0]      # each rank held slab + halo only
+    for a, b in zip(tiles0, tiles1):                                # tile path: every image complete on rank 0
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
