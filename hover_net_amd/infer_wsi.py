@@ -347,6 +347,7 @@ class DeviceMerger:
         self.cap = 1 << 20
         self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
         self.epoch = 0
+        self._max_map_id = 0                 # largest id ever written to the map (ids without a dict entry included)
         self.removed_cap = 1 << 16
         self.removed = torch.zeros(self.removed_cap, dtype=torch.int32, device=self.device)
         self.counters = torch.zeros(4, dtype=torch.int32, device=self.device)
@@ -367,10 +368,11 @@ class DeviceMerger:
             return pred_inst.contiguous()
         return torch.from_numpy(np.ascontiguousarray(pred_inst, np.int32)).to(self.device, non_blocking=True)
 
-    def normal(self, pred_inst, info, tile_tl, tile_br, ready=None):
+    def normal(self, pred_inst, info, tile_tl, tile_br, ready=None, n_local=None):
         if len(info) == 0:
             return
         off = self._max_id()
+        self._max_map_id = max(self._max_map_id, off + int(max(n_local or 0, max(info))))
         for i, e in info.items():
             self._insert(i + off, e)
         with torch.cuda.stream(self.stream):
@@ -387,9 +389,10 @@ class DeviceMerger:
         if n_local is None:                                      # the tile's largest label: new ids WITHOUT a dict entry are written / dropped too
             n_local = int(pred_inst.max())
         n_local = int(max(n_local, max(info)))
-        if off + 1 >= self.cap:                                  # the id tables index every id in the map
-            self.cap = max(2 * self.cap, off + 2)
+        if self._max_map_id + 1 >= self.cap:                     # the id tables index every id in the map (also ids without a dict entry)
+            self.cap = max(2 * self.cap, self._max_map_id + 2)
             self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
+        self._max_map_id = max(self._max_map_id, off + n_local)
         if n_local + 1 > self.touching.shape[0]:
             self.touching = torch.zeros(2 * (n_local + 1), dtype=torch.uint8, device=self.device)
             self._h_touching = torch.zeros(2 * (n_local + 1), dtype=torch.uint8, pin_memory=True)
@@ -684,7 +687,7 @@ class WsiInference:
                     dev, ready, n_local = self._dev_results.pop(i, (None, None, None))
                     src = inst_h if dev is None else dev           # remote ranks' tiles arrive as host arrays and are uploaded
                     if phase == 0:
-                        merger.normal(src, info, tiles[i][0], tiles[i][1], ready=ready)
+                        merger.normal(src, info, tiles[i][0], tiles[i][1], ready=ready, n_local=int(inst_h.max()) if n_local is None else n_local)
                     else:
                         merger.fixing(src, info, tiles[i][0], tiles[i][1], ready=ready, n_local=int(inst_h.max()) if n_local is None else n_local)
                 else:
