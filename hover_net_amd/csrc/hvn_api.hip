@@ -201,6 +201,7 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.y2sn = op->y2.sn; a.y2sy = op->y2.sy; a.y2sx = op->y2.sx; a.N2 = op->cout2;
         a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w;
         a.M = (long)batch * a.Ho * a.Wo;
+        a.bm = op->tile_n == 64 ? 64 : 128;      // CHAIN: tile_n = pixels per workgroup (0 / 128: 128)
         if (op->act_dtype != 0) return fail(HVN_E_ARG, "chain: fp32 only%s", "");
         if (!a.x || !a.w1 || !a.y || !a.w2 || !a.y2) return fail(HVN_E_ARG, "chain: null pointer%s", "");
         if (op->kh != 1 || op->kw != 1 || op->stride != 1 || op->pad_t || op->pad_l || op->relu || op->bias)

@@ -48,25 +48,33 @@ static __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 
-template <int N2, bool HAS_X2>
-__global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
+// BM = pixels per workgroup: 128 (two workgroups per CU) or 64 (W1' staged one k-step at a time: 40 / 48 KB of LDS, <= 168 VGPRs, three
+// workgroups per CU -- for the seams that are bound by exposed load latency rather than by bytes; chosen per launch by the engine's
+// timing pass, `tile_n` of the op).  Every output element is summed in the same order for both.
+template <int BM, int N2, bool HAS_X2>
+__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void hvn_conv_chain_f32(const ChainArgs p)
 {
-    constexpr int PA = CH_BM / 32, PB = CH_BN / 32, PB2 = N2 / 32;
-    constexpr int WAVES_N2 = N2 >= 128 ? 2 : 1, WAVES_M2 = 4 / WAVES_N2;
-    constexpr int WM2 = CH_BM / WAVES_M2, WN2 = N2 / WAVES_N2;
+    constexpr int PA = BM / 32, PB = CH_BN / 32, PB2 = N2 / 32;
+    constexpr int W1M = BM / 32 >= 4 ? 4 : BM / 32, W1N = 4 / W1M;          // GEMM1: waves over pixels x the chunk's 64 channels
+    constexpr int TN1 = CH_BN / W1N / 32;
+    constexpr int WM2_MAX = N2 >= 128 ? 2 : 4;
+    constexpr int WAVES_M2 = BM / 32 < WM2_MAX ? BM / 32 : WM2_MAX, WAVES_N2 = 4 / WAVES_M2;
+    constexpr int WM2 = BM / WAVES_M2, WN2 = N2 / WAVES_N2;
     constexpr int TM2 = WM2 / 32, TN2 = WN2 / 32;
+    constexpr bool B2ONE = BM == 64;                                       // W1' chunk: one k-step of 32 in LDS at a time
     constexpr unsigned OOB = 0x80000000u;
+    static_assert(W1M * W1N == 4 && TN1 >= 1 && TM2 >= 1 && TN2 >= 1, "256 threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                              // [2][128][32]
-    float *Bs = smem + 2 * CH_BM * 32;             // [2][64][32]
-    float *ep = smem;                              // [128][68], aliases As / Bs
-    float *B2s = smem + 2 * (CH_BM + CH_BN) * 32;  // [2][N2][32]
+    float *As = smem;                              // [2][BM][32]
+    float *Bs = smem + 2 * BM * 32;                // [2][64][32]
+    float *ep = smem;                              // [BM][68], aliases As / Bs
+    float *B2s = smem + 2 * (BM + CH_BN) * 32;     // [2 | 1][N2][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const unsigned M = (unsigned)p.M;
-    const unsigned m0 = blockIdx.x * (unsigned)CH_BM;
+    const unsigned m0 = blockIdx.x * (unsigned)BM;
     const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
     const unsigned n_blk = m0 / HoWo;
 
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
     // ---- epilogue coordinates: thread = (16-byte column piece, rows erow0 + 16 it) -------------------------------------
     const int ecol = (tid & 15) * 4;
     const int erow0 = tid >> 4;
-    constexpr int NIT = CH_BM / 16;
+    constexpr int NIT = BM / 16;
     unsigned y_voff[NIT];      // the residual view has the output's strides (validated by the launcher): same offsets, other base
     const bool has_res = p.res != nullptr;
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         for (int j = 0; j < PB; ++j) st.rb[j] = buf_load(rsrc_w1, w_voff[j], w_soff);
     };
     auto store1 = [&](int buf) {
-        float *a = As + buf * CH_BM * 32;
+        float *a = As + buf * BM * 32;
         float *b = Bs + buf * CH_BN * 32;
 #pragma unroll
         for (int j = 0; j < PA; ++j) *(f32x4 *)(a + (srow + 32 * j) * 32 + lcol) = st.ra[j];
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         for (int j = 0; j < PB; ++j) *(f32x4 *)(b + (srow + 32 * j) * 32 + lcol) = st.rb[j];
     };
 
-    f32x16 acc1[2];
+    f32x16 acc1[TN1];
     f32x16 acc2[TM2][TN2];
 #pragma unroll
     for (int i = 0; i < TM2; ++i)
@@ -161,19 +169,20 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
     const int key = (l31 >> 1) & 7;
     const int wm2 = wave / WAVES_N2, wn2 = wave % WAVES_N2;
+    const int w1m = wave / W1N, w1n = wave % W1N;
 
-    auto mma1 = [&](int buf) {          // wave = 32 pixels x 64 channels of the chunk
-        const float *a = As + buf * CH_BM * 32 + (wave * 32 + l31) * 32;
-        const float *b = Bs + buf * CH_BN * 32 + l31 * 32;
+    auto mma1 = [&](int buf) {          // wave = 32 pixels x (64 / W1N) channels of the chunk
+        const float *a = As + buf * BM * 32 + (w1m * 32 + l31) * 32;
+        const float *b = Bs + buf * CH_BN * 32 + (w1n * TN1 * 32 + l31) * 32;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int off = ((2 * q + lh) ^ key) * 4;
             const f32x4 fa = *(const f32x4 *)(a + off);
-            f32x4 fb[2];
+            f32x4 fb[TN1];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * 32 + off);
+            for (int j = 0; j < TN1; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * 32 + off);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN1; ++j) {
                 acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc1[j], 0, 0, 0);
                 acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc1[j], 0, 0, 0);
                 acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc1[j], 0, 0, 0);
@@ -181,29 +190,26 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
             }
         }
     };
-    auto mma2 = [&]() {                 // A = the activated chunk in the epilogue tile, B = W1' chunk: two k-steps of 32
+    auto mma2 = [&](int ks) {           // A = the activated chunk in the epilogue tile, B = W1' chunk: k-step ks (32 channels) of two
         const float *a = ep + (wm2 * WM2 + l31) * CH_EP;
+        const float *b = B2s + (B2ONE ? 0 : ks) * N2 * 32 + (wn2 * WN2 + l31) * 32;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const float *b = B2s + ks * N2 * 32 + (wn2 * WN2 + l31) * 32;
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa[TM2], fb[TN2];
+            const int off = ((2 * q + lh) ^ key) * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 fa[TM2], fb[TN2];
-                const int off = ((2 * q + lh) ^ key) * 4;
+            for (int i = 0; i < TM2; ++i) fa[i] = *(const f32x4 *)(a + i * 32 * CH_EP + ks * 32 + q * 8 + 4 * lh);
 #pragma unroll
-                for (int i = 0; i < TM2; ++i) fa[i] = *(const f32x4 *)(a + i * 32 * CH_EP + ks * 32 + q * 8 + 4 * lh);
+            for (int j = 0; j < TN2; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * 32 + off);
 #pragma unroll
-                for (int j = 0; j < TN2; ++j) fb[j] = *(const f32x4 *)(b + j * 32 * 32 + off);
+            for (int i = 0; i < TM2; ++i)
 #pragma unroll
-                for (int i = 0; i < TM2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN2; ++j) {
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc2[i][j], 0, 0, 0);
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc2[i][j], 0, 0, 0);
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc2[i][j], 0, 0, 0);
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc2[i][j], 0, 0, 0);
-                    }
-            }
+                for (int j = 0; j < TN2; ++j) {
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc2[i][j], 0, 0, 0);
+                }
         }
     };
 
@@ -219,30 +225,28 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         // for it also drains the previous chunk's y stores (one vmcnt for loads and stores), which have had all of GEMM2 to
         // retire -- nothing else may be in flight yet or the wait would include it.
         store1(0);
-        {
-            // W1' chunk (both k-steps of 32): loaded under the first GEMM1 step, parked in its own LDS region (free since the
-            // barrier behind the previous GEMM2) right after it
-            f32x4 rb2[2][PB2];
+        // W1' chunk (both k-steps of 32): loaded under the first GEMM1 step, parked in its own LDS region (free since the barrier
+        // behind the previous GEMM2) right after it; with one k-step of LDS (BM = 64) the second stays in registers until GEMM2
+        f32x4 rb2[2][PB2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < PB2; ++j) rb2[ks][j] = buf_load(rsrc_w2, w2_voff[j], ((2 * c + ks) * 32) * 4);
-            __syncthreads();
-            CH_STAMP(2);
+            for (int j = 0; j < PB2; ++j) rb2[ks][j] = buf_load(rsrc_w2, w2_voff[j], ((2 * c + ks) * 32) * 4);
+        __syncthreads();
+        CH_STAMP(2);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN1; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-            // first k-step (KT >= 2: validated by the launcher)
-            load1(c, 1);
-            mma1(0);
+            for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+        // first k-step (KT >= 2: validated by the launcher)
+        load1(c, 1);
+        mma1(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < (B2ONE ? 1 : 2); ++ks)
 #pragma unroll
-                for (int j = 0; j < PB2; ++j) *(f32x4 *)(B2s + ks * N2 * 32 + (srow + 32 * j) * 32 + lcol) = rb2[ks][j];
-            store1(1);
-            __syncthreads();
-        }
+            for (int j = 0; j < PB2; ++j) *(f32x4 *)(B2s + ks * N2 * 32 + (srow + 32 * j) * 32 + lcol) = rb2[ks][j];
+        store1(1);
+        __syncthreads();
         for (int kt = 1; kt + 1 < KT; ++kt) {
             load1(c, kt + 1);
             mma1(kt & 1);
@@ -259,11 +263,11 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         CH_STAMP(3);
         __syncthreads();               // every wave is done reading the staging buffers: the tile may overwrite them
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN1; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                ep[row * CH_EP + j * 32 + l31] = acc1[j][r];
+                const int row = w1m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ep[row * CH_EP + (w1n * TN1 + j) * 32 + l31] = acc1[j][r];
             }
         __syncthreads();
         CH_STAMP(4);
@@ -307,7 +311,14 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
         CH_STAMP(5);
         __syncthreads();
         CH_STAMP(6);
-        mma2();
+        mma2(0);
+        if constexpr (B2ONE) {
+            __syncthreads();           // every wave is done with k-step 0 of W1': its LDS tile takes k-step 1
+#pragma unroll
+            for (int j = 0; j < PB2; ++j) *(f32x4 *)(B2s + (srow + 32 * j) * 32 + lcol) = rb2[1][j];
+            __syncthreads();
+        }
+        mma2(1);
         CH_STAMP(7);
         __syncthreads();               // tile and W1' chunk are free again
     }
@@ -329,19 +340,18 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
     const float relu_lo = p.relu2 ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int h = 0; h < N2 / 64; ++h) {
-        constexpr int JH = 2;                       // 32-column MFMA tiles per 64-channel half
-        const int own = (h * 64) / WN2;             // wave column that holds this half
-        const int jb = ((h * 64) % WN2) / 32;
-        if (wn2 == own) {
 #pragma unroll
-            for (int i = 0; i < TM2; ++i)
+        for (int j = 0; j < TN2; ++j) {
+            const int col0 = wn2 * WN2 + j * 32;        // this wave's 32-column tile j: does it belong to the 64-channel half h?
+            if (col0 / 64 == h) {
 #pragma unroll
-                for (int j = 0; j < JH; ++j)
+                for (int i = 0; i < TM2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = wm2 * WM2 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        ep[row * CH_EP + j * 32 + l31] = acc2[i][jb + j][r];
+                        ep[row * CH_EP + (col0 & 63) + l31] = acc2[i][j][r];
                     }
+            }
         }
         __syncthreads();
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
@@ -370,18 +380,18 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_f32(const ChainArgs p)
 #undef CH_STAMP
 }
 
-template <int N2, bool HAS_X2>
+template <int BM, int N2, bool HAS_X2>
 static int launch_chain(const ChainArgs &a, hipStream_t stream)
 {
-    constexpr size_t lds = (size_t)(2 * (CH_BM + CH_BN) * 32 + 2 * N2 * 32) * sizeof(float);
-    static_assert((size_t)CH_BM * CH_EP <= (size_t)2 * (CH_BM + CH_BN) * 32, "the epilogue tile must fit the staging buffers it aliases");
+    constexpr size_t lds = (size_t)(2 * (BM + CH_BN) * 32 + (BM == 64 ? 1 : 2) * N2 * 32) * sizeof(float);
+    static_assert((size_t)BM * CH_EP <= (size_t)2 * (BM + CH_BN) * 32, "the epilogue tile must fit the staging buffers it aliases");
     static bool attr_done = false;
-    auto kern = hvn_conv_chain_f32<N2, HAS_X2>;
+    auto kern = hvn_conv_chain_f32<BM, N2, HAS_X2>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         attr_done = true;
     }
-    const long grid = (a.M + CH_BM - 1) / CH_BM;
+    const long grid = (a.M + BM - 1) / BM;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     static unsigned long long *dbg_buf = nullptr;
     static int dbg_on = -1;
@@ -416,6 +426,11 @@ int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream)
     for (long s : spans)
         if (s < 0 || s * 4 >= (1L << 31)) return -1;
     if ((long)(a.C + 64) * (a.K1 + a.K1b) * 4 >= (1L << 31) || (long)(a.N2 + 64) * a.C * 4 >= (1L << 31)) return -1;
-    if (a.N2 == 64) return a.x2 ? launch_chain<64, true>(a, stream) : launch_chain<64, false>(a, stream);
-    return a.x2 ? launch_chain<128, true>(a, stream) : launch_chain<128, false>(a, stream);
+    const bool small = a.bm == 64;          // pixels per workgroup: 128 (default) or 64
+    if (a.N2 == 64) {
+        if (small) return a.x2 ? launch_chain<64, 64, true>(a, stream) : launch_chain<64, 64, false>(a, stream);
+        return a.x2 ? launch_chain<128, 64, true>(a, stream) : launch_chain<128, 64, false>(a, stream);
+    }
+    if (small) return a.x2 ? launch_chain<64, 128, true>(a, stream) : launch_chain<64, 128, false>(a, stream);
+    return a.x2 ? launch_chain<128, 128, true>(a, stream) : launch_chain<128, 128, false>(a, stream);
 }

@@ -59,6 +59,7 @@ struct ChainArgs {
     int N2;
     int N, Ho, Wo;
     long M;
+    int bm;               // pixels per workgroup: 64, or anything else for 128
     unsigned long long *dbg;   // optional (HVN_CHAIN_TRACE): 10 cycle stamps per workgroup, see tools/chain_bench.py
 };
 int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream);

@@ -115,6 +115,8 @@ class Engine:
             for o, op, tn in zip(self.ops, plan.ops, tiles):
                 if op.kind == PL.OP_CONV and ((op.tile_n == 128 and tn in (64, 128)) or (op.tile_n == 64 and tn in (64, 320))):
                     o.tile_n = tn
+                if op.kind == PL.OP_CHAIN and tn in (64, 128):
+                    o.tile_n = tn
         elif dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
             self.autotune_tiles()
 
@@ -223,6 +225,8 @@ class Engine:
         (min of `reps` HIP-event timings after a warm-up launch, on whatever the arena holds -- MFMA time does not depend
         on the values) and gets the narrow tile when that is faster by more than 1.5 %.  Both widths produce the same bits
         (identical k order per output element), so the choice is invisible in the results.  ~1 s per engine."""
+        import os
+
         lib = L.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -241,6 +245,22 @@ class Engine:
             return best
 
         for i, op in enumerate(self.plan.ops):
+            if op.kind == PL.OP_CHAIN:                     # chained 1x1 convs: 128 or 64 pixels per workgroup (same bits)
+                if os.environ.get("HVN_CHAIN_BM"):         # A/B runs: force one
+                    self.ops[i].tile_n = int(os.environ["HVN_CHAIN_BM"])
+                    continue
+                x2 = op.extra.get("x2")
+                key = ("chain", op.x.c, x2.c if x2 is not None else 0, op.cout, op.extra["cout2"], op.y.h, op.y.w, op.res is not None,
+                       op.post is not None, op.pre is not None)
+                if key not in self.tile_choice:
+                    o = self.ops[i]
+                    t = {}
+                    for tn in (128, 64):
+                        o.tile_n = tn
+                        t[tn] = time_op(i)
+                    self.tile_choice[key] = (64 if t[64] < margin * t[128] else 128, t[128], t[64])
+                self.ops[i].tile_n = self.tile_choice[key][0]
+                continue
             if op.kind != PL.OP_CONV or op.tile_n not in (128, 64) or int(op.extra.get("groups", 1)) != 1:
                 continue
             x2 = op.extra.get("x2")

@@ -333,7 +333,7 @@ class DeviceMerger:
     dictionary: per fix-up tile the list of removed ids and the "touching" flags of the new ids come back (a few hundred bytes),
     which also yields the next tile's id offset -- the one true sequential dependency of wsi.py:569-677."""
 
-    def __init__(self, proc_shape, device):
+    def __init__(self, proc_shape, device, cap=1 << 20):
         import ctypes
 
         from . import lib as L
@@ -344,7 +344,7 @@ class DeviceMerger:
         self.inst_info = {}
         self._ids = []
         self.stream = torch.cuda.Stream(self.device, priority=-1)
-        self.cap = 1 << 20
+        self.cap = int(cap)                  # id-table size: grows on demand
         self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
         self.epoch = 0
         self._max_map_id = 0                 # largest id ever written to the map (ids without a dict entry included)

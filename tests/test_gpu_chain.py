@@ -35,7 +35,7 @@ def _two_convs(n, h, w, k1, c, n2, *, res, x2, post, pre, seed, inplace=True):
     return P, (t2, acc, out, t1)
 
 
-def _run(P, n, seed):
+def _run(P, n, seed, bm=None):
     """Every buffer filled with values that depend on (seed, buffer name) only -- the fused and the unfused plan pack their arenas
     differently, but see the same tensors."""
     from hover_net_amd.engine import Engine
@@ -48,6 +48,8 @@ def _run(P, n, seed):
         g = torch.Generator().manual_seed(seed * 1000 + names.index(b.name))
         eng.buffer(PL.View(b), n).copy_(torch.randn((n, b.h, b.w, b.c), generator=g))
     start = eng.arena.cpu().clone()
+    if bm is not None:                                # CHAIN: pixels per workgroup (the engine's timing pass would pick)
+        eng.ops[0].tile_n = bm
     eng.run_raw(n)
     torch.cuda.synchronize()
     return eng, start
@@ -65,14 +67,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("bm", [128, 64])
 @pytest.mark.parametrize("case", CASES)
-def test_chain_matches_reference_and_unfused_launches(case):
+def test_chain_matches_reference_and_unfused_launches(case, bm):
     n, h, w, k1, c, n2, res, x2, post, pre = case
     # fused
     P, (t2, acc, out, t1) = _two_convs(n, h, w, k1, c, n2, res=res, x2=x2, post=post, pre=pre, seed=7, inplace=not post)
     P.fuse_chains()
     assert [o.kind for o in P.ops] == [PL.OP_CHAIN]
-    eng, start = _run(P, n, seed=11)
+    eng, start = _run(P, n, seed=11, bm=bm)
     got = eng.arena.cpu()
     # torch interpreter on the same arena contents, from the CHAIN op's own fields
     A = plan_interp.Arena(P, n)

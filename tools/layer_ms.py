@@ -39,7 +39,7 @@ def main():
         run_desc.infer_step_device(tiles, net)
     torch.cuda.synchronize()
     eng = net.engine(args.batch)
-    marked = [(o.name, o.kind, eng.ops[i].tile_n if o.kind == OP_CONV else 0,
+    marked = [(o.name, o.kind, eng.ops[i].tile_n if o.kind in (OP_CONV, OP_CHAIN) else 0,
                o.extra.get("exec_flops", o.flops()) * args.batch if o.kind in (OP_CONV, OP_CHAIN) else 0.0)
               for i, o in enumerate(eng.plan.ops) if o.kind in (OP_CONV, OP_CHAIN, OP_WINO_IN, OP_WINO_OUT)]
     buf = (ctypes.c_double * 4096)()

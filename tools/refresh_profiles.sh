@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 R=${1:-r}
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_gpu_tests.log
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -40 > gpurun_out/${R}_gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/${R}_smoke.log
 timeout 900 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-traffic > gpurun_out/${R}_bench_profiled_run.json 2>gpurun_out/${R}_prof.err
