@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel summary (calls, total ms, average ms, share) of a rocprofv3 --kernel-trace results.db as CSV.
-Conv launches dispatched BEFORE the first plan execution (= before the first `hvn_conv0` kernel) are the engine's tile
+Conv / chain launches dispatched BEFORE the first plan execution (= before the first `hvn_conv0` kernel) are the engine's tile
 autotune (`Engine.autotune_tiles`: every re-tileable shape timed with both tile widths at engine build); they are reported
 on their own comment line and left out of the table, so that `total_ms / plan executions` is the per-step time again.
 usage: python tools/kernel_stats.py <results.db> [header comment]"""
@@ -12,8 +12,8 @@ first = c.execute("select min(start) from kernels where name like '%hvn_conv0%'"
 tune = (0, 0)
 cond = ""
 if first is not None:
-    tune = c.execute("select count(*), coalesce(sum(duration), 0) from kernels where start < ? and name like '%hvn_conv_igemm%'", (first,)).fetchone()
-    cond = "where not (start < %d and name like '%%hvn_conv_igemm%%')" % first
+    tune = c.execute("select count(*), coalesce(sum(duration), 0) from kernels where start < ? and (name like '%hvn_conv_igemm%' or name like '%hvn_conv_chain%')", (first,)).fetchone()
+    cond = "where not (start < %d and (name like '%%hvn_conv_igemm%%' or name like '%%hvn_conv_chain%%'))" % first
 rows = list(c.execute("select name, count(*), sum(duration), avg(duration) from kernels %s group by name order by sum(duration) desc" % cond))
 tot = sum(r[2] for r in rows)
 if len(sys.argv) > 2:
