@@ -27,6 +27,9 @@ T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD
 MOMENTUM = 0.1
 
 
+_TILE_CHOICE = {}       # (batch, launch shape) -> (tile, ms of the first candidate, ms of the second): see TrainEngine.autotune_tiles
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 
@@ -72,7 +75,7 @@ class TrainEngine:
         self.sums = torch.zeros(64, dtype=torch.float64, device=dev)
         self.sobel_ws = torch.empty((self.n, ho, ho, 2), dtype=torch.float32, device=dev)
         cmax = max(P.bns.values())
-        self.bn_ws = torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev)     # HVN_BN_MAX_PARTS partial sums
+        self.bn_ws = torch.zeros(128 + 256 * 2 * cmax, dtype=torch.float64, device=dev)   # HVN_BN_HEAD ticket counters (zero) + HVN_BN_MAX_PARTS partial sums
         self.bn_coef = torch.empty(3 * cmax, dtype=torch.float32, device=dev)
         self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
         self._bn_save_off, off = {}, 0
@@ -97,6 +100,7 @@ class TrainEngine:
         self._dec_off = min(self._poff[k] for k in dec_keys)
         self._loss = self._loss_desc()
         self.last_terms = None
+        self.autotune_tiles()
 
     # -- parameter / gradient slabs ------------------------------------------------------------------
     def _build_slabs(self):
@@ -364,6 +368,46 @@ class TrainEngine:
         for i, t in enumerate(flat):
             ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(t), ctypes.sizeof(L.hvn_top))
         return arr
+
+    def autotune_tiles(self, reps=3, margin=0.985):
+        """Measured column-tile selection for the step's CONV launches (forward convs, data gradients, the Winograd-domain products),
+        like `engine.Engine.autotune_tiles` for the inference plan: the static choice of `plan._tile_n` fits batch 32 of the
+        inference path, while a phase-1 step carries 4 samples per GPU (opt.py:75-76) and most of its launches are one or two rounds
+        of workgroups, where the narrower tile's finer quantisation wins.  Candidates: 128 x 128 | 128 x 64 for cout >= 128,
+        128 x 64 | 256 x 64 for cout = 64 -- same packed weights, same k order per output element, hence the same bits.  Timed
+        on whatever the arenas hold (min of `reps` HIP-event timings after a warm-up launch); one choice per launch shape and
+        batch, shared by every engine of the process.  HVN_TILE_SELECT=0 | model keeps the static tiles."""
+        if os.environ.get("HVN_TILE_SELECT", "auto") in ("0", "model"):
+            return
+        lib = L.lib()
+        stream = self._stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def time_op(o):
+            best = float("inf")
+            for r in range(reps + 1):
+                e0.record()
+                L.check(lib.hvn_run_op(ctypes.addressof(o), self.n, stream), "hvn_run_op (autotune)")
+                e1.record()
+                e1.synchronize()
+                if r:
+                    best = min(best, e0.elapsed_time(e1))
+            return best
+
+        for o in self._keep:
+            if not isinstance(o, L.hvn_op) or o.kind != OP_CONV or o.groups > 1 or o.tile_n not in (128, 64):
+                continue
+            key = (self.n, o.kh, o.kw, o.stride, o.pad_t, o.x.c, o.cout, o.y.h, o.y.w, o.x.h, o.x.w, bool(o.res.base), int(o.nbatch))
+            cands = (128, 64) if o.tile_n == 128 else (64, 320)
+            if key not in _TILE_CHOICE:
+                t = {}
+                for tn in cands:
+                    o.tile_n = tn
+                    t[tn] = time_op(o)
+                _TILE_CHOICE[key] = (cands[1] if t[cands[1]] < margin * t[cands[0]] else cands[0], t[cands[0]], t[cands[1]])
+            o.tile_n = _TILE_CHOICE[key][0]
+        torch.cuda.synchronize(self.device)
+        self.gmem.zero_()       # the data-gradient launches accumulate into the gradient arena
 
     def _loss_desc(self):
         d = L.hvn_loss()

@@ -183,7 +183,9 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *                [lead_pad][cout/32][taps][32]), 2 conv0 ([7][7][3][64] x 1/255); 3 / 4 Winograd F(4x4,5x5) transform
  *                U = G g G^T of a 5x5 conv for the forward / data-gradient pass ([64][lead_pad][k/32][32], p[2] = G
  *                [8][5]); cout, cin_g, groups, kh, kw
- *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[256][2c] (scratch for the partial sums),
+ *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[128 + 256 * 2c]: 128 doubles of ticket counters
+ *                (ZERO before the first launch, left zero by every launch; the per-channel finalize runs in the reduction's
+ *                last workgroup) followed by scratch for the partial sums; launches sharing a ws must be stream-ordered;
  *                p[1] = save[4c] (scale, shift, mean, rstd), p[2] = gamma, p[3] = beta, p[4] = running_mean,
  *                p[5] = running_var (updated: momentum, unbiased variance); eps, momentum
  *   BN_BWD       x = z, y = a, dy = grad a, dx = grad z (+=, base NULL: none); p[0] = ws, p[1] = save, p[2] = gamma,

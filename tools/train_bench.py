@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hover_net_amd import net_desc  # noqa: E402
 from hover_net_amd.optim import FusedAdam  # noqa: E402
 from hover_net_amd.synth import synth_state_dict, synth_train_batch  # noqa: E402
+from hover_net_amd import train_engine  # noqa: E402
 from hover_net_amd.train_engine import TrainEngine  # noqa: E402
 
 
@@ -99,6 +100,12 @@ def main():
                           "gradient_slab_mb": slab_mb,
                           "allreduce": "not measurable on one GPU: N > 1 all-reduces the gradient slab (%.0f MB fp32) in two buckets + 64 doubles of "
                                        "loss partial sums per step; no RCCL run exists for it (one-GPU box)" % slab_mb,
+                          "conv_tiles": {"launch_shapes_timed": sum(1 for k in train_engine._TILE_CHOICE if k[0] == bs),
+                                         "re_tiled": sum(1 for k, v in train_engine._TILE_CHOICE.items() if k[0] == bs and v[0] in (64, 320) and v[1] > v[2]),
+                                         "static_ms": sum(v[1] for k, v in train_engine._TILE_CHOICE.items() if k[0] == bs),
+                                         "chosen_ms": sum(min(v[1], v[2]) if v[0] in (64, 320) and v[2] < v[1] else v[1]
+                                                          for k, v in train_engine._TILE_CHOICE.items() if k[0] == bs),
+                                         "note": "TrainEngine.autotune_tiles: one timing per distinct launch shape (sums are over shapes, not launches); HVN_TILE_SELECT=0 keeps the static tiles"},
                           "loss": eng.loss_terms()["overall_loss"], "arena_gb": eng.arena.numel() * 4 / 1e9, "grad_gb": eng.gmem.numel() * 4 / 1e9}))
         del eng, net, opt
         torch.cuda.empty_cache()
