@@ -19,7 +19,7 @@ static int fail(int code, const char *fmt, const char *a = "", long b = 0)
 
 extern "C" {
 
-int hvn_version(void) { return 103; }   // 1.02: + CHAIN op (two chained 1x1 convs), hvn_op grew y2 / w2 / bias2 / cout2; 1.03: BN workspace carries 128 doubles of ticket counters in front
+int hvn_version(void) { return 102; }   // 1.02: + CHAIN op (two chained 1x1 convs), hvn_op grew y2 / w2 / bias2 / cout2
 
 #ifndef HVN_BUILD_ID
 #define HVN_BUILD_ID "unstamped"

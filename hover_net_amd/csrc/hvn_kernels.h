@@ -156,13 +156,13 @@ struct WgradArgs {
     unsigned rows_per_split;
     int nbatch;           // > 1: blockIdx.z selects one of nbatch independent problems
     long xb, db, wb;      // element strides of x, dy, dw between them
+    int want_wgs;         // workgroups the K split aims at (0: the default)
 };
 int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream);
 int hvn_launch_wino_dy(const struct WinoArgs &a, hipStream_t stream);
 int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, int cin, hipStream_t stream);
 
 #define HVN_BN_MAX_PARTS 256
-#define HVN_BN_HEAD 128       // doubles in front of the partial sums: the fused finalize's ticket counters (one unsigned per channel group)
 struct BnArgs {
     const float *z;       // conv output (pre-normalisation)
     long zsn, zsy, zsx;
@@ -173,8 +173,7 @@ struct BnArgs {
     long gsn, gsy, gsx;
     float *dz;            // backward: gradient of z (accumulated), may be null
     long dsn, dsy, dsx;
-    double *ws;           // [HVN_BN_HEAD] ticket counters (zero before the first launch) + [HVN_BN_MAX_PARTS][2*C] partial sums
-    unsigned *cnt;        // set by the launcher: the counters, or null for a separate finalize launch
+    double *ws;           // [HVN_BN_MAX_PARTS][2*C] partial sums (no initialisation needed)
     float *save;          // [4*C] scale, shift, mean, rstd
     float *coef;          // [3*C] backward coefficients
     const float *gamma, *beta;

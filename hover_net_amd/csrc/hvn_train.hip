@@ -326,11 +326,14 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream)
     const long tiles = (long)a.tiles_m * a.tiles_n * a.KH * a.KW;
     const long R = (long)a.N * a.Ho * a.Wo;
     const int nb = a.nbatch > 1 ? a.nbatch : 1;
-    // experiment knobs (tools/wgrad_sweep.py; read per launch so that one process can sweep them): workgroups aimed at per launch
-    // and the fewest rows of the reduction a workgroup takes
+    // The K split trades matrix time against atomic traffic (every workgroup ends with one fp32 atomic per element of its tile).
+    // Default: ~3 workgroups per slot of the 512 the chip holds, at least 8 k-steps per workgroup.  The best target depends on
+    // the launch shape (profiles/r03_train_wgrad_sweep.txt: 512 for the encoder's few-tile launches at batch 4, >= 1024 for the
+    // decoder's 5x5 launches), so TrainEngine.autotune_tiles times a few per shape and passes its choice in `want_wgs`.
+    // HVN_WGRAD_WGS / HVN_WGRAD_MIN_ROWS override (tools/wgrad_sweep.py; read per launch so that one process can sweep them).
     const char *e_wgs = getenv("HVN_WGRAD_WGS"), *e_rows = getenv("HVN_WGRAD_MIN_ROWS");
-    const long want = e_wgs ? atol(e_wgs) : 1536;         // ~3 workgroups per slot of the 512 the chip holds
-    const long min_rows = e_rows ? atol(e_rows) : 256;    // at least 8 k-steps per workgroup
+    const long want = e_wgs ? atol(e_wgs) : (a.want_wgs > 0 ? a.want_wgs : 1536);
+    const long min_rows = e_rows ? atol(e_rows) : 256;
     long ksplit = (want + tiles * nb - 1) / (tiles * nb);
     const long max_split = (R + min_rows - 1) / min_rows;
     if (ksplit > max_split) ksplit = max_split;
@@ -475,35 +478,6 @@ int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, 
 // g = da * (a > 0), xhat = (z - mean) * rstd.  A thread owns one channel quad (LQ lanes per row, 256/LQ rows per
 // block pass), accumulates in double (8 rows in flight), the block combines through LDS and writes one partial per
 // (row block, channel) to ws[block][2*c + {0,1}]; the finalize kernels sum the partials in a fixed order.
-// forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
-__device__ inline void bn_finalize_fwd(const BnArgs &p, int c, double s1, double s2)
-{
-    const double n = (double)p.N * p.H * p.W;
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)p.eps);
-    const double sc = (double)p.gamma[c] * rstd;
-    p.save[c] = (float)sc;
-    p.save[p.C + c] = (float)((double)p.beta[c] - mean * sc);
-    p.save[2 * p.C + c] = (float)mean;
-    p.save[3 * p.C + c] = (float)rstd;
-    const float mom = p.momentum;
-    p.running_mean[c] = (1.f - mom) * p.running_mean[c] + mom * (float)mean;
-    p.running_var[c] = (1.f - mom) * p.running_var[c] + mom * (float)(var * n / (n - 1.0));
-}
-
-// backward finalize: dgamma += sum g*xhat, dbeta += sum g; coefficients of the dz formula
-__device__ inline void bn_finalize_bwd(const BnArgs &p, int c, double s1, double s2)
-{
-    const double n = (double)p.N * p.H * p.W;
-    p.dgamma[c] += (float)s2;
-    p.dbeta[c] += (float)s1;
-    p.coef[c] = p.gamma[c] * p.save[3 * p.C + c];
-    p.coef[p.C + c] = (float)(s1 / n);
-    p.coef[2 * p.C + c] = (float)(s2 / n);
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
 {
@@ -567,51 +541,13 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
         for (int k = 1; k < rper; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += red[threadIdx.x + k * LQ][e];
-        // one partial per (row block, channel): no atomics, summed by the finalize step in a fixed order
+        // one partial per (row block, channel): no atomics, summed by the finalize kernel in a fixed order
         double *part = p.ws + (long)blockIdx.y * 2 * p.C;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             part[2 * (q * 4 + e)] = s[e];
             part[2 * (q * 4 + e) + 1] = s[4 + e];
         }
-    }
-    if (!p.cnt) return;     // separate finalize launch (HVN_BN_SPLIT_FINAL=1)
-    // Fused finalize: the row block of this channel group that finishes LAST sums the group's partials -- in the order of
-    // bn_part_sums, so the totals are the same bits as the separate launch's -- and writes the per-channel results.  The ticket
-    // counter of the group is re-armed by that block; launches sharing `ws` are ordered by their stream.
-    __shared__ bool is_last;
-    __threadfence();                                    // this block's partials are visible device-wide before its ticket
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(p.cnt + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = t + 1 == gridDim.y;
-        if (is_last) __hip_atomic_store(p.cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    for (int cl = threadIdx.x; cl < 4 * LQ; cl += 256) {
-        const int c = blockIdx.x * 4 * LQ + cl;
-        if (c >= p.C) continue;
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k0 = 0; k0 < p.nparts; k0 += 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j < p.nparts) {
-                    a[j] += p.ws[(long)(k0 + j) * 2 * p.C + 2 * c];
-                    b[j] += p.ws[(long)(k0 + j) * 2 * p.C + 2 * c + 1];
-                }
-        }
-        double s1 = a[0], s2 = b[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            s1 += a[j];
-            s2 += b[j];
-        }
-        if (MODE == 0)
-            bn_finalize_fwd(p, c, s1, s2);
-        else
-            bn_finalize_bwd(p, c, s1, s2);
     }
 }
 
@@ -641,21 +577,39 @@ __device__ inline bool bn_part_sums(const BnArgs &p, double &s1, double &s2, int
     return true;
 }
 
-// the finalize step as its own launch (HVN_BN_SPLIT_FINAL=1; the default runs it inside hvn_bn_reduce's last block)
+// forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
 __global__ __launch_bounds__(256) void hvn_bn_final(const BnArgs p)
 {
     double s1, s2;
     int c;
     if (!bn_part_sums(p, s1, s2, c)) return;
-    bn_finalize_fwd(p, c, s1, s2);
+    const double n = (double)p.N * p.H * p.W;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)p.eps);
+    const double sc = (double)p.gamma[c] * rstd;
+    p.save[c] = (float)sc;
+    p.save[p.C + c] = (float)((double)p.beta[c] - mean * sc);
+    p.save[2 * p.C + c] = (float)mean;
+    p.save[3 * p.C + c] = (float)rstd;
+    const float mom = p.momentum;
+    p.running_mean[c] = (1.f - mom) * p.running_mean[c] + mom * (float)mean;
+    p.running_var[c] = (1.f - mom) * p.running_var[c] + mom * (float)(var * n / (n - 1.0));
 }
 
+// backward finalize: dgamma += sum g*xhat, dbeta += sum g; coefficients of the dz formula
 __global__ __launch_bounds__(256) void hvn_bn_bwd_final(const BnArgs p)
 {
     double s1, s2;
     int c;
     if (!bn_part_sums(p, s1, s2, c)) return;
-    bn_finalize_bwd(p, c, s1, s2);
+    const double n = (double)p.N * p.H * p.W;
+    p.dgamma[c] += (float)s2;
+    p.dbeta[c] += (float)s1;
+    p.coef[c] = p.gamma[c] * p.save[3 * p.C + c];
+    p.coef[p.C + c] = (float)(s1 / n);
+    p.coef[2 * p.C + c] = (float)(s2 / n);
 }
 
 // MODE 0: a = relu(z*scale + shift).  MODE 1: dz += c1 * (g - c2 - xhat*c3).
@@ -698,10 +652,6 @@ __global__ __launch_bounds__(256) void hvn_bn_apply(const BnArgs p, long total)
 
 static void bn_grid(BnArgs &a, dim3 &grid)
 {
-    // ws = [HVN_BN_HEAD doubles: ticket counters of the fused finalize, zero before the first launch][HVN_BN_MAX_PARTS][2C] partial sums
-    const char *e = getenv("HVN_BN_SPLIT_FINAL");     // read per launch: tests/test_gpu_train.py compares both forms in one process
-    a.cnt = (e && atoi(e)) ? nullptr : (unsigned *)a.ws;
-    a.ws += HVN_BN_HEAD;
     const int cq = a.C / 4;
     int lq = 64;
     while (lq > cq) lq >>= 1;      // largest power of two <= min(64, cq)
@@ -717,7 +667,6 @@ static void bn_grid(BnArgs &a, dim3 &grid)
     if (gy < 1) gy = 1;
     a.lq = lq;
     a.nparts = (int)gy;
-    if (gx > 2 * HVN_BN_HEAD) a.cnt = nullptr;          // more channel groups than ticket counters: separate finalize launch
     grid = dim3((unsigned)gx, (unsigned)gy);
 }
 
@@ -727,7 +676,7 @@ int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
     dim3 grid;
     bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<0>, grid, dim3(256), 0, stream, a);
-    if (!a.cnt) hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
     const long total = (long)a.N * a.H * a.W * (a.C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -741,7 +690,7 @@ int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
     dim3 grid;
     bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<1>, grid, dim3(256), 0, stream, a);
-    if (!a.cnt) hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
     if (a.dz) {
         const long total = (long)a.N * a.H * a.W * (a.C / 4);
         long blocks = (total + 255) / 256;

@@ -73,6 +73,7 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
         a.groups = t->groups > 1 ? t->groups : 1; a.Cin_g = a.Cin / a.groups;
         a.nbatch = t->nbatch > 1 ? t->nbatch : 1;
         a.xb = t->batch_stride[0]; a.db = t->batch_stride[1]; a.wb = t->batch_stride[2];
+        a.want_wgs = t->mode > 0 ? t->mode : 0;
         if ((long)batch * a.Ho * a.Wo >= (1L << 31)) return tfail(HVN_E_ARG, "wgrad: too many rows", idx);
         int rc = hvn_launch_wgrad(a, s);
         if (rc == -1) return tfail(HVN_E_ARG, "wgrad: unsupported channel counts", idx);

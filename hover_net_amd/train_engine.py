@@ -27,7 +27,8 @@ T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD
 MOMENTUM = 0.1
 
 
-_TILE_CHOICE = {}       # (batch, launch shape) -> (tile, ms of the first candidate, ms of the second): see TrainEngine.autotune_tiles
+_TILE_CHOICE = {}       # (batch, launch shape) -> (choice, ms of the static choice, ms of the alternative): see TrainEngine.autotune_tiles
+WGRAD_TARGETS = (1536, 1024, 768, 512, 384)     # workgroups a weight-gradient launch may aim at; the first is the untuned default
 
 
 def _align(n, a=64):
@@ -75,7 +76,7 @@ class TrainEngine:
         self.sums = torch.zeros(64, dtype=torch.float64, device=dev)
         self.sobel_ws = torch.empty((self.n, ho, ho, 2), dtype=torch.float32, device=dev)
         cmax = max(P.bns.values())
-        self.bn_ws = torch.zeros(128 + 256 * 2 * cmax, dtype=torch.float64, device=dev)   # HVN_BN_HEAD ticket counters (zero) + HVN_BN_MAX_PARTS partial sums
+        self.bn_ws = torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev)     # HVN_BN_MAX_PARTS partial sums
         self.bn_coef = torch.empty(3 * cmax, dtype=torch.float32, device=dev)
         self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
         self._bn_save_off, off = {}, 0
@@ -376,7 +377,9 @@ class TrainEngine:
         of workgroups, where the narrower tile's finer quantisation wins.  Candidates: 128 x 128 | 128 x 64 for cout >= 128,
         128 x 64 | 256 x 64 for cout = 64 -- same packed weights, same k order per output element, hence the same bits.  Timed
         on whatever the arenas hold (min of `reps` HIP-event timings after a warm-up launch); one choice per launch shape and
-        batch, shared by every engine of the process.  HVN_TILE_SELECT=0 | model keeps the static tiles."""
+        batch, shared by every engine of the process.  The weight-gradient launches get the same treatment for the split of
+        their pixel sum (fewer, longer workgroups pay fewer atomics: best for the encoder's few-tile launches at batch 4; the
+        decoder's 400-tile 5x5 launches want the opposite).  HVN_TILE_SELECT=0 | model keeps the static choices."""
         if os.environ.get("HVN_TILE_SELECT", "auto") in ("0", "model"):
             return
         lib = L.lib()
@@ -406,8 +409,38 @@ class TrainEngine:
                     t[tn] = time_op(o)
                 _TILE_CHOICE[key] = (cands[1] if t[cands[1]] < margin * t[cands[0]] else cands[0], t[cands[0]], t[cands[1]])
             o.tile_n = _TILE_CHOICE[key][0]
+        # weight gradients: the split of the pixel sum (hvn_top.mode = workgroups aimed at; csrc/hvn_train.hip: launch_wgrad)
+        tsz = ctypes.sizeof(L.hvn_top)
+        base = ctypes.addressof(self.bwd_ops)
+
+        def time_top(i):
+            best = float("inf")
+            for r in range(reps + 1):
+                e0.record()
+                rc = lib.hvn_run_train_plan(base + i * tsz, 1, self.n, stream)
+                if rc:
+                    raise L.HvnError("hvn_run_train_plan (autotune) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+                e1.record()
+                e1.synchronize()
+                if r:
+                    best = min(best, e0.elapsed_time(e1))
+            return best
+
+        for i in range(len(self.bwd_ops)):
+            t = self.bwd_ops[i]
+            if t.kind != T_WGRAD:
+                continue
+            key = ("wgrad", self.n, t.kh, t.kw, t.stride, t.pad_t, t.x.c, t.dy.c, t.dy.h, t.dy.w, t.x.h, t.x.w, t.groups, int(t.nbatch))
+            if key not in _TILE_CHOICE:
+                ms = {}
+                for want in WGRAD_TARGETS:
+                    t.mode = want
+                    ms[want] = time_top(i)
+                best = min(ms, key=ms.get)
+                _TILE_CHOICE[key] = (best if ms[best] < margin * ms[WGRAD_TARGETS[0]] else WGRAD_TARGETS[0], ms[WGRAD_TARGETS[0]], ms[best])
+            t.mode = _TILE_CHOICE[key][0]
         torch.cuda.synchronize(self.device)
-        self.gmem.zero_()       # the data-gradient launches accumulate into the gradient arena
+        self.gmem.zero_()       # the data-gradient and weight-gradient launches accumulate
 
     def _loss_desc(self):
         d = L.hvn_loss()

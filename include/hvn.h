@@ -183,15 +183,14 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *                [lead_pad][cout/32][taps][32]), 2 conv0 ([7][7][3][64] x 1/255); 3 / 4 Winograd F(4x4,5x5) transform
  *                U = G g G^T of a 5x5 conv for the forward / data-gradient pass ([64][lead_pad][k/32][32], p[2] = G
  *                [8][5]); cout, cin_g, groups, kh, kw
- *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[128 + 256 * 2c]: 128 doubles of ticket counters
- *                (ZERO before the first launch, left zero by every launch; the per-channel finalize runs in the reduction's
- *                last workgroup) followed by scratch for the partial sums; launches sharing a ws must be stream-ordered;
+ *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[256][2c] (scratch for the partial sums),
  *                p[1] = save[4c] (scale, shift, mean, rstd), p[2] = gamma, p[3] = beta, p[4] = running_mean,
  *                p[5] = running_var (updated: momentum, unbiased variance); eps, momentum
  *   BN_BWD       x = z, y = a, dy = grad a, dx = grad z (+=, base NULL: none); p[0] = ws, p[1] = save, p[2] = gamma,
  *                p[3] = grad gamma (+=), p[4] = grad beta (+=), p[5] = coef[3c] scratch
  *   WGRAD        p[0][cout][kh*kw][cin_g] += sum_pixels dy (x) x: x = conv input view, dy = output-gradient view;
- *                kh, kw, stride, pad_t, pad_l, groups
+ *                kh, kw, stride, pad_t, pad_l, groups; mode = workgroups the split of the pixel sum aims at (0: default;
+ *                a tuning hint, the result is the same sum in another order)
  *   CONV0_WGRAD  x = uint8 image view, dy = grad of the conv0 output, p[0] = grad [64][7][7][3] (+=); pad_t
  *   UPADD_BWD    dy = grad of nearest2x(lo) + skip; dx = grad lo (+= 2x2 sums, nullable), y = grad skip (+=, nullable)
  *   HEAD_BWD     x = head input [h][w][64], dx = its grad (+=), p[0] = logit grad NCHW, p[1] = W [cout][64],

@@ -105,7 +105,12 @@ def main():
                                          "static_ms": sum(v[1] for k, v in train_engine._TILE_CHOICE.items() if k[0] == bs),
                                          "chosen_ms": sum(min(v[1], v[2]) if v[0] in (64, 320) and v[2] < v[1] else v[1]
                                                           for k, v in train_engine._TILE_CHOICE.items() if k[0] == bs),
-                                         "note": "TrainEngine.autotune_tiles: one timing per distinct launch shape (sums are over shapes, not launches); HVN_TILE_SELECT=0 keeps the static tiles"},
+                                         "wgrad_targets": {str(w): sum(1 for k, v in train_engine._TILE_CHOICE.items() if k[0] == "wgrad" and k[1] == bs and v[0] == w)
+                                                           for w in train_engine.WGRAD_TARGETS},
+                                         "wgrad_static_ms": sum(v[1] for k, v in train_engine._TILE_CHOICE.items() if k[0] == "wgrad" and k[1] == bs),
+                                         "wgrad_chosen_ms": sum(v[2] if v[0] != train_engine.WGRAD_TARGETS[0] else v[1]
+                                                                for k, v in train_engine._TILE_CHOICE.items() if k[0] == "wgrad" and k[1] == bs),
+                                         "note": "TrainEngine.autotune_tiles: one timing per distinct launch shape (sums are over shapes, not launches); HVN_TILE_SELECT=0 keeps the static choices"},
                           "loss": eng.loss_terms()["overall_loss"], "arena_gb": eng.arena.numel() * 4 / 1e9, "grad_gb": eng.gmem.numel() * 4 / 1e9}))
         del eng, net, opt
         torch.cuda.empty_cache()
