@@ -11,9 +11,9 @@ import sys
 
 db, line, passes = sys.argv[1], json.loads(open(sys.argv[2]).readline()), int(sys.argv[3])
 c = sqlite3.connect(db)
-# conv launches before the first step (= before the first conv0 kernel) are TrainEngine.autotune_tiles' timing launches: left out
+# conv launches before the first step (= before the first conv0 kernel) and weight-gradient launches are TrainEngine.autotune_tiles' timing launches: left out
 first = c.execute("select min(start) from kernels where name like '%hvn_conv0%'").fetchone()[0] or 0
-rows = list(c.execute("select name, count(*), sum(duration) from kernels where not (start < ? and name like '%hvn_conv_igemm%') group by name", (first,)))
+rows = list(c.execute("select name, count(*), sum(duration) from kernels where not (start < ? and (name like '%hvn_conv_igemm%' or name like '%hvn_conv_wgrad%')) group by name", (first,)))
 mfma = ("hvn_conv_igemm_f32", "hvn_conv_wgrad_f32", "hvn_conv0_mfma", "hvn_conv0_wgrad_mfma", "hvn_dense_grouped", "hvn_conv_chain")
 feed = ("hvn_wino_in", "hvn_wino_out", "hvn_wino_dy", "hvn_wino_dw", "hvn_pack_w")
 t_mfma = sum(r[2] for r in rows if any(k in r[0] for k in mfma)) / 1e6 / passes
