@@ -334,6 +334,36 @@ def main():
             variants["with_dict"] = {"value": tiles_per_step_global * args.steps / dt_d, "unit": "tiles/s",
                                      "what": "host_to_host + contour tracing and inst_info_dict assembly on the host (one thread), "
                                              "overlapped with the next step's GPU work"}
+        if world == 1 and args.dtype == "fp32" and not os.environ.get("HVN_SPLIT") and not os.environ.get("HVN_LANES"):
+            # the same step on the other launch schedule (engine.Engine.run): the encoder as two sub-batches on two streams, the
+            # decoder branches on their own streams -- same bits (tests/test_gpu_chain.py), not the headline because the roofline leg
+            # times every conv launch alone on ONE stream and has to describe the engine that `value` was measured on
+            os.environ["HVN_SPLIT"], os.environ["HVN_LANES"] = "2", "2"
+            try:
+                net2 = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
+                net2.load_state_dict(sd, strict=True)
+                net2.max_batch = args.batch
+                net2.compute_dtype = args.dtype
+                net2 = net2.to(dev).eval()
+                pipe2 = TilePipeline(net2, nr_types=nt, return_centroids=True)
+
+                def step2():
+                    out2 = None
+                    for t in tiles:
+                        out2 = pipe2.submit(t, extra_maps=structured, to_host=True)
+                    return out2
+
+                for _ in range(args.warmup):
+                    step2()
+                dt2, _ = timed(step2, args.steps)
+                variants["two_stream_schedule"] = {"value": tiles_per_step_global * args.steps / dt2, "unit": "tiles/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                                                   "what": "the timed step with HVN_SPLIT=2 HVN_LANES=2 (two encoder sub-batches on two streams, decoder "
+                                                           "branches on three): a launch schedule, bit-equal outputs"}
+                del pipe2, net2
+            finally:
+                os.environ.pop("HVN_SPLIT", None)
+                os.environ.pop("HVN_LANES", None)
+            torch.cuda.empty_cache()
         reps, t_end = 0, time.perf_counter() + args.sustain_seconds
         fence()
         t0 = time.perf_counter()

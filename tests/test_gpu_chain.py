@@ -147,3 +147,30 @@ def test_network_with_and_without_upadd_fusion_is_bit_equal(monkeypatch):
             outs.append({k: v.clone() for k, v in logits.items()})
         for k in outs[0]:
             assert torch.equal(outs[0][k], outs[1][k]), (mode, k)
+
+
+def test_network_on_sub_batch_and_branch_streams_is_bit_equal(monkeypatch):
+    """HVN_SPLIT=2 HVN_LANES=2 -- the encoder as two sub-batches on two streams, the decoder branches on their own streams
+    (engine.Engine.run; +2.6 % on the round-3 kernels, profiles/r03_streams_ab.txt) -- is a launch SCHEDULE: every kernel sees the
+    same per-sample operands, so logits and prediction map carry the bits of the single-stream run (chains and Winograd scratch
+    included: each sample owns its rows of every buffer)."""
+    from hover_net_amd import net_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+
+    tiles = torch.from_numpy(synth_tiles(5, 270, seed=6)).cuda()       # 5: uneven sub-batches (2 + 3)
+    outs = []
+    for split, lanes in (("1", "0"), ("2", "2")):
+        monkeypatch.setenv("HVN_SPLIT", split)
+        monkeypatch.setenv("HVN_LANES", lanes)
+        net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
+        net.load_state_dict(synth_state_dict("original", 5, seed=2), strict=True)
+        net = net.cuda().eval()
+        eng = net.engine(5)
+        assert eng.n_split == int(split) and eng.n_lane_streams == int(lanes)
+        logits, pred = eng.run(tiles)
+        torch.cuda.synchronize()
+        out = {k: v.clone() for k, v in logits.items()}
+        out["pred_map"] = pred.clone()
+        outs.append(out)
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
