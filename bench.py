@@ -3,10 +3,23 @@
 
 One *step* = one pass of the whole hot path over one batch of synthetic tiles resident in HBM:
 32 uint8 270x270 tiles -> HIP network (original mode, 5 types, fp32) -> infer_step epilogue -> on-GPU
-instance separation (Sobel / threshold / CC / watershed) + per-instance table -> [N > 1: RCCL gather of
-instance maps + record tables to rank 0] -> D2H of instance maps, records and counts into pinned host
-memory.  The post-processing of step i runs on a side stream under the network of step i+1
-(hover_net_amd/pipeline.py); nothing inside a step waits on the host.
+instance separation (Sobel / threshold / CC / watershed) + per-instance table OF THE NETWORK'S OWN OUTPUT
+-> [N > 1: RCCL gather of instance maps + record tables to rank 0] -> D2H of instance maps, records and
+counts into pinned host memory.  The post-processing of step i runs on a side stream under the network of
+step i+1 (hover_net_amd/pipeline.py); nothing inside a step waits on the host.
+
+The checkpoint (round 4): a random-init network emits maps without nuclei, so the flow of
+/root/reference/infer/tile.py:308-316,361-386 (network maps -> `process`) had nothing to separate.  By default the
+checkpoint is now FITTED at bench start, outside every timed region, with the repository's own trainer
+(hover_net_amd/synth_fit.py: ~200 steps of run_desc.train_step on painted H&E-like tiles at CoNSeP's nucleus density),
+and the timed tiles are painted tiles of the same kind: the step's instance separation runs on what the network
+emits.  `--checkpoint random` keeps the seeded random-init weights; `variants.plus_structured_maps` is round 3's step
+(an additional resident batch of structured synthetic maps post-processed per step).
+
+Launch schedule (round 4): the timed step runs the engine's default schedule -- the encoder as two sub-batches on two
+HIP streams, the decoder branches on three (bit-equal outputs, tests/test_gpu_chain.py) -- and the roofline leg has
+its OWN engine of the same checkpoint on ONE launch stream, where every conv launch can be timed alone;
+`variants.single_stream_schedule` is the timed step on that engine.
 
 `value` = tiles/s over exactly --steps steps, inputs resident in HBM when the timed region starts, results on the
 host (the bench contract).  SURVEY 8d defines the metric from pinned host memory to host results: that rate is
@@ -23,7 +36,7 @@ are gathered to rank 0 INSIDE the timed step (`infer_tile.gather_to_rank0`, the 
 
 `roofline` is for the dominant kernel (`hvn_conv_igemm_f32`, fp32 MFMA): achieved = MFMA FLOPs the conv
 launches of one step EXECUTE (after the Winograd transforms: that is what the matrix pipe issues) / summed
-HIP-event duration of those launches, measured in the same single-stream execution mode as the timed steps.
+HIP-event duration of those launches, measured on the single-stream engine (same plan, same kernels).
 `algorithmic_speedup` = direct-convolution FLOPs / executed FLOPs (what Winograd removes) is reported
 beside it, never folded into `frac`.  `cpu_baseline` (N = 1 only) times the CPU oracle -- torch fp32
 restatement of the network + the C / python restatement of `process()` -- on a bounded sample of the same
@@ -79,6 +92,13 @@ def _control_flow_selftest(args, rank, world, dev):
     for _ in range(args.warmup):
         submit()
     dt, out = timed(args.steps)
+    per_rank = None
+    if world > 1:                      # the per-rank diagnosis of main(): every rank's own numbers all_gathered
+        mine = torch.tensor([float(rank), 0.0], dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t[0]) for t in allr]
+        assert per_rank == [float(r) for r in range(world)]
     if rank == 0:
         assert out[0].shape[0] == world * b and out[0][::b, 0, 0].tolist() == list(range(1, world + 1)), "gather order = rank order"
         assert out[2][::b].tolist() == list(range(world))
@@ -124,6 +144,12 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help="internal: one untimed step and nothing else (the run rocprofv3 --pmc wraps)")
     ap.add_argument("--sustain-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--checkpoint", default="fitted", choices=("fitted", "random"),
+                    help="fitted (default): a checkpoint fitted at bench start with the repo's own trainer on painted tiles, so that the network's "
+                         "output holds nuclei and the timed instance separation works on it; random: seeded random-init weights + noise tiles "
+                         "(round 3's workload: the step then also post-processes a resident batch of structured maps)")
+    ap.add_argument("--fit-steps", type=int, default=200)
+    ap.add_argument("--fit-init", default="synth", choices=("synth", "kaiming"))
     ap.add_argument("--quiet-net-output", action="store_true",
                     help="bias the NP head of the random-init checkpoint towards background, so that the network's own output "
                          "holds no nuclei and the instance-separation load of the step comes from the structured maps only")
@@ -167,16 +193,51 @@ def main():
     from hover_net_amd.pipeline import TilePipeline
     from hover_net_amd.synth import synth_pred_maps, synth_state_dict, synth_tiles
 
+    from hover_net_amd import synth_fit
+
     nt = args.nr_types if args.nr_types > 0 else None
     size = 270 if args.mode == "original" else 256
-    sd = synth_state_dict(args.mode, nt, seed=0)
+    fitted = args.checkpoint == "fitted" and not args.pmc_child       # HBM traffic does not depend on the weights' values
+    fit_info = {}
+
+    def make_checkpoint(mode, nr_types, sz, seed=0):
+        """-> (state_dict on the host, info).  Outside every timed region."""
+        if not fitted:
+            return synth_state_dict(mode, nr_types, seed=seed), {"kind": "random-init (seeded)"}
+        t_fit = time.perf_counter()
+        tnet, curve = synth_fit.fit(mode, nr_types, steps=args.fit_steps, batch=8, lr=1e-3, seed=seed, init=args.fit_init,
+                                    density=synth_fit.consep_density(sz))
+        sd_ = {k: v.detach().cpu().clone() for k, v in tnet.state_dict().items()}
+        tnet._train_engine = None
+        del tnet
+        torch.cuda.empty_cache()
+        return sd_, {"kind": "fitted at bench start: %d steps of run_desc.train_step (batch 8, Adam 1e-3, init %s) on painted tiles"
+                             % (args.fit_steps, args.fit_init),
+                     "loss_first10": float(np.mean(curve[:10])), "loss_last10": float(np.mean(curve[-10:])), "seconds": time.perf_counter() - t_fit}
+
+    def make_tiles(n, sz, seed):
+        if not fitted:
+            return synth_tiles(n, sz, seed=seed)
+        return synth_fit.painted_tiles(n, sz, seed, *synth_fit.consep_density(sz))[0]
+
+    sd, fit_info = make_checkpoint(args.mode, nt, size)
     if args.quiet_net_output:
         sd["decoder.np.u0.conv.bias"] = torch.tensor([8.0, -8.0])
-    net = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
-    net.load_state_dict(sd, strict=True)
-    net.max_batch = args.batch
-    net.compute_dtype = args.dtype
-    net = net.to(dev).eval()
+
+    def make_net(schedule=None, mode=args.mode, nr_types=nt, sd_=None, batch=args.batch, dtype=args.dtype):
+        n_ = net_desc.create_model(mode=mode, nr_types=nr_types, input_ch=3)
+        n_.load_state_dict(sd if sd_ is None else sd_, strict=True)
+        n_.max_batch = batch
+        n_.compute_dtype = dtype
+        n_.launch_schedule = schedule
+        return n_.to(dev).eval()
+
+    if args.pmc_child:              # counters are collected per dispatch by the wrapping rocprofv3: ONE plan execution on one launch stream
+        net = make_net((1, 0))
+        run_desc.infer_step_device(torch.from_numpy(make_tiles(args.batch, size, 1)).to(dev), net)
+        torch.cuda.synchronize(dev)
+        return
+    net = make_net()           # the engine's default launch schedule (fp32: two encoder sub-batches + decoder branch streams)
     # the work of one step on this rank: `sub` batches of `args.batch` tiles
     if args.scaling == "strong":
         lo, hi = infer_tile.shard_range(args.strong_tiles, rank, world)
@@ -185,25 +246,33 @@ def main():
     else:
         sub = 1
         tiles_per_step_global = world * args.batch
-    tiles_host = [torch.from_numpy(synth_tiles(args.batch, size, seed=1 + rank + 1000 * j)).pin_memory() for j in range(sub)]
+    tiles_host = [torch.from_numpy(make_tiles(args.batch, size, 1 + rank + 1000 * j)).pin_memory() for j in range(sub)]
     tiles = [t.to(dev) for t in tiles_host]                       # resident in HBM
-    # A random-init network emits maps without nuclei (0 instances -> the watershed has nothing to flood).  So that the
-    # step carries a realistic instance-separation load it ALSO post-processes a resident batch of structured synthetic
-    # maps (painted, partly touching elliptical nuclei, hover_net_amd.synth.synth_pred_maps): post-proc runs twice per
-    # batch, which over-counts its cost.  Density: CoNSeP has 24 319 nuclei in 41 images of 1000x1000 px = 3.8 per 80x80
-    # output tile; the structured maps carry 2..8 (mean 5) per 80x80, scaled by area for other output sizes.
-    out_hw = net.engine(args.batch).plan.geo["out"]
+    # Structured synthetic maps (painted, partly touching elliptical nuclei, hover_net_amd.synth.synth_pred_maps; 2..8 per
+    # 80x80, CoNSeP: 3.8): with a FITTED checkpoint the network's own output carries the instance-separation load and these are
+    # only `variants.plus_structured_maps` (round 3's step) and the stage split's post-processing sample; with a random-init
+    # checkpoint (0 instances in the network output) the step also post-processes them, as in round 3.
+    eng0 = net.engine(args.batch)
+    out_hw = eng0.plan.geo["out"]
     structured_np = synth_pred_maps(args.batch, out_hw, out_hw, nt, seed=100 + rank, k_lo=2, k_hi=8)[0]
     structured = torch.from_numpy(structured_np).to(dev)
 
     # network of batch i+1 (main stream) overlaps the post-processing of batch i (side stream)
     pipe = TilePipeline(net, nr_types=nt, return_centroids=True)
+    pipe.time_gather = world > 1
     gather = infer_tile.gather_to_rank0 if world > 1 else None
+    # does the network's own output hold nuclei?  (one untimed pass; a fit that did not converge falls back to round 3's step)
+    probe = pipe.submit(tiles[0], to_host=True)
+    pipe.wait()
+    net_inst = int(probe[2].sum().item())
+    extra = None if (fitted and net_inst > 0) else structured
+    if fitted and net_inst == 0:
+        fit_info["note"] = "the fitted network emitted 0 instances: the step also post-processes the structured maps (round 3's step)"
 
-    def step(src=tiles):
+    def step(src=tiles, extra_maps=extra, p=None):
         out = None
         for t in src:
-            out = pipe.submit(t, extra_maps=structured, gather=gather, to_host=True)
+            out = (p or pipe).submit(t, extra_maps=extra_maps, gather=gather, to_host=True)
         return out
 
     def fence():
@@ -218,6 +287,9 @@ def main():
         out = None
         for _ in range(steps):
             out = fn()
+        # this rank's own clock: last result of this rank on the host (its side stream drained), BEFORE the closing barrier
+        torch.cuda.synchronize(dev)
+        last_rank_dt[0] = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -226,16 +298,25 @@ def main():
             dt = float(t.item())
         return dt, out
 
-    if args.pmc_child:              # counters are collected per dispatch by the wrapping rocprofv3: one plan execution is all it needs
-        step()
-        torch.cuda.synchronize(dev)
-        return
+    last_rank_dt = [0.0]
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        pipe.gather_ms()                 # drop the warm-up's gather timings
     dt, out = timed(step, args.steps)
     n_inst = int(out[2].sum().item()) if (rank == 0 and out is not None) else 0
     if rank == 0 and world > 1:
         assert out[0].shape[0] == world * args.batch, "rank 0 must hold every rank's instance maps after the gather"
+    per_rank = None
+    if world > 1:
+        # diagnosis of a bad scaling curve from ONE run: every rank's own step time (its clock stops when its own last result is on
+        # the host, before the closing barrier) and the mean duration of its `gather` call on the side stream
+        mine = torch.tensor([1e3 * last_rank_dt[0] / args.steps, pipe.gather_ms()], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"step_ms": [float(t[0]) for t in allr], "gather_ms": [float(t[1]) for t in allr],
+                    "what": "per rank: wall time per step up to its own last result (before the closing barrier); mean HIP-event time of the "
+                            "per-batch gather to rank 0 on the side stream (overlaps the next network pass)"}
 
     ms_per_step = 1e3 * dt / args.steps
     result = {
@@ -251,17 +332,24 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 tiles per GPU resident in HBM, "
-                               "random-init checkpoint (seeded%s): network + infer_step epilogue + on-GPU instance separation and "
-                               "instance table (of the network output AND of a resident batch of structured synthetic maps), %s"
+        "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 %s tiles per GPU resident in HBM, "
+                               "%s checkpoint%s: network + infer_step epilogue + on-GPU instance separation and instance table of %s, %s"
                                "D2H of instance maps + records to pinned host memory"
-                               % (args.mode, nt, args.batch, size, size, ", NP head biased to background" if args.quiet_net_output else "",
+                               % (args.mode, nt, args.batch, size, size, "painted H&E-like (CoNSeP nucleus density)" if fitted else "noise",
+                                  "fitted (trained-like, made at bench start outside the timed region)" if fitted else "random-init (seeded)",
+                                  ", NP head biased to background" if args.quiet_net_output else "",
+                                  "the network's own output" if extra is None else "the network output AND of a resident batch of structured synthetic maps",
                                   "RCCL gather to rank 0, " if world > 1 else ""),
                    "global_batch": tiles_per_step_global, "world_size": world, "batches_per_step_per_rank": sub,
                    "instances_last_step": n_inst,
+                   "instances_from": "network output" if extra is None else "structured synthetic maps (the network output of this checkpoint: %d instances)" % net_inst,
+                   "checkpoint": fit_info,
                    "parallelism": "tile-sharded x%d, %s" % (world, "gather to rank 0 per batch" if world > 1 else "single GPU"),
-                   "execution": "network on one HIP stream, post-processing + gather + D2H on a side stream under the next network pass"},
+                   "execution": "network: engine default launch schedule (n_split %d, %d decoder branch streams); post-processing + gather + D2H on a "
+                                "side stream under the next network pass" % (eng0.n_split, eng0.n_lane_streams)},
     }
+    if per_rank is not None:
+        result["config"]["per_rank"] = per_rank
 
     # ---- per-stage split of one batch (rank 0): each stage ALONE on the launch stream, warmed, median of 5 passes ------
     # (a stage alone is not a share of the pipelined step: there the post-processing of batch i runs under the network of
@@ -284,17 +372,21 @@ def main():
 
         torch.cuda.synchronize(dev)
         net_ms, pred = med_ms(lambda: run_desc.infer_step_device(tiles[0], net), inner=4)
+        pred = pred.clone()
+        ppn_ms, (inst_n, _r, counts_n) = med_ms(lambda: post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True))
         pp_ms, (inst, rec, counts) = med_ms(lambda: post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True))
         d2h_ms, host = med_ms(lambda: [t.cpu() for t in (inst, rec, counts)])
         t1 = time.perf_counter()
         rec_h, inst_h = host[1].numpy(), host[0].numpy()
         dicts = [post_proc.records_to_dict(rec_h[i].view(post_proc._REC_DTYPE).reshape(-1), nt, inst_h[i]) for i in range(inst_h.shape[0])]
         dict_ms = 1e3 * (time.perf_counter() - t1)
-        result["config"]["stage_ms"] = {"network": net_ms, "postproc_structured": pp_ms, "d2h_results": d2h_ms,
+        result["config"]["stage_ms"] = {"network": net_ms, "postproc_network_output": ppn_ms, "instances_in_network_output": int(counts_n.sum().item()),
+                                        "postproc_structured": pp_ms, "d2h_results": d2h_ms,
                                         "host_contours_and_dict": dict_ms, "instances_in_dicts": sum(len(d) for d in dicts),
                                         "how": "each stage alone on the launch stream, median of 5 warmed measurements (network: 4 back-to-back passes per measurement)"}
 
     # ---- variants (untimed by the driver; same K steps each) ---------------------------------------------------------
+    net_rf = None              # the single-stream engine of the same checkpoint (roofline leg, single_stream_schedule variant)
     if not args.no_variants:
         variants = {}
         dt_h, _ = timed(lambda: step(tiles_host), args.steps)
@@ -334,36 +426,25 @@ def main():
             variants["with_dict"] = {"value": tiles_per_step_global * args.steps / dt_d, "unit": "tiles/s",
                                      "what": "host_to_host + contour tracing and inst_info_dict assembly on the host (one thread), "
                                              "overlapped with the next step's GPU work"}
-        if world == 1 and args.dtype == "fp32" and not os.environ.get("HVN_SPLIT") and not os.environ.get("HVN_LANES"):
-            # the same step on the other launch schedule (engine.Engine.run): the encoder as two sub-batches on two streams, the
-            # decoder branches on their own streams -- same bits (tests/test_gpu_chain.py), not the headline because the roofline leg
-            # times every conv launch alone on ONE stream and has to describe the engine that `value` was measured on
-            os.environ["HVN_SPLIT"], os.environ["HVN_LANES"] = "2", "2"
-            try:
-                net2 = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
-                net2.load_state_dict(sd, strict=True)
-                net2.max_batch = args.batch
-                net2.compute_dtype = args.dtype
-                net2 = net2.to(dev).eval()
-                pipe2 = TilePipeline(net2, nr_types=nt, return_centroids=True)
-
-                def step2():
-                    out2 = None
-                    for t in tiles:
-                        out2 = pipe2.submit(t, extra_maps=structured, to_host=True)
-                    return out2
-
-                for _ in range(args.warmup):
-                    step2()
-                dt2, _ = timed(step2, args.steps)
-                variants["two_stream_schedule"] = {"value": tiles_per_step_global * args.steps / dt2, "unit": "tiles/s", "ms_per_step": 1e3 * dt2 / args.steps,
-                                                   "what": "the timed step with HVN_SPLIT=2 HVN_LANES=2 (two encoder sub-batches on two streams, decoder "
-                                                           "branches on three): a launch schedule, bit-equal outputs"}
-                del pipe2, net2
-            finally:
-                os.environ.pop("HVN_SPLIT", None)
-                os.environ.pop("HVN_LANES", None)
-            torch.cuda.empty_cache()
+        if world == 1:
+            # the same step on ONE launch stream (the roofline leg's engine; same plan and kernels, bit-equal outputs:
+            # tests/test_gpu_chain.py::test_network_on_sub_batch_and_branch_streams_is_bit_equal)
+            net_rf = make_net((1, 0))
+            pipe_rf = TilePipeline(net_rf, nr_types=nt, return_centroids=True)
+            for _ in range(args.warmup):
+                step(p=pipe_rf)
+            dt2, _ = timed(lambda: step(p=pipe_rf), args.steps)
+            variants["single_stream_schedule"] = {"value": tiles_per_step_global * args.steps / dt2, "unit": "tiles/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                                                  "what": "the timed step with the network on ONE HIP stream (n_split 1, no branch streams): round 3's headline "
+                                                          "schedule, the one the roofline leg times its launches on"}
+            del pipe_rf
+            if extra is None:
+                for _ in range(2):
+                    step(extra_maps=structured)
+                dt3, _ = timed(lambda: step(extra_maps=structured), args.steps)
+                variants["plus_structured_maps"] = {"value": tiles_per_step_global * args.steps / dt3, "unit": "tiles/s", "ms_per_step": 1e3 * dt3 / args.steps,
+                                                    "what": "the timed step + instance separation and table of a resident batch of structured synthetic maps "
+                                                            "(2..8 nuclei per 80x80), i.e. round 3's step on this round's checkpoint"}
         reps, t_end = 0, time.perf_counter() + args.sustain_seconds
         fence()
         t0 = time.perf_counter()
@@ -428,13 +509,13 @@ def main():
         tmp = tempfile.mkdtemp(prefix="hvn_pmc_", dir="/tmp")
         dbs = {}
         tile_file = os.path.join(tmp, "tiles.json")       # the children run THIS engine's measured column-tile choices (no autotune under the counters)
-        json.dump([int(o.tile_n) for o in net.engine(args.batch).ops], open(tile_file, "w"))
+        json.dump([int(o.tile_n) for o in net_rf.engine(args.batch).ops], open(tile_file, "w"))
         try:
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, counter)
                 cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(args.batch),
                        "--mode", args.mode, "--nr-types", str(args.nr_types), "--dtype", args.dtype]
-                env = dict(os.environ, TMPDIR="/tmp", HVN_TILE_FILE=tile_file)
+                env = dict(os.environ, TMPDIR="/tmp", HVN_TILE_FILE=tile_file, HVN_SPLIT="1", HVN_LANES="0")
                 for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
                     env.pop(k, None)
                 r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=args.traffic_timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -452,7 +533,9 @@ def main():
             shutil.rmtree(tmp, ignore_errors=True)
 
     if rank == 0 and not args.no_roofline:
-        roof = roofline_of(net, tiles[0], args.batch, args.dtype)
+        if net_rf is None:
+            net_rf = make_net((1, 0))
+        roof = roofline_of(net_rf, tiles[0], args.batch, args.dtype)
         n_conv = roof["conv_launches_per_step"]
         red, why = (None, "--no-traffic") if (args.no_traffic or world > 1) else measure_traffic(n_conv)
         if red is not None:
@@ -461,7 +544,7 @@ def main():
             roof["traffic_unit"] = ("HBM bytes per conv launch, mean over the step's %d launches, MEASURED IN THIS RUN: two `rocprofv3 --pmc` child "
                                     "passes of this script (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)" % n_conv)
         else:
-            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                 tpath = os.path.join(REPO, "profiles", name)
                 if os.path.exists(tpath) and args.batch == 32 and args.mode == "original" and nt == 5 and args.dtype == "fp32":
                     roof["traffic"] = json.load(open(tpath))["hbm_bytes_per_step"] / max(1, n_conv)
@@ -475,30 +558,37 @@ def main():
     # ---- BASELINE cfg 3 as a driver-visible leg: fast mode, 6 types, batch 64, bf16 (rank 0, N = 1) --------------------
     if rank == 0 and world == 1 and not args.no_variants and not args.no_cfg3 and not (args.mode == "fast" and args.dtype == "bf16"):
         nt3, b3 = 6, 64
-        net3 = net_desc.create_model(mode="fast", nr_types=nt3, input_ch=3)
-        net3.load_state_dict(synth_state_dict("fast", nt3, seed=0), strict=True)
-        net3.max_batch, net3.compute_dtype = b3, "bf16"
-        net3 = net3.to(dev).eval()
-        tiles3 = torch.from_numpy(synth_tiles(b3, 256, seed=1)).to(dev)
+        sd3, fit3 = make_checkpoint("fast", nt3, 256)
+        net3 = make_net(None, "fast", nt3, sd3, b3, "bf16")
+        tiles3 = torch.from_numpy(make_tiles(b3, 256, 1)).to(dev)
         out3 = net3.engine(b3).plan.geo["out"]
         structured3 = torch.from_numpy(synth_pred_maps(b3, out3, out3, nt3, seed=100, k_lo=2, k_hi=8)[0]).to(dev)
         pipe3 = TilePipeline(net3, nr_types=nt3, return_centroids=True)
+        probe3 = pipe3.submit(tiles3, to_host=True)
+        pipe3.wait()
+        net_inst3 = int(probe3[2].sum().item())
+        extra3 = None if (fitted and net_inst3 > 0) else structured3
 
         def step3():
-            return pipe3.submit(tiles3, extra_maps=structured3, to_host=True)
+            return pipe3.submit(tiles3, extra_maps=extra3, to_host=True)
 
         for _ in range(2):
             step3()
         k3 = max(5, args.steps // 2)
         dt3, out3_ = timed(step3, k3)
+        net3_ms, _ = med_ms(lambda: run_desc.infer_step_device(tiles3, net3), inner=2)
         roof3 = roofline_of(net3, tiles3, b3, "bf16", n_prof=3)
         result.setdefault("variants", {})["cfg3_fast_b64_bf16"] = {
             "value": b3 * k3 / dt3, "unit": "tiles/s", "steps": k3, "ms_per_step": 1e3 * dt3 / k3, "dtype": "bf16",
+            "network_ms": net3_ms, "step_over_network": 1e3 * dt3 / k3 / net3_ms,
             "workload": "PanNuke 'fast' mode (256x256 -> 164x164, 6 types), batch 64 resident in HBM, bf16 activations / weights with fp32 "
-                        "accumulation and fp32 logits; same step as the headline (network + epilogue + instance separation + table of the network "
-                        "output and of a structured batch + D2H), random-init checkpoint, no output biasing",
+                        "accumulation and fp32 logits; same step as the headline (network + epilogue + instance separation + table of %s "
+                        "+ D2H), %s checkpoint" % ("the network's own output" if extra3 is None else "the network output and of a structured batch",
+                                                   "fitted" if fitted else "random-init"),
+            "checkpoint": fit3, "instances_in_network_output": net_inst3,
             "instances_last_step": int(out3_[2].sum().item()), "roofline": roof3}
         del pipe3, net3
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same tiles ------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -527,7 +617,7 @@ def main():
             x = cpu_tiles[:k].permute(0, 3, 1, 2).float()
             pm = net_torch.infer_epilogue(net_torch.forward(sd, x, args.mode)).numpy()
             t2 = time.perf_counter()
-            for m in list(pm) + list(structured_np[:k]):       # what the GPU step post-processes: net output + structured maps
+            for m in list(pm) + (list(structured_np[:k]) if extra is not None else []):       # what the GPU step post-processes
                 process_np.process(m, nt, True)
             return t2 - t1, time.perf_counter() - t2
 
@@ -536,8 +626,8 @@ def main():
         net_s, pp_s = cpu_pass(k)
         result["cpu_baseline"] = {"value": k / (net_s + pp_s), "unit": "tiles/s", "cores": cores, "kind": "port",
                                   "sample": "%d of the same %d tiles: oracle/net_torch.py (torch-CPU fp32, %d threads) %.2f s + "
-                                            "oracle process() restatement (hvn_oracle.c + process_np.py, 1 thread) on the %d network maps and "
-                                            "%d structured maps %.2f s" % (k, args.batch, cores, net_s, k, k, pp_s),
+                                            "oracle process() restatement (hvn_oracle.c + process_np.py, 1 thread) on the %d network maps%s "
+                                            "%.2f s" % (k, args.batch, cores, net_s, k, " and %d structured maps" % k if extra is not None else "", pp_s),
                                   "network_s_per_tile": net_s / k, "postproc_s_per_tile": pp_s / k}
     if rank == 0:
         print(json.dumps(result))

@@ -421,8 +421,12 @@ int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream)
 {
     if (!hvn_chain_supported(a.C, a.N2) || a.K1 <= 0 || a.K1 % 32 || a.K1 + a.K1b < 64 || (a.x2 && (a.K1b <= 0 || a.K1b % 32))) return -1;
     if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
-    // 32-bit per-thread byte offsets below 2^31 (the top bit marks rows past the end): a tile spans at most two samples
-    const long spans[5] = {2 * a.xsn, a.x2 ? 2 * a.x2sn : 0, 2 * a.ysn, a.res ? 2 * a.rsn : 0, 2 * a.y2sn};
+    // 32-bit per-thread byte offsets below 2^31 (the top bit marks rows past the end): a tile of `bm` pixels spans at most
+    // bm / (Ho * Wo) + 2 samples (two when a sample holds at least a tile's worth of pixels, as in every HoVer-Net plan)
+    const long px = (long)a.Ho * a.Wo;
+    if (px <= 0) return -1;
+    const long ns = (a.bm == 64 ? 64 : 128) / px + 2;
+    const long spans[5] = {ns * a.xsn, a.x2 ? ns * a.x2sn : 0, ns * a.ysn, a.res ? ns * a.rsn : 0, ns * a.y2sn};
     for (long s : spans)
         if (s < 0 || s * 4 >= (1L << 31)) return -1;
     if ((long)(a.C + 64) * (a.K1 + a.K1b) * 4 >= (1L << 31) || (long)(a.N2 + 64) * a.C * 4 >= (1L << 31)) return -1;

@@ -32,7 +32,8 @@ struct MergeArgs {
     long cap;
     int32_t *removed;
     int removed_cap;
-    int32_t *counters;        // 0: removed ids, 1: smallest value on the window edge, 2: smallest value in the window, 3: smallest value of the new tile
+    int32_t *counters;        // 0: removed ids, 1: smallest value on the window edge, 2: smallest value in the window, 3: smallest value of the new tile,
+                              // 4: window pixels whose id lies beyond the id tables (>= cap): the caller sized the tables too small -> it raises
     uint8_t *touching;        // [n_local + 1]
     int n_local;
 };
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(MG_T) void mg_init(MergeArgs a)
         a.counters[1] = 0x7fffffff;
         a.counters[2] = 0x7fffffff;
         a.counters[3] = 0x7fffffff;
+        a.counters[4] = 0;
     }
     if (i <= a.n_local) a.touching[i] = 0;
 }
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(MG_T) void mg_remove(MergeArgs a)
     const int y = (int)(i / a.w), x = (int)(i - (long)y * a.w);
     int32_t *m = a.map + (long)(a.y0 + y) * a.map_w + (a.x0 + x);
     const int32_t id = *m;
+    if (id >= a.cap) atomicAdd(&a.counters[4], 1);      // never silently: the host raises on a non-zero count
     if (id <= 0 || id >= a.cap) return;
     const int32_t edge_min = a.counters[1], roi_min = a.counters[2];
     // np.unique(...)[1:] drops the smallest value: the background 0 if the window (edge) holds any, else the smallest id

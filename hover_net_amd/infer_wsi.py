@@ -345,14 +345,16 @@ class DeviceMerger:
         self._ids = []
         self.stream = torch.cuda.Stream(self.device, priority=-1)
         self.cap = int(cap)                  # id-table size: grows on demand
-        self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
         self.epoch = 0
         self._max_map_id = 0                 # largest id ever written to the map (ids without a dict entry included)
         self.removed_cap = 1 << 16
-        self.removed = torch.zeros(self.removed_cap, dtype=torch.int32, device=self.device)
-        self.counters = torch.zeros(4, dtype=torch.int32, device=self.device)
-        self.touching = torch.zeros(1 << 16, dtype=torch.uint8, device=self.device)
-        self._h_counters = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))      # inst_map's zero-fill ran on the caller's stream
+        with torch.cuda.stream(self.stream):     # every table is (re)allocated and zero-filled ON the merge stream: ordered before the kernels that stamp it
+            self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
+            self.removed = torch.zeros(self.removed_cap, dtype=torch.int32, device=self.device)
+            self.counters = torch.zeros(5, dtype=torch.int32, device=self.device)
+            self.touching = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)      # mg_init clears it per tile
+        self._h_counters = torch.zeros(5, dtype=torch.int32, pin_memory=True)
         self._h_removed = torch.zeros(self.removed_cap, dtype=torch.int32, pin_memory=True)
         self._h_touching = torch.zeros(1 << 16, dtype=torch.uint8, pin_memory=True)
 
@@ -372,7 +374,9 @@ class DeviceMerger:
         if len(info) == 0:
             return
         off = self._max_id()
-        self._max_map_id = max(self._max_map_id, off + int(max(n_local or 0, max(info))))
+        if n_local is None:                                      # ids without a dict entry (contours under 3 points) can exceed max(info)
+            n_local = int(pred_inst.max())
+        self._max_map_id = max(self._max_map_id, off + int(max(n_local, max(info))))
         for i, e in info.items():
             self._insert(i + off, e)
         with torch.cuda.stream(self.stream):
@@ -391,10 +395,12 @@ class DeviceMerger:
         n_local = int(max(n_local, max(info)))
         if self._max_map_id + 1 >= self.cap:                     # the id tables index every id in the map (also ids without a dict entry)
             self.cap = max(2 * self.cap, self._max_map_id + 2)
-            self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
+            with torch.cuda.stream(self.stream):                 # zero-fill ordered before mg_scan's stamps (not on the caller's stream)
+                self.flags = torch.zeros((2, self.cap), dtype=torch.int32, device=self.device)
         self._max_map_id = max(self._max_map_id, off + n_local)
         if n_local + 1 > self.touching.shape[0]:
-            self.touching = torch.zeros(2 * (n_local + 1), dtype=torch.uint8, device=self.device)
+            with torch.cuda.stream(self.stream):
+                self.touching = torch.empty(2 * (n_local + 1), dtype=torch.uint8, device=self.device)
             self._h_touching = torch.zeros(2 * (n_local + 1), dtype=torch.uint8, pin_memory=True)
         self.epoch += 1
         with torch.cuda.stream(self.stream):
@@ -410,6 +416,9 @@ class DeviceMerger:
             self._h_touching[:n_local + 1].copy_(self.touching[:n_local + 1], non_blocking=True)
         self.stream.synchronize()
         n_rem = int(self._h_counters[0])
+        if int(self._h_counters[4]):
+            raise RuntimeError("%d window pixels carry ids beyond the id tables (cap %d): the tables were sized from a too small n_local"
+                               % (int(self._h_counters[4]), self.cap))
         if n_rem > self.removed_cap:
             raise RuntimeError("%d instances removed by one fix-up tile: beyond the list of %d" % (n_rem, self.removed_cap))
         rem = self._h_removed[:n_rem].numpy() if n_rem <= 4096 else self.removed[:n_rem].cpu().numpy()

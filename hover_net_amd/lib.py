@@ -97,12 +97,37 @@ def _built_id(path):
 
 
 def _compile(out, extra, verbose):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    """One object per source, compiled in parallel and cached by the hash of what it is built from (the source, both headers, the
+    flags) under csrc/.obj/, then linked: editing one kernel file recompiles that file only (~30 s instead of ~150 s for all).
+    The .so still carries the id of ALL sources (`hvn_build_id`, stamped into hvn_api.hip's object)."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
     sid = source_id() + ("" if not extra else "+" + "".join(extra))
-    cmd = ["hipcc", *HIPCC_FLAGS, *extra, '-DHVN_BUILD_ID="%s"' % sid, *srcs, "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr = open(os.path.join(CSRC, "hvn_kernels.h"), "rb").read() + open(os.path.join(os.path.dirname(_HERE), "include", "hvn.h"), "rb").read()
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra)
+    jobs, objs = [], []
+    for src in SOURCES:
+        defs = ['-DHVN_BUILD_ID="%s"' % sid] if src == "hvn_api.hip" else []
+        h = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr + " ".join(cflags + defs).encode()).hexdigest()[:16]
+        obj = os.path.join(objdir, "%s.%s.o" % (src, h))
+        objs.append(obj)
+        if not os.path.exists(obj):
+            for old in os.listdir(objdir):          # one cached object per source and flag set is enough
+                if old.startswith(src + ".") and not extra:
+                    os.remove(os.path.join(objdir, old))
+            jobs.append(["hipcc", *cflags, *defs, "-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *objs, "-o", out])
     return out
 
 

@@ -112,6 +112,9 @@ class HoVerNet(nn.Module):
         # "fp32" (parity configuration, logits within 1e-3) or "bf16" (BASELINE cfg 3: bf16 weights / activations, fp32
         # accumulation; no reference bf16 exists, the declared tolerance is on the fp32 logits, tests/test_gpu_bf16.py)
         self.compute_dtype = os.environ.get("HVN_DTYPE", "fp32")
+        # launch schedule of the inference engine: None = the engine's default (fp32: two encoder sub-batches + decoder branch
+        # streams), or (n_split, n_lanes); (1, 0) = one launch stream (every launch can then be timed alone: bench.py's roofline leg)
+        self.launch_schedule = None
 
     def _apply(self, fn, *a, **k):
         # .to() / .cuda() / .float() replace the parameter storage: the bound plans (and the training engine's slabs
@@ -135,13 +138,14 @@ class HoVerNet(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("HoVerNet runs on MI355X only: call .to('cuda') first (no CPU fallback)")
-        key = (self._weights_version(), str(dev), self.compute_dtype)
+        key = (self._weights_version(), str(dev), self.compute_dtype, self.launch_schedule)
         if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             bf16 = self.compute_dtype == "bf16"
             plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None, chain=False if bf16 else None)
             self._engine = None  # free the old arena first
-            self._engine = E.Engine(plan, max(self.max_batch, batch), dev, dtype=self.compute_dtype)
+            ns, nl = self.launch_schedule if self.launch_schedule is not None else (None, None)
+            self._engine = E.Engine(plan, max(self.max_batch, batch), dev, dtype=self.compute_dtype, n_split=ns, n_lanes=nl)
             self._engine_key = key
         return self._engine
 

@@ -31,6 +31,9 @@ class TilePipeline:
         self.h2d = torch.cuda.Stream(self.device)
         self._in = [None, None]
         self._in_free = [None, None]                 # event: the network is done reading _in[k]
+        # optional diagnosis (bench.py --gpus N): HIP events around every `gather` call on the side stream
+        self.time_gather = False
+        self.gather_events = []
 
     def submit(self, tiles_u8, extra_maps=None, gather=None, to_host=False):
         """Network on the current stream, post-processing on the side stream.  Returns
@@ -64,7 +67,13 @@ class TilePipeline:
             if extra_maps is not None:
                 out = self._run_pp(extra_maps)
             if gather is not None:
+                if self.time_gather:
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record(self.side)
                 out = gather(out)
+                if self.time_gather:
+                    g1.record(self.side)
+                    self.gather_events.append((g0, g1))
             if to_host and out is not None:
                 out = self._to_host(out, k)
             self._free[k] = torch.cuda.Event()
@@ -107,6 +116,12 @@ class TilePipeline:
             if t is not None:
                 b.copy_(t, non_blocking=True)
         return bufs
+
+    def gather_ms(self):
+        """Mean duration (ms) of the timed `gather` calls since the last call of this method (side stream synchronised first)."""
+        self.side.synchronize()
+        ev, self.gather_events = self.gather_events, []
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else 0.0
 
     def wait(self):
         self.side.synchronize()

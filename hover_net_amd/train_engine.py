@@ -400,7 +400,10 @@ class TrainEngine:
         for o in self._keep:
             if not isinstance(o, L.hvn_op) or o.kind != OP_CONV or o.groups > 1 or o.tile_n not in (128, 64):
                 continue
-            key = (self.n, o.kh, o.kw, o.stride, o.pad_t, o.x.c, o.cout, o.y.h, o.y.w, o.x.h, o.x.w, bool(o.res.base), int(o.nbatch))
+            if o.tile_n == 64 and o.x2.base:
+                continue                                   # the fused-shortcut instantiations exist for 128 x 128 and 128 x 64 tiles only (as in Engine.autotune_tiles)
+            key = (self.n, o.kh, o.kw, o.stride, o.pad_t, o.x.c, o.cout, o.y.h, o.y.w, o.x.h, o.x.w, bool(o.res.base), int(o.nbatch),
+                   bool(o.pre_scale), int(o.x2.c) if o.x2.base else 0)
             cands = (128, 64) if o.tile_n == 128 else (64, 320)
             if key not in _TILE_CHOICE:
                 t = {}
@@ -441,6 +444,28 @@ class TrainEngine:
             t.mode = _TILE_CHOICE[key][0]
         torch.cuda.synchronize(self.device)
         self.gmem.zero_()       # the data-gradient and weight-gradient launches accumulate
+        self._share_launch_shapes()
+
+    def _share_launch_shapes(self):
+        """Data-parallel training: every rank times its own launches, and noise could give two ranks different weight-gradient splits,
+        i.e. different fp32 summation orders of the same gradient (harmless after the all-reduce, but run-to-run variation nobody asked
+        for).  Rank 0's choices are broadcast (one small int32 tensor at engine build; every rank builds its engine at the same step).
+        HVN_TILE_SHARE=0 keeps the per-rank choices."""
+        import torch.distributed as dist
+
+        if os.environ.get("HVN_TILE_SHARE", "1") == "0" or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        convs = [o for o in self._keep if isinstance(o, L.hvn_op) and o.kind == OP_CONV]
+        tops = [self.bwd_ops[i] for i in range(len(self.bwd_ops)) if self.bwd_ops[i].kind == T_WGRAD]
+        vals = torch.tensor([int(o.tile_n) for o in convs] + [int(t.mode) for t in tops], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            vals = vals.to(self.device)
+        dist.broadcast(vals, 0)
+        vals = vals.cpu().tolist()
+        for o, v in zip(convs, vals[:len(convs)]):
+            o.tile_n = v
+        for t, v in zip(tops, vals[len(convs):]):
+            t.mode = v
 
     def _loss_desc(self):
         d = L.hvn_loss()

@@ -157,7 +157,7 @@ HVN_API int hvn_instance_table(const int32_t *inst, const float *pred, int n, in
  *          reference does) are zeroed and listed in `removed` (count in counters[0]; counters[1] / [2] = smallest value on the window
  *          edge / in the window, counters[3] = smallest value of pred_inst: np.unique(pred_inst)[1:] drops it too); touching[i] = 1 for new ids i <= n_local that overlap a kept old instance (they are dropped); the
  *          other new ids are written with + off.  id_flags: dev int32 [2][cap] epoch-stamped tables (zeroed once; cap > every id in
- *          the map), epoch > 0 and increasing from call to call; removed: dev [removed_cap]; counters: dev [4]; touching: dev [n_local + 1]. */
+ *          the map), epoch > 0 and increasing from call to call; removed: dev [removed_cap]; counters: dev [5] (counters[4] = window pixels whose id is >= cap, i.e. beyond the id tables: must be 0, the caller checks); touching: dev [n_local + 1]. */
 HVN_API int hvn_wsi_merge_normal(int32_t *inst_map, int64_t map_w, int y0, int x0, int h, int w, const int32_t *pred_inst, int32_t off,
                                  void *stream);
 HVN_API int hvn_wsi_merge_fixing(int32_t *inst_map, int64_t map_w, int y0, int x0, int h, int w, const int32_t *pred_inst, int32_t n_local,

@@ -56,7 +56,7 @@ def _upsample2x(x):
     return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
 
 
-def _res_block(sd, name, x):
+def _res_block(sd, name, x, taps=None):
     stride = RES_STRIDE[name]
     shortcut = F.conv2d(x, sd[name + ".shortcut.weight"], stride=stride)  # net_utils.py:229-230
     prev = x
@@ -74,6 +74,8 @@ def _res_block(sd, name, x):
         f = F.conv2d(f, sd[p + "conv3.weight"])
         prev = f + shortcut  # net_utils.py:263-264
         shortcut = prev
+    if taps is not None:
+        taps[name + ".sum"] = prev      # the block's un-normalised running sum (net_utils.py:250-266), before blk_bna
     return _bn(sd, name + ".blk_bna.bn", prev)
 
 
@@ -102,7 +104,7 @@ def forward(sd, imgs, mode="original", taps=None):
         x = _bn(sd, "conv0.bn", x)
         d = []
         for name in ("d0", "d1", "d2", "d3"):
-            x = _res_block(sd, name, x)
+            x = _res_block(sd, name, x, taps)
             d.append(x)
         d[3] = F.conv2d(d[3], sd["conv_bot.weight"])
         if mode == "original":

@@ -1,0 +1,89 @@
+"""fp32 parity at a REALISTIC activation scale (round-3 verdict, missing #3 / next #3).
+
+Every other fp32 logit test runs `synth_state_dict`, whose residual convs are damped so that activations stay O(1..10).  A real
+pre-activation ResNet-50 checkpoint is not like that: a block's output is an UN-normalised running sum over its units
+(/root/reference/models/hovernet/net_utils.py:250-266) and Winograd's fp32 error scales with the activation range.  No checkpoint
+can be downloaded, so one is FITTED here with the repository's own trainer (hover_net_amd/synth_fit.py) from the reference's own
+initialisation (`Net.weights_init`: un-damped Kaiming convs, BatchNorm 1 / 0) -- trained BatchNorm statistics, a network that
+segments -- and then, on held-out painted tiles:
+
+  * HIP fp32 logits vs the torch-CPU fp32 oracle (oracle/net_torch.py) within 1e-3 (BASELINE north_star), for the default lowering
+    (F(4x4,5x5) decoder, F(6x6,3x3) encoder) and for each optional one (F(4x4,3x3); F(6x6,5x5); direct convolution);
+  * the on-GPU instance maps of those NETWORK outputs vs the C oracle (oracle/hvn_oracle.c) bit for bit
+    (/root/reference/models/hovernet/run_desc.py:171-197 -> post_proc.py:27-90).
+
+max |activation| per stage and the measured error / margin are printed (`-s`), and quoted in DESIGN.md."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+# (HVN_WINOGRAD, HVN_WINOGRAD3_M, HVN_WINOGRAD3): decoder F(m,5) tile | encoder F(m,3) tile | 0 = no Winograd at all
+LOWERINGS = [("default", {}), ("F(4,3) encoder", {"HVN_WINOGRAD3_M": "4"}), ("F(6,5) decoder", {"HVN_WINOGRAD": "6"}),
+             ("direct convolutions", {"HVN_WINOGRAD": "0"})]
+
+
+@pytest.mark.parametrize("mode,nr_types", [("original", 5), ("fast", 6)])
+def test_fp32_parity_on_a_trained_like_checkpoint(mode, nr_types, monkeypatch):
+    import fit_util
+    from hover_net_amd import net_desc, post_proc, run_desc
+    from oracle import net_torch
+    from oracle import postproc as O
+    from pq_util import pq
+
+    size, out = (270, 80) if mode == "original" else (256, 164)
+    dens = fit_util.consep_density(size)
+    init = os.environ.get("HVN_FIT_INIT", "kaiming")
+    tnet, curve = fit_util.fit(mode, nr_types, steps=int(os.environ.get("HVN_FIT_STEPS", "240")), lr=1e-3, seed=0, init=init, density=dens)
+    assert np.mean(curve[-30:]) < 0.7 * np.mean(curve[10:40]), "the fit did not converge: %s" % curve[::40]
+    sd = {k: v.detach().cpu().clone() for k, v in tnet.state_dict().items()}
+    tnet._train_engine = None
+    del tnet
+    torch.cuda.empty_cache()
+
+    n = 4
+    imgs, anns, _typs = fit_util.painted_tiles(n, size, seed=4242, k_lo=dens[0], k_hi=dens[1], nr_types=nr_types)
+    tiles = torch.from_numpy(imgs)
+    taps = {}
+    want = net_torch.forward(sd, tiles.permute(0, 3, 1, 2).float(), mode, taps=taps)
+    want_pm = net_torch.infer_epilogue(want)
+    scale = {k: float(v.abs().max()) for k, v in taps.items()}
+    print("\n%s/%d trained-like (init %s): loss %.3f -> %.3f; max |activation| per stage: %s; max |logit| %s"
+          % (mode, nr_types, init, np.mean(curve[:10]), np.mean(curve[-10:]), " ".join("%s %.1f" % kv for kv in sorted(scale.items())),
+             " ".join("%s %.1f" % (k, float(v.abs().max())) for k, v in want.items())))
+    o = (size - out) // 2
+    truth = anns[:, o:o + out, o:o + out]
+    errs = {}
+    for name, env in LOWERINGS:
+        for k in ("HVN_WINOGRAD", "HVN_WINOGRAD3_M", "HVN_WINOGRAD3"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = net_desc.create_model(mode=mode, nr_types=nr_types, input_ch=3)
+        net.load_state_dict(sd, strict=True)
+        net.max_batch = n
+        net = net.to("cuda").eval()
+        pred = run_desc.infer_step_device(tiles, net).clone()
+        eng = net.engine(n)
+        err = max(float((eng.logits[k][:n].cpu() - want[k]).abs().max()) for k in want)
+        errs[name] = err
+        # the instance separation of the NETWORK's output: GPU vs the C oracle on the same map, bit for bit
+        inst, _, counts = post_proc.process_batch_device(pred, nr_types=nr_types)
+        pm = pred.cpu().numpy()
+        np.testing.assert_array_equal(inst.cpu().numpy(), O.proc_batch(pm))
+        if name == "default":
+            assert int(counts.sum().item()) > 0, "the fitted network emits no nuclei"
+            q = [pq(truth[i], inst[i].cpu().numpy()) for i in range(n)]
+            c0 = 1
+            dp = float((pred.cpu()[..., c0] - want_pm[..., c0]).abs().max())
+            print("  instances %d on %d tiles, PQ vs the painted truth %.3f, max |p_nuc - oracle| %.2e" % (int(counts.sum().item()), n, float(np.mean(q)), dp))
+            assert np.mean(q) > 0.5, "the fitted network does not segment: PQ vs truth %.3f" % np.mean(q)
+        del net, eng
+        torch.cuda.empty_cache()
+    print("  max |logit - oracle|: " + "; ".join("%s %.2e (margin %.0fx)" % (k, v, TOL / max(v, 1e-12)) for k, v in errs.items()))
+    for name, err in errs.items():
+        assert err <= TOL, (name, err)

@@ -120,3 +120,41 @@ def test_affine_gather_agrees_with_scipy_affine_transform():
         want_a = ndimage.affine_transform(ann[..., 0], m_rc, offset=off_rc, order=0, mode="constant", cval=0)
         both = (want_a != 0) & (got_a[..., 0] != 0)
         assert np.array_equal(want_a[both], got_a[..., 0][both])
+
+
+def test_shape_augment_sampling_equals_scipy_affine_transform():
+    """SURVEY 8f-4 / round-3 verdict item 8: the geometric half pinned against an independent library.  imgaug's `Affine(order=0,
+    cval=0, backend="cv2")` (dataloader/train_loader.py:123-150) is `cv2.warpAffine(INTER_NEAREST, BORDER_CONSTANT)` over a matrix
+    built about the image centre (w/2 - 0.5, h/2 - 0.5); neither library is on this box.  What CAN be pinned: for a given matrix, the
+    oracle's (and therefore the kernel's: tests/test_gpu_augment.py, bit for bit) nearest-neighbour / constant-0 sampling + centre crop
+    equals `scipy.ndimage.affine_transform(order=0, mode="grid-constant", cval=0)` -- the same "round the source coordinate to the
+    nearest pixel, constant outside the image" rule -- on random scale / translate / shear / rotate draws from the reference's ranges.
+    A pixel whose source coordinate lands within float rounding of x.5 may go either way (two summation orders): <= 3 per case.
+    THE LIMIT, stated: imgaug's random stream, its shear parameterisation and cv2's 10-bit fixed-point coordinate rounding are not
+    checked by anything here."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(7)
+    h = w = 96
+    out_hw = (64, 64)
+    for case in range(12):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ann = rng.integers(0, 50, (h, w, 2)).astype(np.int32)
+        m = A.affine_matrix(h, w, rng.uniform(0.8, 1.2, 2), rng.uniform(-0.01, 0.01, 2) * np.array([w, h]), rng.uniform(-5, 5), rng.uniform(-179, 179))
+        inv = np.linalg.inv(m)
+        got_img, got_ann = A.shape_augment(img, ann, inv, out_hw, False, False)
+        # scipy works in (row, col): out[r, c] = in[M @ (r, c) + off]; the centre crop is an output offset
+        y0, x0 = (h - out_hw[0]) // 2, (w - out_hw[1]) // 2
+        mat = np.array([[inv[1, 1], inv[1, 0]], [inv[0, 1], inv[0, 0]]])
+        off = np.array([inv[1, 2], inv[0, 2]]) + mat @ np.array([y0, x0], np.float64)
+        bad = 0
+        for c in range(3):
+            want = ndimage.affine_transform(img[..., c], mat, offset=off, output_shape=out_hw, order=0, mode="grid-constant", cval=0)
+            bad = max(bad, int((want != got_img[..., c]).sum()))
+        for c in range(2):
+            want = ndimage.affine_transform(ann[..., c], mat, offset=off, output_shape=out_hw, order=0, mode="grid-constant", cval=0)
+            bad = max(bad, int((want != got_ann[..., c]).sum()))
+        assert bad <= 3, (case, bad)
+    # and the flips are numpy's, applied after the crop
+    got_f, _ = A.shape_augment(img, ann, inv, out_hw, True, True)
+    np.testing.assert_array_equal(got_f, got_img[::-1, ::-1])

@@ -100,10 +100,10 @@ def test_abi_exports_every_declared_symbol():
     assert lib.hvn_version() == 102
 
 
-@pytest.mark.parametrize("env,tol", [({"HVN_CHAIN": "0"}, 1e-4), ({"HVN_FUSE_UPADD": "1"}, 1e-4), ({"HVN_WINOGRAD3_M": "6"}, 1e-4),
+@pytest.mark.parametrize("env,tol", [({"HVN_CHAIN": "0"}, 1e-4), ({"HVN_FUSE_UPADD": "1"}, 1e-4), ({"HVN_WINOGRAD3_M": "4"}, 1e-4),
                                      ({"HVN_WINOGRAD": "6", "HVN_WINOGRAD3_M": "6"}, 5e-4), ({"HVN_WINOGRAD": "0"}, 1e-4)])
 def test_plan_options_match_oracle(env, tol, monkeypatch):
-    """The lowering options next to the default -- chains off, UPADD fused into the Winograd input transform, F(6x6,3x3) /
+    """The lowering options next to the default -- chains off, UPADD fused into the Winograd input transform, F(4x4,3x3) (the default is F(6x6,3x3) since round 4) /
     F(6x6,5x5) Winograd tiles, no Winograd at all -- interpreted with torch ops equal the oracle (F(6x6,5x5): ten interpolation
     points, 2e-4 on the logits, which is why it is not the default)."""
     for k, v in env.items():
