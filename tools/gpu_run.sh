@@ -1,0 +1,34 @@
+#!/bin/bash
+# ONE entry point for GPU-box sessions:  gpurun -- 'bash tools/gpu_run.sh <target> [tag]'.  Outputs land in gpurun_out/ (scratch);
+# what is to be judged is copied to profiles/ afterwards.  tools/refresh_profiles.sh is the round-end target set.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+T=${1:-bench}; R=${2:-r04}; O=gpurun_out/${R}_${T}.log; : > $O
+bench() {   # bench <name> [env / args ...]: one bench.py run -> gpurun_out/<R>_<name>.json + its summary in the log
+  local name=$1; shift
+  SECONDS=0
+  env "${ENVV[@]}" timeout 900 python bench.py "$@" > gpurun_out/${R}_${name}.json 2> gpurun_out/${R}_${name}.err
+  echo "== bench $name (${ENVV[*]} $*) rc=$? wall=${SECONDS}s" >> $O
+  python tools/bench_summary.py gpurun_out/${R}_${name}.json >> $O 2>&1 || tail -5 gpurun_out/${R}_${name}.err >> $O
+}
+ENVV=()
+case $T in
+  first)      # round-4 first contact: trained-like parity (both inits if the first fails), the default bench line, F(6,5) A/B
+    timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
+    if ! grep -q "2 passed" $O; then
+      echo "== retry with HVN_FIT_INIT=synth" >> $O
+      HVN_FIT_INIT=synth timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
+    fi
+    bench bench_default
+    ENVV=(HVN_WINOGRAD=6); bench bench_f65 --steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random
+    ENVV=(); bench bench_random --steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random
+    ;;
+  bench)
+    bench bench_default
+    ;;
+  tests)
+    timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 >> $O
+    ;;
+  *) echo "unknown target $T" >> $O ;;
+esac
+cat $O
