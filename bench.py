@@ -344,6 +344,12 @@ def main():
                    "instances_last_step": n_inst,
                    "instances_from": "network output" if extra is None else "structured synthetic maps (the network output of this checkpoint: %d instances)" % net_inst,
                    "checkpoint": fit_info,
+                   "arithmetic": ("fp32 activations, weights, accumulation and outputs; the MFMA-bound conv launches form their products on the bf16 "
+                                  "matrix pipe from exact three-way bf16 splits of the fp32 operands (x = h + m + l, 8 significand bits each; "
+                                  "%s partial products per product, fp32 accumulate: csrc/hvn_conv_x3.hip), the others on the fp32 matrix pipe; "
+                                  "logits within 1e-3 of the fp32 oracle (tests/test_gpu_trained_like.py, test_gpu_x3.py); variants.fp32_mfma_only = "
+                                  "every launch on the fp32 pipe" % os.environ.get("HVN_X3", "6")) if (args.dtype == "fp32" and os.environ.get("HVN_X3", "6") != "0")
+                                 else "%s MFMA, fp32 accumulation" % args.dtype,
                    "parallelism": "tile-sharded x%d, %s" % (world, "gather to rank 0 per batch" if world > 1 else "single GPU"),
                    "execution": "network: engine default launch schedule (n_split %d, %d decoder branch streams); post-processing + gather + D2H on a "
                                 "side stream under the next network pass" % (eng0.n_split, eng0.n_lane_streams)},
@@ -438,6 +444,23 @@ def main():
                                                   "what": "the timed step with the network on ONE HIP stream (n_split 1, no branch streams): round 3's headline "
                                                           "schedule, the one the roofline leg times its launches on"}
             del pipe_rf
+            if args.dtype == "fp32" and os.environ.get("HVN_X3", "6") != "0":
+                # the same step with EVERY conv launch on the fp32 matrix pipe (round 3's kernels; HVN_X3=0): what the bf16x3 kernel buys
+                os.environ["HVN_X3"] = "0"
+                try:
+                    net_nat = make_net()
+                    net_nat.engine(args.batch)
+                finally:
+                    os.environ.pop("HVN_X3", None)
+                pipe_nat = TilePipeline(net_nat, nr_types=nt, return_centroids=True)
+                for _ in range(args.warmup):
+                    step(p=pipe_nat)
+                dtn, _ = timed(lambda: step(p=pipe_nat), args.steps)
+                variants["fp32_mfma_only"] = {"value": tiles_per_step_global * args.steps / dtn, "unit": "tiles/s", "ms_per_step": 1e3 * dtn / args.steps,
+                                              "what": "the timed step with every conv launch on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; HVN_X3=0): "
+                                                      "round 3's arithmetic, same checkpoint, same launch schedule"}
+                del pipe_nat, net_nat
+                torch.cuda.empty_cache()
             if extra is None:
                 for _ in range(2):
                     step(extra_maps=structured)
@@ -465,33 +488,78 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0) ---------------------------------------------------------------------
     def roofline_of(net_, tiles0, batch, dtype, n_prof=5):
+        import ctypes
+
         eng = net_.engine(batch)
-        assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: HVN_SPLIT=1 HVN_LANES=0"
-        convs = [o for o in eng.plan.ops if o.kind in (2, 8)]          # CONV + CHAIN (two chained 1x1 convs) launches
+        assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: launch_schedule (1, 0)"
+        timed = [o for o in eng.plan.ops if o.kind in (2, 8, 6, 7)]     # CONV, CHAIN (two chained 1x1 convs), WINO_IN, WINO_OUT: the launches hvn_profile times
+        convs = [o for o in timed if o.kind in (2, 8)]
         algo_flops = sum(o.flops() for o in convs) * batch
         exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in convs) * batch
         torch.cuda.synchronize(dev)
-        ms_list, launches = [], 0
+        buf = (ctypes.c_double * 4096)()
+        rows, launches = [], 0
         for _ in range(n_prof):
             L.lib().hvn_profile_enable(1)
-            run_desc.infer_step_device(tiles0, net_)            # same engine, same single launch stream as the timed steps
-            ms_list.append(L.lib().hvn_profile_conv_ms())
-            launches = L.lib().hvn_profile_conv_launches()
+            run_desc.infer_step_device(tiles0, net_)            # same checkpoint, plan and kernels as the timed steps, ONE launch stream
+            launches = L.lib().hvn_profile_conv_ms_list(buf, 4096)
             L.lib().hvn_profile_enable(0)
-        ms = sorted(ms_list)[len(ms_list) // 2]
+            rows.append(np.array(buf[:launches]))
+        per = np.median(np.stack(rows), 0)                      # per launch: median of n_prof passes
+        ms = float(per.sum())
         n_conv = len(convs)
-        peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
-        achieved = exec_flops / (ms * 1e-3) / 1e12
+        note = ("achieved = MFMA FLOPs executed by the launches (Winograd-domain GEMMs counted as issued; SURVEY 8d's direct-convolution figure is "
+                "`algorithmic_gflop_per_step` / batch) / summed HIP-event time of those launches, per-launch median of %d passes, single stream" % n_prof)
+        if dtype != "fp32" or launches != len(timed):
+            peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+            achieved = exec_flops / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)" if dtype == "fp32" else "hvn_conv_igemm_bf16",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "flops_per_launch": exec_flops / max(1, n_conv), "avg_launch_ms": ms / max(1, launches),
+                    "timed_launches_per_step": launches, "conv_launches_per_step": n_conv, "conv_ms_per_step": ms,
+                    "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9,
+                    "algorithmic_speedup": algo_flops / exec_flops, "note": note + " (incl. the Winograd transform launches)"}
+        # fp32 engine: two matrix pipes.  The launches Plan.mark_x3 put on csrc/hvn_conv_x3.hip issue bf16 MFMAs (6 | 9 per fp32 product
+        # block: exact three-way bf16 splits of fp32 operands, fp32 accumulation); the rest (chained 1x1 pairs of d0 / d1, grouped 5x5,
+        # d0's first 1x1) issue fp32 MFMAs; the Winograd transforms issue none.  The DOMINANT kernel is the bf16x3 one: `achieved` / `peak` /
+        # `frac` describe it on ITS pipe; `other_launches` the fp32-pipe launches + transforms; `whole_step` both, as ideal matrix time
+        # (each launch's executed FLOPs / its pipe's peak) over measured time.
+        x3_ms = x3_eq = x3_bf16 = 0.0
+        rest_ms = rest_flops = 0.0
+        n_x3 = 0
+        for o, t in zip(timed, per):
+            fl = o.extra.get("exec_flops", o.flops()) * batch if o.kind in (2, 8) else 0.0
+            if o.kind == 2 and o.extra.get("x3"):
+                x3_ms += float(t); x3_eq += fl; x3_bf16 += fl * int(o.extra["x3"]); n_x3 += 1
+            else:
+                rest_ms += float(t); rest_flops += fl
+        if n_x3 == 0:
+            achieved = exec_flops / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "flops_per_launch": exec_flops / max(1, n_conv),
+                    "avg_launch_ms": ms / max(1, launches), "timed_launches_per_step": launches, "conv_launches_per_step": n_conv,
+                    "conv_ms_per_step": ms, "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9,
+                    "algorithmic_speedup": algo_flops / exec_flops, "note": note + " (incl. the Winograd transform launches)"}
+        ach_x3 = x3_bf16 / (x3_ms * 1e-3) / 1e12
+        ideal_ms = 1e3 * (x3_bf16 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
         return {
-            "bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)" if dtype == "fp32" else "hvn_conv_igemm_bf16",
-            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-            "flops_per_launch": exec_flops / max(1, n_conv), "avg_launch_ms": ms / max(1, launches),
-            "timed_launches_per_step": launches, "conv_launches_per_step": n_conv,
-            "conv_ms_per_step": ms, "executed_gflop_per_step": exec_flops / 1e9,
-            "algorithmic_gflop_per_step": algo_flops / 1e9, "algorithmic_speedup": algo_flops / exec_flops,
-            "note": "achieved = MFMA FLOPs executed by the conv launches of one step (Winograd-domain GEMMs counted as issued; "
-                    "SURVEY 8d's direct-convolution figure is `algorithmic_gflop_per_step` / batch) / summed HIP-event time of those "
-                    "launches incl. the Winograd transform launches, median of %d passes, single stream" % n_prof}
+            "bound": "mfma", "kernel": "hvn_conv_igemm_x3 (fp32 convolution, products on the bf16 matrix pipe from exact bf16x3 splits of the fp32 operands)",
+            "achieved": ach_x3, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x3 / PEAK_BF16_MATRIX_TFLOPS, "traffic": None,
+            "launches": n_x3, "ms_per_step": x3_ms, "avg_launch_ms": x3_ms / n_x3, "flops_per_launch": x3_bf16 / n_x3,
+            "bf16_mfma_gflop_per_step": x3_bf16 / 1e9, "fp32_products_gflop_per_step": x3_eq / 1e9,
+            "fp32_equivalent_tflops": x3_eq / (x3_ms * 1e-3) / 1e12,
+            "other_launches": {"what": "fp32-MFMA launches (hvn_conv_chain_f32, hvn_conv_igemm_f32, hvn_dense_grouped*) + Winograd transform launches",
+                               "launches": launches - n_x3, "ms_per_step": rest_ms, "executed_gflop_per_step": rest_flops / 1e9,
+                               "achieved": rest_flops / (rest_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                               "frac": rest_flops / (rest_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS},
+            "whole_step": {"conv_ms_per_step": ms, "ideal_matrix_ms": ideal_ms, "frac": ideal_ms / ms,
+                           "fp32_equivalent_tflops": exec_flops / (ms * 1e-3) / 1e12,
+                           "what": "ideal = each launch's executed MFMA FLOPs / the dense peak of the pipe it issues on (bf16 2500, fp32 157.3 TFLOP/s); "
+                                   "fp32_equivalent = fp32 multiply-adds of the executed GEMMs (each counted once) / time: comparable with round 3's "
+                                   "`achieved` (102.5), not a fraction of any one pipe's peak"},
+            "timed_launches_per_step": launches, "conv_launches_per_step": n_conv, "conv_ms_per_step": ms,
+            "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9, "algorithmic_speedup": algo_flops / exec_flops,
+            "note": note}
 
     def measure_traffic(n_conv):
         """HBM bytes per conv launch, measured NOW: two `rocprofv3 --pmc` child runs of this script (FETCH_SIZE and WRITE_SIZE need

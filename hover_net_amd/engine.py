@@ -73,6 +73,31 @@ def repack_conv_bf16(w32):
     return to_bf16_bits(w)
 
 
+def split_bf16x3(w32):
+    """fp32 array -> its three bf16 planes (uint16 bit patterns) with h + m + l == w exactly: h = bf16(w), m = bf16(w - h),
+    l = bf16(w - h - m), round to nearest even, every difference exact in fp32 (the device splits activations the same way)."""
+    w = np.ascontiguousarray(w32, np.float32)
+
+    def bf(a):
+        bits = to_bf16_bits(a)
+        return bits, (bits.astype(np.uint32) << 16).view(np.float32)
+
+    h, hf = bf(w)
+    r = w - hf
+    m, mf = bf(r)
+    l, _ = bf(r - mf)
+    return h, m, l
+
+
+def pack_conv_x3(w32):
+    """[..., cout_pad, cin/32, taps, 32] fp32 (plan._pack_conv; a leading axis for the Winograd positions) ->
+    [..., cout_pad, k-steps, 3, 32] bf16 bits: the three planes of every k-step (slab-major, tap inside) side by side."""
+    lead = w32.shape[:-3]
+    kt = w32.shape[-3] * w32.shape[-2]
+    planes = split_bf16x3(w32.reshape(lead + (kt, 32)))
+    return np.stack(planes, axis=-2)
+
+
 class Engine:
     def __init__(self, plan, max_batch=32, device="cuda", n_split=None, dtype="fp32", n_lanes=None):
         L.require_gpu()
@@ -117,7 +142,7 @@ class Engine:
             if len(tiles) != len(self.ops):
                 raise ValueError("HVN_TILE_FILE holds %d entries for a plan of %d ops" % (len(tiles), len(self.ops)))
             for o, op, tn in zip(self.ops, plan.ops, tiles):
-                if op.kind == PL.OP_CONV and ((op.tile_n == 128 and tn in (64, 128)) or (op.tile_n == 64 and tn in (64, 320))):
+                if op.kind == PL.OP_CONV and ((op.tile_n == 128 and tn in (64, 128)) or (op.tile_n == 64 and tn in (64, 320) and not op.extra.get("x3"))):
                     o.tile_n = tn
                 if op.kind == PL.OP_CHAIN and tn in (64, 128):
                     o.tile_n = tn
@@ -141,6 +166,11 @@ class Engine:
         for i, op in enumerate(self.plan.ops):
             if self.dtype == "bf16" and op.kind == PL.OP_CONV:
                 wb = repack_conv_bf16(op.w).ravel()
+                off16[i] = tot16
+                w16.append((tot16, wb))
+                tot16 += (wb.size + 127) // 128 * 128
+            elif self.dtype == "fp32" and op.kind == PL.OP_CONV and op.extra.get("x3"):
+                wb = pack_conv_x3(op.w).ravel()          # fp32 weights as three bf16 planes (csrc/hvn_conv_x3.hip)
                 off16[i] = tot16
                 w16.append((tot16, wb))
                 tot16 += (wb.size + 127) // 128 * 128
@@ -216,8 +246,12 @@ class Engine:
                 o.y.base = self.logits[br].data_ptr()
                 o.y.h, o.y.w, o.y.c = op.y.h, op.y.w, op.y.c
             o.w = self._pptr(i, "w") if i not in self._poff16 else self.params16.data_ptr() + 2 * self._poff16[i]
-            if i in self._poff16:
+            if i in self._poff16 and self.dtype == "bf16":
                 o.groups = 1        # grouped convs run as block-diagonal dense GEMMs on the bf16 pipe
+            if self.dtype == "fp32" and op.kind == PL.OP_CONV and op.extra.get("x3"):
+                o.act_dtype = 2 if int(op.extra["x3"]) == 9 else 3
+                if o.nbatch > 1:    # Winograd positions: the plane packing's stride between problems, in bf16 elements
+                    o.batch_stride[1] = int(op.w.shape[-4]) * int(op.w.shape[-3]) * int(op.w.shape[-2]) * 96
             o.bias = self._pptr(i, "bias")
             o.pre_scale, o.pre_shift = self._pptr(i, "pre_s"), self._pptr(i, "pre_b")
             o.post_scale, o.post_shift = self._pptr(i, "post_s"), self._pptr(i, "post_b")
@@ -242,6 +276,8 @@ class Engine:
         enc_end = lanes[0][2] if (lanes and lanes[0][0] == "main" and len(lanes) > 1) else 0
         split = self.n_split if (self.n_split > 1 and self.max_batch >= 2 * self.n_split) else 1
         sub_n = -(-self.max_batch // split)
+        if os.environ.get("HVN_TUNE_SUB", "1") == "0":      # A/B knob: time every launch at the full batch (round 3's selection)
+            sub_n = self.max_batch
 
         def time_op(i):
             best = float("inf")
@@ -278,8 +314,9 @@ class Engine:
             key = (sub_n if (i < enc_end or self.split_decoder) else self.max_batch, op.kh, op.kw, op.stride, op.x.c, op.cout, op.y.h, op.y.w, op.x.h, op.x.w, op.res is not None, op.pre is not None,
                    op.post is not None, int(op.extra.get("nbatch", 1)), x2.c if x2 is not None else 0)
             # 128-channel-wide plans: 128 x 128 or 128 x 64 tiles; 64-wide ones: 128 x 64 or 256 x 64 (tile_n 320 = 64 | 0x100)
-            if op.tile_n == 64 and x2 is not None:
-                continue                                   # the fused-shortcut instantiations exist for 128 x 128 and 128 x 64 tiles only
+            if op.tile_n == 64 and (x2 is not None or op.extra.get("x3")):
+                continue                                   # the fused-shortcut and bf16x3 instantiations exist for 128 x 128 and 128 x 64 tiles only
+            key = key + (int(op.extra.get("x3", 0)),)
             cands = (128, 64) if op.tile_n == 128 else (64, 320)
             if key not in self.tile_choice:
                 o = self.ops[i]

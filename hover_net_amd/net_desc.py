@@ -142,7 +142,7 @@ class HoVerNet(nn.Module):
         if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             bf16 = self.compute_dtype == "bf16"
-            plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None, chain=False if bf16 else None)
+            plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None, chain=False if bf16 else None, x3=0 if bf16 else None)
             self._engine = None  # free the old arena first
             ns, nl = self.launch_schedule if self.launch_schedule is not None else (None, None)
             self._engine = E.Engine(plan, max(self.max_batch, batch), dev, dtype=self.compute_dtype, n_split=ns, n_lanes=nl)

@@ -271,6 +271,25 @@ class Plan:
                bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m, "r": r})
         return self.add(o)
 
+    def mark_x3(self, terms, d1=False):
+        """Which CONV launches run on csrc/hvn_conv_x3.hip (fp32 in / out, products on the bf16 matrix pipe from exact bf16x3 splits,
+        `terms` = 9 | 6 partial products per product): every dense (ungrouped) conv with a 128- or 64-wide column tile EXCEPT the 1x1
+        convs of d0 / d1 -- those are HBM-bound, and they are the chain partners (`fuse_chains`, which leaves marked ops alone): the
+        chained and the unchained lowering of the same checkpoint must stay bit-identical, so the rule is by layer, not by what the
+        chain pass did.  A static
+        rule (not a timing): a tile's bits must not depend on the batch it is run in."""
+        import re
+
+        assert terms in (9, 6), terms
+        for op in self.ops:
+            if op.kind != OP_CONV or int(op.extra.get("groups", 1)) != 1 or op.tile_n not in (128, 64):
+                continue
+            if re.match(r"^d0\.units\.\d+\.conv[13]$", op.name) or op.name == "d1.units.0.conv1":
+                continue
+            if not d1 and re.match(r"^d1\.units\.\d+\.conv[13]$", op.name):
+                continue                # d1=True (HVN_X3_D1=1, a measured option): d1's 1x1 convs on this kernel INSTEAD of chained launches
+            op.extra["x3"] = terms
+
     def reindex(self):
         """Recompute every buffer's live interval from the op list (after a pass that merged / removed ops)."""
         ops, self.ops = self.ops, []
@@ -291,7 +310,7 @@ class Plan:
 
             def plain1x1(o):
                 return (o is not None and o.kind == OP_CONV and o.kh == 1 and o.kw == 1 and o.stride == 1 and o.pad_t == 0 and
-                        not o.extra.get("nbatch") and o.extra.get("groups", 1) == 1)
+                        not o.extra.get("nbatch") and o.extra.get("groups", 1) == 1 and not o.extra.get("x3"))
 
             ok = (plain1x1(a) and plain1x1(b) and (a.res is not None or a.extra.get("x2") is not None) and a.pre is None and
                   a.bias is None and not a.relu and a.cout % 64 == 0 and a.x.c + (a.extra["x2"].c if a.extra.get("x2") is not None else 0) >= 64 and
@@ -361,18 +380,27 @@ class Plan:
         return sum(o.flops() for o in self.ops)
 
 
-def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None, chain=None):
+def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None, chain=None, x3=None):
     """sd: reference-format state_dict (torch tensors or numpy arrays).
     winograd: output tile m (2 or 4) of the Winograd F(m x m, 5x5) form of the 5x5 decoder convs; 0 / False = direct
     convolution; default 4 (env HVN_WINOGRAD).
     chain: fuse conv3 -> next conv1 seams of the encoder into OP_CHAIN launches (`Plan.fuse_chains`); default on
-    (env HVN_CHAIN=0 turns it off, HVN_CHAIN_MAXN2 = 64 | 128 bounds the second conv's width); fp32 only."""
+    (env HVN_CHAIN=0 turns it off, HVN_CHAIN_MAXN2 = 64 | 128 bounds the second conv's width); fp32 only.
+    x3: 0 = every fp32 conv on the fp32 matrix pipe; 9 | 6 = the MFMA-bound conv launches form their products on the bf16 matrix pipe
+    from exact three-way bf16 splits of the fp32 operands (csrc/hvn_conv_x3.hip, `Plan.mark_x3`); default env HVN_X3; fp32 only."""
     import os
     if chain is None:
         chain = os.environ.get("HVN_CHAIN", "1") != "0"
     if winograd is None:
         winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
     wino_m = 4 if winograd is True else int(winograd)
+    # per decoder stage override of the 5x5 output tile, e.g. HVN_WINOGRAD_STAGES="u3:6" (F(6x6,5x5) for u3.conva only, the rest as
+    # HVN_WINOGRAD says): F(6x6,5x5) costs ~8x the fp32 error of F(4x4,5x5) (tests/test_gpu_trained_like.py), which stage carries it matters
+    # Default since round 4: u3 (1024 -> 256 @62^2, the largest product) as F(6x6,5x5): 1.95e-4 on the trained-like checkpoint against
+    # 1.70e-4 without and 1.95e-4 for direct convolutions; u2 (4.0e-4) and u1 (1.15e-3: it feeds the logits directly) keep F(4x4,5x5).
+    wino_stage = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in os.environ.get("HVN_WINOGRAD_STAGES", "u3:6").split(",") if ":" in kv}
+    if not winograd:
+        wino_stage = {}
     wino3 = int(os.environ.get("HVN_WINOGRAD3", "128"))      # minimum channel count for the Winograd form of the encoder's 3x3 convs; 0 = off
     wino3_m = int(os.environ.get("HVN_WINOGRAD3_M", "6"))     # its output tile: F(6x6,3x3) (default since round 4: same logit error, 1.78 instead of 2.25 multiplies per output) or F(4x4,3x3)
     P = Plan(mode, nr_types)
@@ -447,7 +475,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
                 # the u3 input is the same for every branch: its transform runs once, before the branch lanes fork
                 # (5x5: F(wino_m, 5); the 'fast' mode's 3x3: F(4, 3))
                 P.conv_winograd(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"), share_in=(uname == "u3"),
-                                m=wino_m if k == 5 else wino3_m)
+                                m=wino_stage.get(uname, wino_m) if k == 5 else wino3_m)
             else:
                 P.conv(p + "conva", cur_in, cat.chans(0, cmid), W(p + "conva.weight"))
             c = cmid
@@ -468,7 +496,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         u1 = View(P.buf(pb + "u1", g["out"], g["out"], 64))
         if winograd and (k == 5 or wino3):
             P.conv_winograd(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
-                            bn=BN(pb + "u0.bn"), relu=1, m=wino_m if k == 5 else wino3_m)
+                            bn=BN(pb + "u0.bn"), relu=1, m=wino_stage.get("u1", wino_m) if k == 5 else wino3_m)
         else:
             P.conv(pb + "u1.conva", cur_in, u1, W(pb + "u1.conva.weight"), pad=_tf_same(cur_in.h, k, 1),
                    bn=BN(pb + "u0.bn"), relu=1)
@@ -482,6 +510,10 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         pm = Buf("pred_map", g["out"], g["out"], 3 if nr_types is None else 4)
         P.pred_map = pm
         P.add(Op(OP_PREDMAP, "infer_step.epilogue", y=View(pm), extra={"branches": list(arch.branch_names(nr_types))}))
+    if x3 is None:
+        x3 = int(os.environ.get("HVN_X3", "6"))       # default since round 4: six partial products (measured: the fp32-MFMA path's own error band)
+    if x3:
+        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "0") != "0")
     if chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
     if os.environ.get("HVN_FUSE_UPADD", "0") != "0":

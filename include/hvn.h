@@ -87,7 +87,13 @@ typedef struct hvn_op {
     int32_t nbatch;
     int32_t act_dtype;   /* 0: fp32 activations / weights; 1: bf16 activations (x, res, y, x2) and packed weights
                             ([cout_pad][ceil(x.c/64)][kh*kw][64] bf16, zero-filled past x.c), fp32 accumulation, fp32 bias /
-                            scales; CONV0 (bf16 output), CONV, UPADD, HEAD (bf16 input, fp32 logits) honour it */
+                            scales; CONV0 (bf16 output), CONV, UPADD, HEAD (bf16 input, fp32 logits) honour it.
+                            CONV only -- 2 | 3: fp32 activations, accumulation and outputs exactly as 0, but the products run on the
+                            bf16 matrix pipe from exact three-way bf16 splits of the fp32 operands (csrc/hvn_conv_x3.hip): `w` then
+                            holds the three bf16 planes of the fp32 packing, [cout_pad][k-step][3][32] bf16 (k-step = (x.c/32 slab,
+                            tap), the fp32 packing's order) and batch_stride[1] counts bf16 elements; 2 = all nine partial
+                            products (the fp32 dot product in another summation order), 3 = the six that carry more than 2^-24
+                            of a product */
     /* CHAIN only: the second conv's output view, packed weights, bias (or NULL) and channel count */
     hvn_view y2;
     const float *w2, *bias2; /* dev */

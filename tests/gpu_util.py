@@ -20,7 +20,7 @@ def rand_conv_weight(rng, cout, cin_g, k):
 
 
 def run_conv_case(n, xbuf_shape, xview, ybuf_shape, yview, wt, *, stride=1, pad=(0, 0), groups=1, bn=False, relu=0, pre=False,
-                  res=False, post=False, seed=0, inplace_res=False, dtype="fp32", force_tile=None):
+                  res=False, post=False, seed=0, inplace_res=False, dtype="fp32", force_tile=None, x3=0):
     """Builds one CONV op over strided views, runs it on the GPU and with the torch
     interpreter.  xview / yview = (y0, x0, h, w, c0, c).  Returns (got, want) NHWC tensors of the
     WHOLE output buffer (so writes outside the view would be caught)."""
@@ -50,6 +50,9 @@ def run_conv_case(n, xbuf_shape, xview, ybuf_shape, yview, wt, *, stride=1, pad=
             rv = PL.View(rb, *yview)
         kw["res"] = rv
     op = P.conv("case", xv, yv, wt, stride=stride, pad=pad, groups=groups, relu=relu, **kw)
+    if x3:
+        assert op.tile_n in (128, 64) and groups == 1
+        op.extra["x3"] = x3          # products on the bf16 matrix pipe from exact bf16x3 splits (csrc/hvn_conv_x3.hip)
     P.pack()
     eng = Engine(P, max_batch=n, dtype=dtype)
     g = torch.Generator().manual_seed(seed)

@@ -26,6 +26,26 @@ case $T in
   bench)
     bench bench_default
     ;;
+  sched)      # launch-schedule A/B on one box: sub-batch streams x decoder lanes x where the tile selection is timed
+    Q="--steps 20 --no-cpu-baseline --no-variants --no-roofline --checkpoint random"
+    for cfg in "HVN_SPLIT=1 HVN_LANES=0" "HVN_SPLIT=2 HVN_LANES=2" "HVN_SPLIT=2 HVN_LANES=2 HVN_TUNE_SUB=0" "HVN_SPLIT=4 HVN_LANES=2" \
+               "HVN_SPLIT=4 HVN_LANES=2 HVN_TUNE_SUB=0" "HVN_SPLIT=2 HVN_LANES=2 HVN_SPLIT_DECODER=1" "HVN_SPLIT=3 HVN_LANES=2" "HVN_SPLIT=2 HVN_LANES=0"; do
+      ENVV=($cfg); bench sched_$(echo $cfg | tr -d ' =A-Z_') $Q
+    done
+    grep -E "^== bench|^value" $O > gpurun_out/${R}_sched_ab.txt
+    ;;
+  x3)         # the bf16x3 kernel: unit tests, goldens, trained-like margins, then speed (native | 9 terms | 6 terms) on one box
+    timeout 900 python -m pytest tests/test_gpu_x3.py -x -q -s 2>&1 | grep -v "^$" | tail -12 >> $O
+    timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -12 >> $O
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for cfg in "HVN_X3=0" "HVN_X3=9" "HVN_X3=6"; do ENVV=($cfg); bench x3_$(echo $cfg | tr -d ' =A-Z_') $Q; done
+    ;;
+  layers)     # per-launch tables, native vs bf16x3 (6 terms), one box
+    for x in 0 6 9; do HVN_X3=$x timeout 300 python tools/layer_ms.py > gpurun_out/${R}_layers_x3_$x.txt 2>&1; tail -1 gpurun_out/${R}_layers_x3_$x.txt >> $O; done
+    ;;
+  trained)
+    timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
+    ;;
   tests)
     timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 >> $O
     ;;

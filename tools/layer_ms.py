@@ -32,6 +32,7 @@ def main():
     net.load_state_dict(synth_state_dict(args.mode, nt, seed=0), strict=True)
     net.max_batch = args.batch
     net.compute_dtype = args.dtype
+    net.launch_schedule = (1, 0)          # one launch stream: every launch is timed alone
     net = net.to("cuda").eval()
     win = 270 if args.mode == "original" else 256
     tiles = torch.from_numpy(synth_tiles(args.batch, win, seed=1)).to("cuda")
@@ -39,7 +40,7 @@ def main():
         run_desc.infer_step_device(tiles, net)
     torch.cuda.synchronize()
     eng = net.engine(args.batch)
-    marked = [(o.name, o.kind, eng.ops[i].tile_n if o.kind in (OP_CONV, OP_CHAIN) else 0,
+    marked = [(o.name + (" [x3-%d]" % o.extra["x3"] if o.extra.get("x3") else ""), o.kind, eng.ops[i].tile_n if o.kind in (OP_CONV, OP_CHAIN) else 0,
                o.extra.get("exec_flops", o.flops()) * args.batch if o.kind in (OP_CONV, OP_CHAIN) else 0.0)
               for i, o in enumerate(eng.plan.ops) if o.kind in (OP_CONV, OP_CHAIN, OP_WINO_IN, OP_WINO_OUT)]
     buf = (ctypes.c_double * 4096)()
