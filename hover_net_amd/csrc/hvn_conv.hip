@@ -669,9 +669,17 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream)
 {
     if (a.Cin % BK != 0 || a.Cin <= 0 || a.Cout % 4 != 0) return -1;
     if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;  // 32-bit pixel index arithmetic in the kernel
-    // 32-bit per-thread byte offsets: a tile spans at most two consecutive samples of the input view
-    const long span = 2 * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
-    if (span < 0 || span * 4 >= (1L << 32)) return -1;
+    // 32-bit per-thread byte offsets relative to the sample of the tile's first row; 2^31 and beyond is the "load zeros" range of the
+    // buffer descriptor.  A tile of bm rows reaches (HoWo + bm - 2) / HoWo samples ahead -- ONE when a sample holds a tile's worth of
+    // pixels, FOUR for a Winograd-domain product with 36 tiles per sample: with the arena's 0.5 GB sample stride that is beyond the
+    // reach, and rows would silently read zeros (round 4: the F(6x6,3x3) product of d3 in 'fast' mode).  Refused here instead.
+    const int bm = tile_n == 320 ? 256 : 128;
+    const long howo = (long)a.Ho * a.Wo;
+    if (howo <= 0) return -1;
+    const long ahead = (howo + bm - 2) / howo;
+    const long span = ahead * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
+    if (span < 0 || span * 4 >= (1L << 31)) return -1;
+    if (a.x2 && (ahead * a.x2sn + (long)a.H * a.x2sy * a.stride2) * 4 >= (1L << 31)) return -1;
     if ((long)(a.Cout + 128) * a.KH * a.KW * a.Cin * 4 >= (1L << 32)) return -1;
     // "padded" = some tap of some output pixel falls outside the input window
     const bool padded = a.pad_t > 0 || a.pad_l > 0 || (a.Ho - 1) * a.stride - a.pad_t + a.KH > a.H ||

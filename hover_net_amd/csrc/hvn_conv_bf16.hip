@@ -372,7 +372,10 @@ int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream)
     if (a.Cin % 32 != 0 || a.Cin <= 0 || a.Cout % 8 != 0 || a.nbatch > 1) return -1;
     if ((((uintptr_t)a.y) & 15) || ((a.ysn | a.ysy | a.ysx) & 7) || (a.res && ((((uintptr_t)a.res) & 15) || ((a.rsn | a.rsy | a.rsx) & 7)))) return -1;   // 16-byte epilogue accesses
     if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
-    const long span = 2 * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
+    const long howo = (long)a.Ho * a.Wo;
+    if (howo <= 0) return -1;
+    const long ahead = (howo + 126) / howo;      // samples a 128-row tile reaches beyond its first row's (hvn_launch_conv)
+    const long span = ahead * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
     if (span < 0 || span * 2 >= (1L << 31)) return -1;
     const long kt = (long)a.KH * a.KW * ((a.Cin + BKH - 1) / BKH) + (a.x2 ? a.Cin2 / BKH : 0);
     if ((long)(a.Cout + 128) * kt * BKH * 2 >= (1L << 31)) return -1;

@@ -391,8 +391,13 @@ int hvn_launch_conv_x3(const ConvArgs &a, int tile_n, int terms, hipStream_t str
 {
     if (a.Cin % XK != 0 || a.Cin <= 0 || a.Cout % 4 != 0 || a.groups > 1) return -1;
     if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
-    const long span = 2 * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
+    // a 128-row tile reaches (HoWo + 126) / HoWo samples ahead of its first row's sample (hvn_launch_conv): 32-bit offsets below 2^31
+    const long howo = (long)a.Ho * a.Wo;
+    if (howo <= 0) return -1;
+    const long ahead = (howo + 126) / howo;
+    const long span = ahead * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
     if (span < 0 || span * 4 >= (1L << 31)) return -1;
+    if (a.x2 && (ahead * a.x2sn + (long)a.H * a.x2sy * a.stride2) * 4 >= (1L << 31)) return -1;
     const long kt = (long)a.KH * a.KW * (a.Cin / XK) + (a.x2 ? a.Cin2 / XK : 0);
     if ((long)(a.Cout + 128) * kt * 192 >= (1L << 31)) return -1;
     const bool padded = a.pad_t > 0 || a.pad_l > 0 || (a.Ho - 1) * a.stride - a.pad_t + a.KH > a.H ||

@@ -238,6 +238,11 @@ class Plan:
         assert kh == kw and (kh, m) in ((5, 2), (5, 4), (5, 6), (3, 4), (3, 6)) and x.c == cin and y.c == cout
         r = kh
         assert y.h == x.h + pad[0] + pad[1] - (r - 1)
+        if m == 6 and -(-y.h // 6) * -(-y.w // 6) < 64:
+            # Few tiles per sample (d3: 33^2 | 32^2 -> 36): a 128-row tile of the transform-domain product then reaches 4 samples
+            # ahead, and with the arena's sample stride (0.5 .. 0.8 GB) that is beyond the kernels' 32-bit offsets (the launchers
+            # refuse it since round 4; before, 'fast' mode at batch >= 8 silently read zeros there).  F(4x4, r x r) has 64 .. 81.
+            m = 4
         at, _g, bt = WG.mats(m, r)
         n2 = (m + r - 1) ** 2
         s = b = None

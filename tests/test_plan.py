@@ -129,3 +129,23 @@ def test_stale_library_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(lib, "_LIB", None)
     with pytest.raises(lib.HvnError, match="built from other sources"):
         lib.lib()
+
+
+@pytest.mark.parametrize("mode,nt", [("original", 5), ("fast", 6), ("original", None)])
+def test_every_conv_launch_stays_inside_the_kernels_32bit_reach(mode, nt):
+    """The conv kernels address a tile's rows with 32-bit byte offsets relative to the sample of its first row (2^31 and beyond is the
+    descriptor's "load zeros" range).  A 128-row tile reaches (HoWo + 126) // HoWo samples ahead: one for every spatial conv, but FOUR
+    for a Winograd-domain product with 36 tiles per sample -- at the arena's sample stride that left the reach ('fast' mode d3 under
+    F(6x6,3x3), round 4: samples 31 and 63 of a batch of 64 read zeros).  `Plan.conv_winograd` keeps F(4x4) for such layers and the
+    launchers refuse a violating launch; this pins the plan side for the default lowering of every configuration."""
+    P = PL.build_plan(synth_state_dict(mode, nt, seed=0), mode, nt)
+    for o in P.ops:
+        if o.kind not in (PL.OP_CONV, PL.OP_CHAIN):
+            continue
+        howo = o.y.h * o.y.w
+        ahead = (howo + 126) // howo
+        assert ahead * P.arena_per_sample * 4 < 2 ** 31, (o.name, howo, ahead, P.arena_per_sample)
+    d3 = [o for o in P.ops if o.kind == PL.OP_WINO_IN and o.name.startswith("d3.")]
+    assert d3 and all(o.extra["m"] == 4 for o in d3)
+    d2 = [o for o in P.ops if o.kind == PL.OP_WINO_IN and o.name.startswith("d2.")]
+    assert d2 and all(o.extra["m"] == 6 for o in d2)

@@ -43,6 +43,12 @@ case $T in
   layers)     # per-launch tables, native vs bf16x3 (6 terms), one box
     for x in 0 6 9; do HVN_X3=$x timeout 300 python tools/layer_ms.py > gpurun_out/${R}_layers_x3_$x.txt 2>&1; tail -1 gpurun_out/${R}_layers_x3_$x.txt >> $O; done
     ;;
+  core)       # the GPU tests every kernel / lowering change touches + the default bench line + the d1-on-bf16x3 option
+    timeout 1200 python -m pytest tests/test_gpu_net.py tests/test_gpu_chain.py tests/test_gpu_bench_shapes.py tests/test_gpu_x3.py tests/test_gpu_conv.py -x -q 2>&1 | tail -6 >> $O
+    bench bench_default
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for cfg in "HVN_X3_D1=0" "HVN_X3_D1=1"; do ENVV=($cfg); bench d1_$(echo $cfg | tr -d ' =A-Z_') $Q; done
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
