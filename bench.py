@@ -174,11 +174,17 @@ def main():
         args.no_roofline = args.no_cpu_baseline = True
         torch.cuda.synchronize = lambda *a, **k: None       # nothing to wait for: the stand-in pipeline is synchronous
     else:
+        # HVN_BENCH_SHARED_GPU=1 (tests/test_gpu_two_ranks_one_gpu.py): every rank on cuda:0, collectives over gloo with device tensors staged
+        # through the host -- the driver's exact N-rank command path with the real kernels on a one-GPU box; measures nothing comparable
+        shared = os.environ.get("HVN_BENCH_SHARED_GPU", "0") != "0"
+        local = 0 if shared else local
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+    shared_gpu = (not selftest) and os.environ.get("HVN_BENCH_SHARED_GPU", "0") != "0"
+    cdev = torch.device("cpu") if (selftest or shared_gpu) else dev          # where the small control collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if selftest:
+        if selftest or shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -293,7 +299,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out
@@ -311,7 +317,7 @@ def main():
     if world > 1:
         # diagnosis of a bad scaling curve from ONE run: every rank's own step time (its clock stops when its own last result is on
         # the host, before the closing barrier) and the mean duration of its `gather` call on the side stream
-        mine = torch.tensor([1e3 * last_rank_dt[0] / args.steps, pipe.gather_ms()], dtype=torch.float64, device=dev)
+        mine = torch.tensor([1e3 * last_rank_dt[0] / args.steps, pipe.gather_ms()], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {"step_ms": [float(t[0]) for t in allr], "gather_ms": [float(t[1]) for t in allr],
@@ -331,7 +337,7 @@ def main():
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
-        "data": "synthetic",
+        "data": "synthetic" if not shared_gpu else "synthetic (HVN_BENCH_SHARED_GPU: all ranks on ONE GPU over gloo -- a control-path run, not a measurement)",
         "config": {"workload": "CoNSeP '%s' mode seg+class (NP+HV+NC, %s types), batch %d of %dx%d uint8 %s tiles per GPU resident in HBM, "
                                "%s checkpoint%s: network + infer_step epilogue + on-GPU instance separation and instance table of %s, %s"
                                "D2H of instance maps + records to pinned host memory"
@@ -475,7 +481,7 @@ def main():
             for _ in range(args.steps):
                 step()
             reps += args.steps
-            flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=dev)
+            flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=cdev)
             if world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if flag.item() == 0.0:

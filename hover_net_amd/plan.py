@@ -276,13 +276,13 @@ class Plan:
                bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m, "r": r})
         return self.add(o)
 
-    def mark_x3(self, terms, d1=False):
+    def mark_x3(self, terms, d1=True):
         """Which CONV launches run on csrc/hvn_conv_x3.hip (fp32 in / out, products on the bf16 matrix pipe from exact bf16x3 splits,
         `terms` = 9 | 6 partial products per product): every dense (ungrouped) conv with a 128- or 64-wide column tile EXCEPT the 1x1
-        convs of d0 / d1 -- those are HBM-bound, and they are the chain partners (`fuse_chains`, which leaves marked ops alone): the
-        chained and the unchained lowering of the same checkpoint must stay bit-identical, so the rule is by layer, not by what the
-        chain pass did.  A static
-        rule (not a timing): a tile's bits must not depend on the batch it is run in."""
+        convs of d0 (+ d1's first conv1, chained to d0's last conv3) -- HBM-bound, they stay chained pairs on the fp32 pipe
+        (`fuse_chains`, which leaves marked ops alone).  d1's 1x1 convs (d1=True) run here unchained: measured faster than their
+        chains (655 -> 674 tiles/s).  The rule is by layer, not by what the chain pass did -- the chained and the unchained lowering
+        of a checkpoint stay bit-identical -- and static, not a timing: a tile's bits must not depend on the batch it is run in."""
         import re
 
         assert terms in (9, 6), terms
@@ -292,7 +292,7 @@ class Plan:
             if re.match(r"^d0\.units\.\d+\.conv[13]$", op.name) or op.name == "d1.units.0.conv1":
                 continue
             if not d1 and re.match(r"^d1\.units\.\d+\.conv[13]$", op.name):
-                continue                # d1=True (HVN_X3_D1=1, a measured option): d1's 1x1 convs on this kernel INSTEAD of chained launches
+                continue                # d1=True (default; HVN_X3_D1=0 chains them on the fp32 pipe instead): measured 655 -> 674 tiles/s
             op.extra["x3"] = terms
 
     def reindex(self):
@@ -518,7 +518,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     if x3 is None:
         x3 = int(os.environ.get("HVN_X3", "6"))       # default since round 4: six partial products (measured: the fp32-MFMA path's own error band)
     if x3:
-        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "0") != "0")
+        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "1") != "0")
     if chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
     if os.environ.get("HVN_FUSE_UPADD", "0") != "0":

@@ -77,3 +77,31 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
     assert rows0 < inst1.shape[0] and out[1][2] < inst1.shape[0] and rows1 == inst1.shape[0]      # each rank held slab + halo only
     for a, b in zip(tiles0, tiles1):                                # tile path: every image complete on rank 0
         assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+
+
+def test_bench_step_on_two_ranks_sharing_the_gpu():
+    """The driver's exact N > 1 command path -- `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` -- with the REAL
+    kernels and bench.py's OWN step (network, instance separation, the per-batch gather to rank 0 on the side stream inside the timed
+    step, D2H), on this box's one GPU: HVN_BENCH_SHARED_GPU=1 puts both ranks on cuda:0 and the collectives on gloo (device tensors
+    staged through the host, `infer_tile.gather_to_rank0`).  Nothing measured here is comparable; what is checked is that the line is
+    produced, carries both ranks' tiles and the per-rank step / gather times a bad scaling curve would be diagnosed from."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVN_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 32000 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-variants",
+           "--no-roofline", "--checkpoint", "random"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["steps"] == 3 and d["value"] > 0
+    pr = d["config"]["per_rank"]
+    assert len(pr["step_ms"]) == 2 and len(pr["gather_ms"]) == 2 and all(t > 0 for t in pr["step_ms"]) and all(t >= 0 for t in pr["gather_ms"])
+    assert d["config"]["instances_last_step"] > 0          # rank 0 holds the gathered results of both ranks
