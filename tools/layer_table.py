@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-op table from a rocprofv3 --kernel-trace results.db of `python bench.py`: maps the LAST plan execution's
 network-kernel dispatches (bench.py's single-stream roofline pass, one launch per plan op, in order) onto the plan's
-ops.  TFLOP/s columns: algorithmic (direct-convolution FLOPs) and executed (after Winograd).
+ops.  TFLOP/s columns: algorithmic (direct-convolution FLOPs) and executed (after Winograd); for launches on the bf16x3 kernel
+(shape marked `x3`) "executed" counts each fp32 product once (fp32-equivalent: x 6 = the bf16 MFMA FLOPs the launch issues).
 usage: python tools/layer_table.py <results.db> [batch]"""
 import os
 import sqlite3
@@ -29,7 +30,7 @@ for o, (name, dur) in zip(P.ops, last):
     a[0] += dur
     a[1] += fl
     a[2] += ex
-    shape = "k%dx%d s%d %4d->%-4d @%-3d" % (o.kh, o.kw, o.stride, o.x.c, o.cout, o.y.h) if o.kind == 2 else (
+    shape = ("k%dx%d s%d %4d->%-4d @%-3d" % (o.kh, o.kw, o.stride, o.x.c, o.cout, o.y.h) + (" x3" if o.extra.get("x3") else "")) if o.kind == 2 else (
         "1x1 %d->%d->%d @%d" % (o.extra["cin_real"], o.cout, o.extra["cout2"], o.y.h) if o.kind == 8 else name.split("(")[0][:24])
     print("%-62s %-24s %9.1f %8.1f %8.1f" % (o.name, shape, dur / 1e3, fl / dur / 1e3, ex / dur / 1e3))
 print("total network-kernel ms %.2f" % (tot / 1e6))
