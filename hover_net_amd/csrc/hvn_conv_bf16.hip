@@ -16,6 +16,7 @@
 //     the store; residuals are read as bf16.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hvn_kernels.h"
 
@@ -37,7 +38,12 @@ __device__ inline uint32_t pack_bf(float a, float b)
     return __builtin_bit_cast(uint32_t, h);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2>
+// WIDE = true (round 4, default): the loop structure of hvn_conv_x3.hip -- a k-step is TWO 64-channel chunks side by side in one LDS
+// buffer (row pitch 272 B = 68 banks = 4 x 17: conflict-free ds_read_b128), barrier, store the staged step, barrier, issue the next
+// step's global loads, 32 MFMAs per wave between barriers instead of 16; one register stage (two workgroups per CU cover each other's
+// store phases).  WIDE = false: round 2's loop (64-channel k-steps, double-buffered LDS, ring of four register stages); HVN_BF16_LOOP=0.
+#define LDW 136     // WIDE: LDS row pitch in bf16 elements (2 x 64 + 8)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2, bool WIDE>
 __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
 {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -45,10 +51,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
     constexpr int PA = BM / 32, PB = BN / 32;  // staging passes (32 rows of 8 x 16 B per pass)
     constexpr int EP_LD = BN + 4;              // epilogue tile row length (floats)
     static_assert(WAVES_M * WAVES_N == 4, "256 threads");
-    static_assert(BM * EP_LD * 4 <= 2 * (BM + BN) * LDH * 2, "epilogue tile must fit in the staging buffers");
+    static_assert(WIDE || BM * EP_LD * 4 <= 2 * (BM + BN) * LDH * 2, "epilogue tile must fit in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) uint16_t smem16[];
-    uint16_t *As = smem16;                    // [2][BM][LDH]
-    uint16_t *Bs = smem16 + 2 * BM * LDH;     // [2][BN][LDH]
+    uint16_t *As = smem16;                                        // [2][BM][LDH]   | WIDE: [BM][LDW]
+    uint16_t *Bs = smem16 + (WIDE ? BM * LDW : 2 * BM * LDH);     // [2][BN][LDH]   | WIDE: [BN][LDW]
     const uint16_t *px = (const uint16_t *)p.x;
     const uint16_t *pw = (const uint16_t *)p.w;
 
@@ -122,11 +128,13 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
     int ld_r = 0, ld_s = 0, ld_c = 0;  // tap row / col / channel chunk of the NEXT load
 
     auto load_global = [&](Stage &s, int kt) {
+        const bool past = kt >= KT;                                    // (uniform; WIDE only) the odd tail's second half: zeros for A and B
         int a_soff = (int)(((long)ld_r * p.xsy + (long)ld_s * p.xsx + ld_c * BKH) * 2);
-        const int w_soff = kt * (BKH * 2);
+        const int w_soff = past ? 0 : kt * (BKH * 2);
         const bool second = HAS_X2 && kt >= KT1;
         if constexpr (HAS_X2) a_soff = second ? (kt - KT1) * (BKH * 2) : a_soff;
-        const bool zero_half = tail_half && ld_c == kchunks - 1 && !second;
+        if (past) a_soff = 0;
+        const bool zero_half = past || (tail_half && ld_c == kchunks - 1 && !second);
         if constexpr (HAS_PRE) s.ch = zero_half ? 0 : ld_c * BKH + scol;      // any valid index for the zero-weighted tail
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
@@ -138,12 +146,14 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
             vo = zero_half ? OOB : vo;
             if constexpr (HAS_X2) {
                 vo = second ? a2_voff[j] : vo;
+                vo = past ? OOB : vo;
                 s.ra[j] = __builtin_amdgcn_raw_buffer_load_b128(second ? rsrc_a2 : rsrc_a, vo, a_soff, 0);
             } else
                 s.ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, a_soff, 0);
         }
 #pragma unroll
-        for (int j = 0; j < PB; ++j) s.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], w_soff, 0);
+        for (int j = 0; j < PB; ++j) s.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, past ? OOB : w_voff[j], w_soff, 0);
+        if (past) return;
         if (++ld_s == p.KW) {
             ld_s = 0;
             if (++ld_r == p.KH) {
@@ -152,9 +162,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
             }
         }
     };
-    auto store_lds = [&](Stage &s, int buf) {
-        uint16_t *a = As + buf * BM * LDH;
-        uint16_t *b = Bs + buf * BN * LDH;
+    auto store_lds = [&](Stage &s, int buf) {    // WIDE: buf = which half of the row (0 | 1)
+        constexpr int LD = WIDE ? LDW : LDH;
+        uint16_t *a = WIDE ? As + buf * BKH : As + buf * BM * LDH;
+        uint16_t *b = WIDE ? Bs + buf * BKH : Bs + buf * BN * LDH;
         f32x4 ps0, ps1, pb0, pb1;
         if constexpr (HAS_PRE) {
             if (has_pre) {      // 32 B each, L1/L2 resident (one [Cin] array pair per layer)
@@ -179,10 +190,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
                     }
                 }
             }
-            *(u32x4 *)(a + (srow + 32 * j) * LDH + scol) = v;
+            *(u32x4 *)(a + (srow + 32 * j) * LD + scol) = v;
         }
 #pragma unroll
-        for (int j = 0; j < PB; ++j) *(u32x4 *)(b + (srow + 32 * j) * LDH + scol) = s.rb[j];
+        for (int j = 0; j < PB; ++j) *(u32x4 *)(b + (srow + 32 * j) * LD + scol) = s.rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -194,15 +205,16 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](int cur) {
-        const uint16_t *a = As + cur * BM * LDH + (wm * WM + l31) * LDH + 8 * lh;
-        const uint16_t *b = Bs + cur * BN * LDH + (wn * WN + l31) * LDH + 8 * lh;
+        constexpr int LD = WIDE ? LDW : LDH;
+        const uint16_t *a = (WIDE ? As : As + cur * BM * LDH) + (wm * WM + l31) * LD + 8 * lh;
+        const uint16_t *b = (WIDE ? Bs : Bs + cur * BN * LDH) + (wn * WN + l31) * LD + 8 * lh;
 #pragma unroll
-        for (int q = 0; q < BKH / 16; ++q) {
+        for (int q = 0; q < (WIDE ? 2 : 1) * BKH / 16; ++q) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(a + i * 32 * LDH + q * 16));
+            for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(a + i * 32 * LD + q * 16));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + j * 32 * LDH + q * 16));
+            for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + j * 32 * LD + q * 16));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -210,6 +222,23 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
         }
     };
 
+    if constexpr (WIDE) {
+        // one LDS buffer, one register stage of two chunks: barrier, park the staged pair, barrier, issue the next pair's loads, compute
+        load_global(st[0], 0);
+        load_global(st[1], 1);                   // kt >= KT: zeros (odd tail)
+        for (int kt = 0; kt < KT; kt += 2) {
+            __syncthreads();
+            store_lds(st[0], 0);
+            store_lds(st[1], 1);
+            __syncthreads();
+            if (kt + 2 < KT) {
+                load_global(st[0], kt + 2);
+                load_global(st[1], kt + 3);
+            }
+            compute(0);
+        }
+        __syncthreads();
+    } else {
     // ring of four register stages: the loads of k-step t+3 are issued while step t computes
     load_global(st[0], 0);
     if (KT > 1) load_global(st[1], 1);
@@ -227,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
                 __syncthreads();
             }
         }
+    }
     }
 
     // ---- epilogue: accumulators -> fp32 LDS tile -> bias / ReLU / residual / post BN-ReLU -> bf16 ----
@@ -347,15 +377,16 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2>
-static int launch_bf16(const ConvArgs &a, hipStream_t stream)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2, bool WIDE>
+static int launch_bf16w(const ConvArgs &a, hipStream_t stream)
 {
     ConvArgs p = a;
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDH * sizeof(uint16_t);
+    constexpr size_t stage_b = WIDE ? (size_t)(BM + BN) * LDW * 2 : (size_t)2 * (BM + BN) * LDH * 2, ep_b = (size_t)BM * (BN + 4) * 4;
+    const size_t lds = stage_b > ep_b ? stage_b : ep_b;
     static bool attr_done = false;
-    auto kern = hvn_conv_igemm_bf16<BM, BN, WAVES_M, WAVES_N, PADDED, HAS_PRE, HAS_X2>;
+    auto kern = hvn_conv_igemm_bf16<BM, BN, WAVES_M, WAVES_N, PADDED, HAS_PRE, HAS_X2, WIDE>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         attr_done = true;
@@ -365,6 +396,20 @@ static int launch_bf16(const ConvArgs &a, hipStream_t stream)
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2>
+static int launch_bf16(const ConvArgs &a, hipStream_t stream)
+{
+    static int wide = -1;
+    if (wide < 0) {
+        const char *e = getenv("HVN_BF16_LOOP");       // 0: round 2's loop (A/B runs); default: the wide-step loop
+        wide = e ? atoi(e) : 1;
+    }
+    // a reduction of ONE 64-channel chunk (d0's conv3: K = 64) would pair it with a chunk of zeros: the narrow loop keeps it
+    const long kt = (long)a.KH * a.KW * ((a.Cin + BKH - 1) / BKH) + (a.x2 ? a.Cin2 / BKH : 0);
+    return (wide && kt >= 2) ? launch_bf16w<BM, BN, WAVES_M, WAVES_N, PADDED, HAS_PRE, HAS_X2, true>(a, stream)
+                             : launch_bf16w<BM, BN, WAVES_M, WAVES_N, PADDED, HAS_PRE, HAS_X2, false>(a, stream);
 }
 
 int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream)

@@ -49,6 +49,13 @@ case $T in
     Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
     for cfg in "HVN_X3_D1=0" "HVN_X3_D1=1"; do ENVV=($cfg); bench d1_$(echo $cfg | tr -d ' =A-Z_') $Q; done
     ;;
+  bf16)       # the bf16 conv loop A/B (HVN_BF16_LOOP=0: round 2's loop) + launch schedule, cfg 3, one box; then its parity tests
+    Q="--dtype bf16 --mode fast --nr-types 6 --batch 64 --steps 10 --warmup 2 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for cfg in "HVN_BF16_LOOP=0" "HVN_BF16_LOOP=1" "HVN_BF16_LOOP=1 HVN_SPLIT=2 HVN_LANES=2"; do ENVV=($cfg); bench bf16_$(echo $cfg | tr -d ' =A-Z_') $Q; done
+    grep -E "^== bench|^value|^roofline" $O > gpurun_out/${R}_bf16_loop_ab.txt
+    for x in 0 1; do HVN_BF16_LOOP=$x timeout 200 python tools/layer_ms.py --dtype bf16 --mode fast --nr-types 6 --batch 64 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_layers_cfg3_bf16_loop$x.txt; done
+    timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_bench_shapes.py -x -q 2>&1 | tail -5 >> $O
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
