@@ -345,6 +345,36 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_x3(ConvArgs p)
         if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
 }
 
+// Training: the fp32 weight packings change every step, so their bf16 planes are made on the device.  src = fp32 packings, any
+// concatenation of [...][32]-float granules (hvn_pack_w's forward / data-gradient / Winograd forms); dst = the same granules as
+// [3][32] bf16 (element offset of a packing in dst = 3 x its offset in src).  One thread = 4 floats of one granule.
+__global__ __launch_bounds__(256) void hvn_split_x3(const float *src, uint16_t *dst, long granules)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long g = t >> 3;
+    const int q = (int)(t & 7);
+    if (g >= granules) return;
+    const f32x4 v = *(const f32x4 *)(src + g * 32 + q * 4);
+    __bf16 h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]);
+    split3(v.y, h[1], m[1], l[1]);
+    split3(v.z, h[2], m[2], l[2]);
+    split3(v.w, h[3], m[3], l[3]);
+    uint16_t *d = dst + g * 96 + q * 4;
+    *(u32x2 *)(d) = (u32x2){pack2(h[0], h[1]), pack2(h[2], h[3])};
+    *(u32x2 *)(d + 32) = (u32x2){pack2(m[0], m[1]), pack2(m[2], m[3])};
+    *(u32x2 *)(d + 64) = (u32x2){pack2(l[0], l[1]), pack2(l[2], l[3])};
+}
+
+int hvn_launch_split_x3(const float *src, uint16_t *dst, long granules, hipStream_t stream)
+{
+    if (!src || !dst || granules <= 0 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return -1;
+    const long blocks = (granules * 8 + 255) / 256;
+    if (blocks > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(hvn_split_x3, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, granules);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PADDED, bool HAS_PRE, bool HAS_X2, int NTERMS>
 static int launch_x3(const ConvArgs &a, hipStream_t stream)
 {

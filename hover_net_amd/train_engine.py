@@ -24,6 +24,7 @@ from . import winograd as WG
 from .plan import OP_CONV, OP_CONV0, OP_HEAD, OP_UPADD, OP_WINO_IN, OP_WINO_OUT, _tile_n
 
 T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD_BWD, T_WINO_DY, T_WINO_DW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+T_SPLIT_X3 = 11
 MOMENTUM = 0.1
 
 
@@ -93,6 +94,7 @@ class TrainEngine:
         self.fwd_ops = self._lower([self._pack_ops()] + [self._lower_fwd(op) for op in P.fwd])
         bwd_groups = [self._lower_bwd(op) for op in P.bwd]
         self.bwd_ops = self._lower(bwd_groups)
+        self._use_x3()
         # gradient buckets for data-parallel training: the backward list finishes the decoder branches first and their
         # parameters are the tail of the slab, so their all-reduce can run under the encoder's backward pass
         first_enc = next((i for i, op in enumerate(P.bwd) if not op.name.startswith("decoder.")), len(P.bwd))
@@ -168,6 +170,11 @@ class TrainEngine:
         self._pack_off[("conv0./.weight", 2)] = (total, 64)
         total += _align(7 * 7 * 3 * 64)
         self.packs = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # bf16x3 (csrc/hvn_conv_x3.hip): the forward / data-gradient convs form their products on the bf16 matrix pipe from exact
+        # three-way bf16 splits; the planes of the step's weight packings are made on the device right after the packing
+        # (HVN_TRAIN_X3 = 6 (default) | 9 partial products per product, 0 = every conv on the fp32 pipe)
+        self.x3_terms = int(os.environ.get("HVN_TRAIN_X3", "6"))
+        self.packs_x3 = torch.zeros(3 * total, dtype=torch.int16, device=self.device) if self.x3_terms else None
 
     def pack_ptr(self, key, mode):
         return self.packs.data_ptr() + 4 * self._pack_off[(key, mode)][0]
@@ -186,7 +193,28 @@ class TrainEngine:
             t.p[1] = self.packs.data_ptr() + 4 * off
             t.p[2] = self._g_ptr
             ops.append(t)
+        if self.x3_terms:
+            t = L.hvn_top()
+            t.kind = T_SPLIT_X3
+            t.p[0], t.p[1] = self.packs.data_ptr(), self.packs_x3.data_ptr()
+            t.batch_stride[0] = self.packs.numel() // 32
+            ops.append(t)
         return ops
+
+    def _use_x3(self):
+        """Point every eligible conv launch (dense, 128- or 64-wide column tile, weights in the step's packing buffer) at the bf16
+        planes of its weights and at csrc/hvn_conv_x3.hip (act_dtype 3 | 2).  Grouped convs, conv0 and the heads stay as they are."""
+        if not self.x3_terms:
+            return
+        lo, hi = self.packs.data_ptr(), self.packs.data_ptr() + 4 * self.packs.numel()
+        for o in self._keep:
+            if not isinstance(o, L.hvn_op) or o.kind != OP_CONV or o.groups > 1 or o.tile_n not in (128, 64) or not o.w or not (lo <= o.w < hi):
+                continue
+            off = (o.w - lo) // 4
+            o.w = self.packs_x3.data_ptr() + 2 * 3 * off
+            o.act_dtype = 3 if self.x3_terms == 6 else 2
+            if o.nbatch > 1:
+                o.batch_stride[1] = 3 * o.batch_stride[1]
 
     def _alloc_wino_scratch(self):
         """Transform-domain tensors: every trained Winograd conv keeps its forward V (the weight gradient reads it
@@ -400,10 +428,10 @@ class TrainEngine:
         for o in self._keep:
             if not isinstance(o, L.hvn_op) or o.kind != OP_CONV or o.groups > 1 or o.tile_n not in (128, 64):
                 continue
-            if o.tile_n == 64 and o.x2.base:
-                continue                                   # the fused-shortcut instantiations exist for 128 x 128 and 128 x 64 tiles only (as in Engine.autotune_tiles)
+            if o.tile_n == 64 and (o.x2.base or o.act_dtype in (2, 3)):
+                continue                                   # the fused-shortcut / bf16x3 instantiations exist for 128 x 128 and 128 x 64 tiles only (as in Engine.autotune_tiles)
             key = (self.n, o.kh, o.kw, o.stride, o.pad_t, o.x.c, o.cout, o.y.h, o.y.w, o.x.h, o.x.w, bool(o.res.base), int(o.nbatch),
-                   bool(o.pre_scale), int(o.x2.c) if o.x2.base else 0)
+                   bool(o.pre_scale), int(o.x2.c) if o.x2.base else 0, int(o.act_dtype))
             cands = (128, 64) if o.tile_n == 128 else (64, 320)
             if key not in _TILE_CHOICE:
                 t = {}

@@ -56,6 +56,16 @@ case $T in
     for x in 0 1; do HVN_BF16_LOOP=$x timeout 200 python tools/layer_ms.py --dtype bf16 --mode fast --nr-types 6 --batch 64 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_layers_cfg3_bf16_loop$x.txt; done
     timeout 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_bench_shapes.py -x -q 2>&1 | tail -5 >> $O
     ;;
+  train)      # training step: fp32 pipe vs bf16x3 forward / data-gradient products on one box, then the training tests
+    for x in 0 6; do HVN_TRAIN_X3=$x timeout 400 python tools/train_bench.py --steps 10 --warmup 3 2>/dev/null | grep "^{" | sed "s/^/HVN_TRAIN_X3=$x /" >> gpurun_out/${R}_train_bench.jsonl; done
+    python - >> $O <<'PY'
+import json
+for l in open("gpurun_out/r04_train_bench.jsonl"):
+    tag, js = l.split(" ", 1); d = json.loads(js)
+    print(tag, "phase", d.get("phase"), "batch", d.get("batch"), "ms/step %.2f" % d.get("ms_per_step", 0), {k: round(v, 2) for k, v in d.items() if k.endswith("_ms")})
+PY
+    timeout 1500 python -m pytest tests/test_gpu_train.py -x -q -s 2>&1 | grep -E "passed|failed|Error|assert|bf16x3|direct vs" | tail -14 >> $O
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
