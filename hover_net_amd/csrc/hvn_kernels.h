@@ -146,6 +146,8 @@ struct PackArgs {
     const float *gmat;    // modes 3 / 4 (Winograd F(4x4,5x5) transforms U = G g G^T, forward / data-gradient): G [8][5]
 };
 int hvn_launch_pack_w(const PackArgs &a, hipStream_t stream);
+// every mode 0 / 1 / 2 packing of a step in one launch: device table + first workgroup of each packing (first_block[n] = grid size)
+int hvn_launch_pack_w_multi(const PackArgs *tbl, const int *first_block, int n, long blocks, hipStream_t stream);
 
 struct WgradArgs {
     const float *x;       // conv input view

@@ -28,10 +28,8 @@ static inline int launch_ok() { return hipGetLastError() == hipSuccess ? 0 : -2;
 // =========================================================================================
 // weight packing
 // =========================================================================================
-__global__ __launch_bounds__(256) void hvn_pack_w(const PackArgs p, long total)
+__device__ __forceinline__ void pack_w_one(const PackArgs &p, long i)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
     const int taps = p.taps;
     if (p.mode == 2) {  // conv0: [64][7][7][3] -> [7][7][3][64] * (1/255)
         const int co = (int)(i % 64);
@@ -68,6 +66,43 @@ __global__ __launch_bounds__(256) void hvn_pack_w(const PackArgs p, long total)
         }
     }
     p.dst[i] = v;
+}
+
+__device__ __forceinline__ long pack_w_total(const PackArgs &a)
+{
+    return a.mode == 2 ? 64L * a.taps * 3 : a.mode == 0 ? (long)a.lead_pad * (a.cin_g * a.groups) * a.taps : (long)a.lead_pad * a.cout * a.taps;
+}
+
+__global__ __launch_bounds__(256) void hvn_pack_w(const PackArgs p, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    pack_w_one(p, i);
+}
+
+// Every mode-0 / 1 / 2 packing of the step in ONE launch (a training step repacks ~260 weights: 260 launches of ~4 us were 1.1 ms of a
+// 51 ms phase-1 step).  tbl[k] = the k-th packing, first_block[k] = its first workgroup (first_block[n] = the grid): a workgroup finds
+// its packing by bisection.
+__global__ __launch_bounds__(256) void hvn_pack_w_multi(const PackArgs *tbl, const int *first_block, int n)
+{
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackArgs p = tbl[lo];
+    const long i = (long)(b - first_block[lo]) * 256 + threadIdx.x;
+    if (i >= pack_w_total(p)) return;
+    pack_w_one(p, i);
+}
+
+int hvn_launch_pack_w_multi(const PackArgs *tbl, const int *first_block, int n, long blocks, hipStream_t stream)
+{
+    if (!tbl || !first_block || n <= 0 || blocks <= 0 || blocks > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(hvn_pack_w_multi, dim3((unsigned)blocks), dim3(256), 0, stream, tbl, first_block, n);
+    return launch_ok();
 }
 
 // Winograd F(4x4,5x5) weight transform U[a*8+b] = sum_{r,s} G[a][r] g[r][s] G[b][s] (double accumulate), written in the
@@ -746,6 +781,14 @@ int hvn_launch_upadd_bwd(const UpAddBwdArgs &a, hipStream_t stream)
 // =========================================================================================
 // 1x1 logit head (64 -> C, bias) backward: da += W^T dl, dW += sum dl (x) a, db += sum dl
 // =========================================================================================
+// Every lane owns one pixel; the weight / bias gradients are summed across the wave with a butterfly (6 exchanges) and leave with ONE
+// LDS atomic per wave and value (round 3 added every lane's product with its own LDS atomic: 64 lanes on one address, 0.36 ms per head).
+__device__ __forceinline__ float head_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __global__ __launch_bounds__(256) void hvn_head_bwd(const HeadBwdArgs p, long total)
 {
     __shared__ float sw[16 * 64 + 16];  // dW tile then db
@@ -753,36 +796,41 @@ __global__ __launch_bounds__(256) void hvn_head_bwd(const HeadBwdArgs p, long to
     for (int i = threadIdx.x; i < C * 64 + C; i += 256) sw[i] = 0.f;
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < total) {
-        const int x = (int)(i % p.W);
-        long t = i / p.W;
-        const int y = (int)(t % p.H);
-        const int n = (int)(t / p.H);
-        const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
-        float *dst = p.dx + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx;
-        const long plane = (long)p.H * p.W;
-        const float *dl = p.dl + (long)n * C * plane + (long)y * p.W + x;
-        float a[64], da[64];
+    const bool act = i < total;
+    const long ii = act ? i : 0;
+    const int x = (int)(ii % p.W);
+    long t = ii / p.W;
+    const int y = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
+    float *dst = p.dx + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx;
+    const long plane = (long)p.H * p.W;
+    const float *dl = p.dl + (long)n * C * plane + (long)y * p.W + x;
+    float a[64], da[64];
 #pragma unroll
-        for (int c = 0; c < 64; c += 4) {
-            const f32x4 v = *(const f32x4 *)(src + c);
-            const f32x4 d = *(const f32x4 *)(dst + c);
+    for (int c = 0; c < 64; c += 4) {
+        const f32x4 v = *(const f32x4 *)(src + c);
+        const f32x4 d = *(const f32x4 *)(dst + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[c + e] = v[e];
-                da[c + e] = d[e];
-            }
+        for (int e = 0; e < 4; ++e) {
+            a[c + e] = act ? v[e] : 0.f;
+            da[c + e] = d[e];
         }
-        for (int co = 0; co < C; ++co) {
-            const float g = dl[co * plane];
-            const float *__restrict__ w = p.w + co * 64;
-            atomicAdd(&sw[C * 64 + co], g);
+    }
+    const bool lead = (threadIdx.x & 63) == 0;
+    for (int co = 0; co < C; ++co) {
+        const float g = act ? dl[co * plane] : 0.f;
+        const float *__restrict__ w = p.w + co * 64;
+        const float gs = head_wave_sum(g);
+        if (lead) atomicAdd(&sw[C * 64 + co], gs);
 #pragma unroll
-            for (int c = 0; c < 64; ++c) {
-                da[c] = fmaf(g, w[c], da[c]);
-                atomicAdd(&sw[co * 64 + c], g * a[c]);
-            }
+        for (int c = 0; c < 64; ++c) {
+            da[c] = fmaf(g, w[c], da[c]);
+            const float ws = head_wave_sum(g * a[c]);
+            if (lead) atomicAdd(&sw[co * 64 + c], ws);
         }
+    }
+    if (act) {
 #pragma unroll
         for (int c = 0; c < 64; c += 4) *(f32x4 *)(dst + c) = (f32x4){da[c], da[c + 1], da[c + 2], da[c + 3]};
     }

@@ -130,6 +130,11 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
             return tfail(HVN_E_ARG, "wino_dy: dM must be [64][tiles][c] and the tiles must cover dy", idx);
         return hvn_launch_wino_dy(a, s);
     }
+    case HVN_T_PACK_MULTI:
+        if (!t->p[0] || !t->p[1] || t->cout <= 0 || t->batch_stride[0] <= 0) return tfail(HVN_E_ARG, "pack_multi: bad arguments", idx);
+        if (hvn_launch_pack_w_multi((const PackArgs *)t->p[0], (const int *)t->p[1], t->cout, (long)t->batch_stride[0], s))
+            return tfail(HVN_E_ARG, "pack_multi: launch refused", idx);
+        return 0;
     case HVN_T_SPLIT_X3:
         if (!t->p[0] || !t->p[1] || t->batch_stride[0] <= 0) return tfail(HVN_E_ARG, "split_x3: bad arguments", idx);
         if (hvn_launch_split_x3((const float *)t->p[0], (uint16_t *)t->p[1], (long)t->batch_stride[0], s)) return tfail(HVN_E_ARG, "split_x3: launch refused", idx);

@@ -43,6 +43,12 @@ class hvn_top(ctypes.Structure):
                 ("batch_stride", ctypes.c_int64 * 3), ("nbatch", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
 
 
+class hvn_pack_desc(ctypes.Structure):
+    """One entry of HVN_T_PACK_MULTI's device table (include/hvn.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p)] + [(k, ctypes.c_int32) for k in ("cout", "cin_g", "groups", "taps", "mode", "lead_pad")] + \
+               [("gmat", ctypes.c_void_p)]
+
+
 class hvn_loss(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("logits_np", "logits_hv", "logits_tp", "true_np", "true_tp", "true_hv",
                                                "grad_np", "grad_hv", "grad_tp", "sums", "sobel_ws")] + \

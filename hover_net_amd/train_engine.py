@@ -24,7 +24,7 @@ from . import winograd as WG
 from .plan import OP_CONV, OP_CONV0, OP_HEAD, OP_UPADD, OP_WINO_IN, OP_WINO_OUT, _tile_n
 
 T_NET, T_PACK_W, T_BN_FWD, T_BN_BWD, T_WGRAD, T_CONV0_WGRAD, T_UPADD_BWD, T_HEAD_BWD, T_WINO_DY, T_WINO_DW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-T_SPLIT_X3 = 11
+T_SPLIT_X3, T_PACK_MULTI = 11, 12
 MOMENTUM = 0.1
 
 
@@ -180,19 +180,43 @@ class TrainEngine:
         return self.packs.data_ptr() + 4 * self._pack_off[(key, mode)][0]
 
     def _pack_ops(self):
-        ops = []
+        """The step's weight packings: every plain (forward / data-gradient / conv0) packing in ONE launch over a device table
+        (HVN_T_PACK_MULTI; HVN_TRAIN_PACK_MULTI=0 keeps one launch per packing), the Winograd transforms one launch each."""
+        import numpy as np
+
+        ops, table, blocks = [], [], [0]
+        multi = os.environ.get("HVN_TRAIN_PACK_MULTI", "1") != "0"
         for (key, mode), (off, lead) in self._pack_off.items():
-            t = L.hvn_top()
-            t.kind, t.mode, t.lead_pad = T_PACK_W, mode, lead
             if mode == 2:
-                t.cout, t.cin_g, t.groups, t.kh, t.kw = 64, 3, 1, 7, 7
+                cout, cin_g, groups, kh, kw = 64, 3, 1, 7, 7
             else:
                 c = self.plan.convs[key]
-                t.cout, t.cin_g, t.groups, t.kh, t.kw = c["cout"], c["cin_g"], c["groups"], c["kh"], c["kw"]
+                cout, cin_g, groups, kh, kw = c["cout"], c["cin_g"], c["groups"], c["kh"], c["kw"]
+            if multi and mode in (0, 1, 2):
+                d = L.hvn_pack_desc()
+                d.src, d.dst = self.wptr(key), self.packs.data_ptr() + 4 * off
+                d.cout, d.cin_g, d.groups, d.taps, d.mode, d.lead_pad = cout, cin_g, max(1, groups), kh * kw, mode, lead
+                total = 64 * kh * kw * 3 if mode == 2 else (lead * cin_g * max(1, groups) * kh * kw if mode == 0 else lead * cout * kh * kw)
+                table.append(d)
+                blocks.append(blocks[-1] + (total + 255) // 256)
+                continue
+            t = L.hvn_top()
+            t.kind, t.mode, t.lead_pad = T_PACK_W, mode, lead
+            t.cout, t.cin_g, t.groups, t.kh, t.kw = cout, cin_g, groups, kh, kw
             t.p[0] = self.wptr(key)
             t.p[1] = self.packs.data_ptr() + 4 * off
             t.p[2] = self._g_ptr
             ops.append(t)
+        if table:
+            arr = (L.hvn_pack_desc * len(table))(*table)
+            raw = np.frombuffer(arr, dtype=np.uint8).copy()
+            self._pack_table = torch.from_numpy(raw).to(self.device)
+            self._pack_first = torch.tensor(blocks, dtype=torch.int32, device=self.device)
+            t = L.hvn_top()
+            t.kind, t.cout = T_PACK_MULTI, len(table)
+            t.p[0], t.p[1] = self._pack_table.data_ptr(), self._pack_first.data_ptr()
+            t.batch_stride[0] = blocks[-1]
+            ops.insert(0, t)
         if self.x3_terms:
             t = L.hvn_top()
             t.kind = T_SPLIT_X3

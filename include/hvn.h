@@ -207,12 +207,20 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *   WINO_DY      dM = A dY A^T per 4x4 tile of the output gradient: x = dy view, y = dM as [64][tiles][c] per sample,
  *                p[0] = A^T [4][8], kh x kw = tile grid
  *   WINO_DW      grad g [cout][25][cin] (p[1]) += G^T dU G of dU [64][cout][cin] (p[0]), p[2] = G [8][5]; cout, cin_g
+ *   PACK_MULTI   every mode 0 / 1 / 2 PACK_W of a step in one launch: p[0] = dev table of hvn_pack_desc [cout], p[1] = dev int32
+ *                [cout + 1] first workgroup (of 256 outputs) of each packing, batch_stride[0] = workgroups in total
  *   SPLIT_X3     p[0] = fp32 weight packings (batch_stride[0] granules of 32 floats, any concatenation of PACK_W outputs), p[1] = their
  *                three bf16 planes, [3][32] bf16 per granule: what a CONV with act_dtype 2 | 3 reads (the weights of a training step
  *                change every step, so the planes are made on the device after the PACK_W ops)
  */
 enum { HVN_T_NET = 1, HVN_T_PACK_W = 2, HVN_T_BN_FWD = 3, HVN_T_BN_BWD = 4, HVN_T_WGRAD = 5, HVN_T_CONV0_WGRAD = 6,
-       HVN_T_UPADD_BWD = 7, HVN_T_HEAD_BWD = 8, HVN_T_WINO_DY = 9, HVN_T_WINO_DW = 10, HVN_T_SPLIT_X3 = 11 };
+       HVN_T_UPADD_BWD = 7, HVN_T_HEAD_BWD = 8, HVN_T_WINO_DY = 9, HVN_T_WINO_DW = 10, HVN_T_SPLIT_X3 = 11, HVN_T_PACK_MULTI = 12 };
+typedef struct hvn_pack_desc {   /* one entry of PACK_MULTI's table = the fields of a PACK_W op */
+    const float *src;            /* parameter [cout][kh*kw][cin_g] (dev) */
+    float *dst;                  /* packing (dev) */
+    int32_t cout, cin_g, groups, taps, mode, lead_pad;
+    const float *gmat;           /* unused by modes 0 / 1 / 2 */
+} hvn_pack_desc;
 typedef struct hvn_top {
     int32_t kind, kh, kw, stride, pad_t, pad_l, groups, cout, cin_g, mode, lead_pad, _pad;
     hvn_view x, y, dx, dy;
