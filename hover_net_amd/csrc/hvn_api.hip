@@ -19,7 +19,7 @@ static int fail(int code, const char *fmt, const char *a = "", long b = 0)
 
 extern "C" {
 
-int hvn_version(void) { return 102; }   // 1.02: + CHAIN op (two chained 1x1 convs), hvn_op grew y2 / w2 / bias2 / cout2
+int hvn_version(void) { return 104; }   // 1.04: + CONV act_dtype 2 | 3 (bf16x3 products), PACK_MULTI / SPLIT_X3 training ops, wsi_merge counters[5]; 1.02: + CHAIN op
 
 #ifndef HVN_BUILD_ID
 #define HVN_BUILD_ID "unstamped"

@@ -103,18 +103,3 @@ def fit(mode="fast", nr_types=None, steps=240, batch=8, lr=1e-3, seed=0, log=Non
             log("step %4d loss %.4f" % (it, curve[-1]))
     net.eval()
     return net, curve
-
-
-def release_training(net):
-    """Drop the training engine of a fitted network (its activation / gradient arenas: tens of GB) and give the parameters their
-    own storage back, so that only the inference engine stays resident.  Returns the network."""
-    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    if getattr(net, "_train_engine", None) is not None:
-        net._train_engine = None
-    dev = next(net.parameters()).device
-    from . import net_desc
-
-    fresh = net_desc.create_model(mode=net.mode, nr_types=net.nr_types, input_ch=3, freeze=False)
-    fresh.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
-    fresh = fresh.to(dev).eval()
-    return fresh

@@ -97,7 +97,7 @@ def test_abi_exports_every_declared_symbol():
     lib = L.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hvn_version() == 102
+    assert lib.hvn_version() == 104
 
 
 @pytest.mark.parametrize("env,tol", [({"HVN_CHAIN": "0"}, 1e-4), ({"HVN_FUSE_UPADD": "1"}, 1e-4), ({"HVN_WINOGRAD3_M": "4"}, 1e-4),
