@@ -173,6 +173,10 @@ def lib():
         if not os.path.exists(path):
             raise HvnError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the HoVer-Net hot path)" % os.path.basename(path))
+        # torch ships its own libamdhip64 and must load it FIRST: a process that dlopens this library before importing torch ends up
+        # with the system HIP runtime for these kernels and torch's for the streams / allocations handed to them (hvn_device_ok then
+        # fails on a GPU box: `build(); smoke()` in one process did, round 4).  Loading torch here makes the order deterministic.
+        import torch  # noqa: F401
         L = ctypes.CDLL(path)
         L.hvn_build_id.restype = ctypes.c_char_p
         built = L.hvn_build_id().decode()
