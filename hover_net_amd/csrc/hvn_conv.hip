@@ -959,6 +959,146 @@ static int launch_dense_grouped2(const ConvArgs &a, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+
+// Third form (round 4): form 2's arithmetic on a ROLLING patch.  Forms 1 / 2 stage a tile's whole input patch, compute, and leave: with two
+// workgroups per CU the matrix pipe waits for a staging phase about as long as the tap loop (measured 36 - 50 TFLOP/s, 48 % of the
+// form's own MFMA bound).  Here a workgroup walks a RUN of vertically consecutive 4 x 32 tiles: consecutive tiles share all but four
+// patch rows, so the patch lives in a ring of 8 rows (slot = input row mod 8), only the four NEW rows are fetched per tile (half the
+// bytes), and they are fetched into registers WHILE the current tile's 30 tap steps run; they are parked in LDS between two barriers
+// once the tile's reads are done.  Same products in the same order per output as form 2 (same bits).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void hvn_dense_grouped3_f32(const ConvArgs p, int tiles_x, int tiles_y, int run, int runs)
+{
+    constexpr int PH = DG2_TH + KS - 1, PW = DG2_TW + KS - 1;
+    constexpr int TAPS2 = KS * (KS + 1);
+    constexpr int NEW = 4 * PW * 16;                 // float4s of the four new patch rows
+    constexpr int NPF = (NEW + 255) / 256;           // ... per thread
+    extern __shared__ __attribute__((aligned(16))) float dg_patch[];   // ring [8][PW][DG_PP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    const int gp = bid & 1;
+    bid >>= 1;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int rn = bid % runs;
+    const int n = bid / runs;
+    const int ty0 = rn * run, ty1 = min(ty0 + run, tiles_y);
+    const int ox0 = tx * DG2_TW;
+    const float *xin = p.x + (long)n * p.xsn + gp * 64;
+    // ---- the first tile's whole patch -----------------------------------------------------------------
+    {
+        const int oy0 = ty0 * DG2_TH;
+        for (int i = tid; i < PH * PW * 16; i += 256) {
+            const int c4 = i & 15, pix = i >> 4;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = oy0 + py, ix = ox0 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy < p.H && ix < p.W) v = *(const f32x4 *)(xin + (long)iy * p.xsy + (long)ix * p.xsx + c4 * 4);
+            *(f32x4 *)(dg_patch + ((iy & 7) * PW + px) * DG_PP + c4 * 4) = v;
+        }
+    }
+    const int gl = wave & 1, half = wave >> 1;   // group inside the pair; tile rows 2*half, 2*half + 1
+    const int g = 2 * gp + gl;
+    const int co = l15 & 7, dx = l15 >> 3;
+    const float *wrow = p.w + ((long)(8 * g + co) * 4 + g) * (KS * KS) * 32 + 8 * q;
+    auto load_w = [&](int t2, f32x4 &w0, f32x4 &w1) {
+        const int tr = t2 / (KS + 1), tc = t2 - tr * (KS + 1) - dx;
+        w0 = w1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tc >= 0 && tc < KS) {
+            w0 = *(const f32x4 *)(wrow + (tr * KS + tc) * 32);
+            w1 = *(const f32x4 *)(wrow + (tr * KS + tc) * 32 + 4);
+        }
+    };
+    const int ch = 8 * g + co;
+    const float bias = p.bias ? p.bias[ch] : 0.f;
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const float *acol = dg_patch + (2 * l15) * DG_PP + 32 * gl + 8 * q;     // + slot * PW * DG_PP + tc * DG_PP
+    __syncthreads();
+    for (int ty = ty0; ty < ty1; ++ty) {
+        const int oy0 = ty * DG2_TH;
+        // the four new rows of the NEXT tile: issued now, parked after this tile's reads
+        f32x4 pf[NPF];
+        const bool more = ty + 1 < ty1;
+        const int ny0 = oy0 + DG2_TH + PH - 4;      // first new input row
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + 256 * j;
+                const int c4 = i & 15, pix = i >> 4;
+                const int py = pix / PW, px = pix - py * PW;
+                const int iy = ny0 + py, ix = ox0 + px;
+                pf[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < NEW && iy < p.H && ix < p.W) pf[j] = *(const f32x4 *)(xin + (long)iy * p.xsy + (long)ix * p.xsx + c4 * 4);
+            }
+        }
+        f32x4 wb[4][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) load_w(t, wb[t][0], wb[t][1]);
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const int r0 = oy0 + 2 * half;            // input row of this wave's first output row at tap row 0
+#pragma unroll
+        for (int t2 = 0; t2 < TAPS2; ++t2) {
+            const int tr = t2 / (KS + 1), tc = t2 % (KS + 1);
+            if (t2 + 3 < TAPS2) load_w(t2 + 3, wb[(t2 + 3) & 3][0], wb[(t2 + 3) & 3][1]);
+            f32x4 a0[2], a1[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float *a = acol + (((r0 + m + tr) & 7) * PW + tc) * DG_PP;
+                a0[m] = *(const f32x4 *)(a);
+                a1[m] = *(const f32x4 *)(a + 4);
+            }
+            const f32x4 b0 = wb[t2 & 3][0], b1 = wb[t2 & 3][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][e], b0[e], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][e], b1[e], acc[m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = oy0 + 2 * half + m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + 2 * (4 * q + i) + dx;
+                if (oy < p.Ho && ox < p.Wo) p.y[(long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + ch] = fmaxf(acc[m][i] + bias, lo);
+            }
+        }
+        if (more) {
+            __syncthreads();                       // every wave is done with the four rows that leave the ring
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const int i = tid + 256 * j;
+                const int c4 = i & 15, pix = i >> 4;
+                const int py = pix / PW, px = pix - py * PW;
+                if (i < NEW) *(f32x4 *)(dg_patch + (((ny0 + py) & 7) * PW + px) * DG_PP + c4 * 4) = pf[j];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int KS>
+static int launch_dense_grouped3(const ConvArgs &a, int run, hipStream_t stream)
+{
+    const int tiles_x = (a.Wo + DG2_TW - 1) / DG2_TW, tiles_y = (a.Ho + DG2_TH - 1) / DG2_TH;
+    const int runs = (tiles_y + run - 1) / run;
+    const size_t lds = (size_t)8 * (DG2_TW + KS - 1) * DG_PP * sizeof(float);
+    static bool attr_done = false;
+    auto kern = hvn_dense_grouped3_f32<KS>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_done = true;
+    }
+    const long grid = 2L * tiles_x * runs * a.N;
+    if (grid <= 0 || grid > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, tiles_x, tiles_y, run, runs);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int hvn_launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
 {
     static int forced = -1;   // HVN_DENSE_FORM=1 | 2 forces a form (A/B runs); default: by the column-tile waste
@@ -968,7 +1108,21 @@ int hvn_launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
     }
     // form 2 (two pixels per column block, 4 x 32 tiles) does 40 % fewer MFMAs but pads the width to a multiple of 32:
     // measured faster up to ~1.55x padding (widths 58..42 and 30 of the u3 / u2 dense blocks), slower beyond (38, 34)
-    const int form = forced ? forced : (((a.Wo + 31) / 32 * 32) * 100 <= a.Wo * 155 ? 2 : 1);
+    // form 3 (rolling patch, runs of 4 tiles) where it was measured faster than form 2: the tall units (58, 54, 50, 52 rows: 1.12 - 1.22x);
+    // below that a run-per-workgroup grid no longer fills the chip (46 .. 34 rows: 0.96 - 1.04x, 30 rows: 0.58x) -- profiles/r04_dense_ab.txt
+    const int wide = ((a.Wo + 31) / 32 * 32) * 100 <= a.Wo * 155;
+    const int form = forced ? forced : (wide ? (a.Ho >= 50 ? 3 : 2) : 1);
+    if (form == 3) {            // form 2's arithmetic on a rolling patch, `run` vertically consecutive tiles per workgroup (HVN_DENSE_RUN)
+        static int run = -1;
+        if (run < 0) {
+            const char *e = getenv("HVN_DENSE_RUN");
+            run = e ? atoi(e) : 4;
+            if (run < 1) run = 1;
+        }
+        if (a.KH == 5) return launch_dense_grouped3<5>(a, run, stream);
+        if (a.KH == 3) return launch_dense_grouped3<3>(a, run, stream);
+        return -1;
+    }
     if (form == 2) {
         if (a.KH == 5) return launch_dense_grouped2<5>(a, stream);
         if (a.KH == 3) return launch_dense_grouped2<3>(a, stream);

@@ -66,6 +66,13 @@ for l in open("gpurun_out/r04_train_bench.jsonl"):
 PY
     timeout 1500 python -m pytest tests/test_gpu_train.py -x -q -s 2>&1 | grep -E "passed|failed|Error|assert|bf16x3|direct vs" | tail -14 >> $O
     ;;
+  dense)      # dense-unit grouped conv: form 2 (whole patch per tile) vs form 3 (rolling patch, runs of tiles), one box; parity tests first
+    timeout 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_net.py -x -q 2>&1 | tail -3 >> $O
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for cfg in "HVN_DENSE_FORM=2" "HVN_DENSE_RUN=4" "HVN_DENSE_RUN=3" "HVN_DENSE_RUN=5" "HVN_DENSE_RUN=8"; do ENVV=($cfg); bench dense_$(echo $cfg | tr -d ' =A-Z_') $Q; done
+    grep -E "^== bench|^value|^roofline" $O > gpurun_out/${R}_dense_ab.txt
+    for cfg in "HVN_DENSE_FORM=2" "HVN_DENSE_RUN=4"; do env $cfg timeout 200 python tools/layer_ms.py 2>/dev/null | grep "dense.units.*conv2" | head -12 > gpurun_out/${R}_dense_layers_$(echo $cfg | tr -d ' =A-Z_').txt; done
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
