@@ -149,3 +149,41 @@ def test_every_conv_launch_stays_inside_the_kernels_32bit_reach(mode, nt):
     assert d3 and all(o.extra["m"] == 4 for o in d3)
     d2 = [o for o in P.ops if o.kind == PL.OP_WINO_IN and o.name.startswith("d2.")]
     assert d2 and all(o.extra["m"] == 6 for o in d2)
+
+
+def test_bf16x3_lowering_rule_and_weight_planes(monkeypatch):
+    """Round 4: which launches go to csrc/hvn_conv_x3.hip is a STATIC rule by layer (`Plan.mark_x3`): every dense conv with a 128- / 64-wide
+    column tile except d0's 1x1 convs and d1's first conv1 (the fp32-pipe chain partners); d1's other 1x1 convs run there unchained.  The
+    chained and the unchained lowering mark the same layers; HVN_X3=0 marks none.  And the three bf16 planes the engine uploads for such a
+    launch sum back to the fp32 weights EXACTLY (h + m + l == w in fp32 arithmetic), in the k-step order the kernel walks."""
+    import re
+
+    from hover_net_amd.engine import pack_conv_x3, split_bf16x3
+
+    sd = synth_state_dict("original", 5, seed=3)
+    P = PL.build_plan(sd, "original", 5)
+    x3 = [o for o in P.ops if o.kind == PL.OP_CONV and o.extra.get("x3")]
+    assert len(x3) == 93 and all(o.extra["x3"] == 6 for o in x3)
+    assert [o.name for o in P.ops if o.kind == PL.OP_CHAIN] == ["d0.units.0.conv3+units.1.conv1", "d0.units.1.conv3+units.2.conv1",
+                                                                "d0.units.2.conv3+d1.units.0.conv1"]
+    assert not any(re.match(r"^d0\.units\.\d+\.conv[13]$", o.name) or o.name == "d1.units.0.conv1" for o in x3)
+    assert not any(int(o.extra.get("groups", 1)) != 1 for o in x3)
+    monkeypatch.setenv("HVN_CHAIN", "0")
+    P0 = PL.build_plan(sd, "original", 5)
+    assert sorted(o.name for o in P0.ops if o.extra.get("x3")) == sorted(o.name for o in x3)          # the rule does not depend on the chain pass
+    monkeypatch.delenv("HVN_CHAIN")
+    monkeypatch.setenv("HVN_X3", "0")
+    assert not any(o.extra.get("x3") for o in PL.build_plan(sd, "original", 5).ops)
+    # the planes: exact three-way split, and the packing's layout [cout_pad][k-step][3][32]
+    op = next(o for o in x3 if o.name == "d2.units.0.conv2")
+    h, m, l = split_bf16x3(op.w)
+    f = lambda b: (b.astype(np.uint32) << 16).view(np.float32)     # noqa: E731
+    assert np.array_equal((f(h) + f(m)) + f(l), op.w)                                # exact in fp32 arithmetic, not just in float64
+    assert np.abs(f(m)).max() <= np.abs(op.w).max() * 2.0 ** -8 and np.abs(f(l)).max() <= np.abs(op.w).max() * 2.0 ** -16
+    pk = pack_conv_x3(op.w)
+    cout_pad, slabs, taps, _ = op.w.shape
+    assert pk.shape == (cout_pad, slabs * taps, 3, 32) and pk.dtype == np.uint16
+    assert np.array_equal(pk[:, :, 0, :].reshape(op.w.shape), h) and np.array_equal(pk[:, :, 2, :].reshape(op.w.shape), l)
+    # the Winograd-domain product keeps its leading position axis
+    g = next(o for o in x3 if o.name.endswith("u3.conva.wino_gemm"))
+    assert pack_conv_x3(g.w).shape == g.w.shape[:2] + (g.w.shape[2] * g.w.shape[3], 3, 32)
