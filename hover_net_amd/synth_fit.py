@@ -61,9 +61,14 @@ def consep_density(size):
     return max(1, int(0.6 * mean)), max(2, int(1.4 * mean))
 
 
-def fit(mode="fast", nr_types=None, steps=240, batch=8, lr=1e-3, seed=0, log=None, init="synth", density=None, pool=None):
+def fit(mode="fast", nr_types=None, steps=240, batch=8, lr=1e-3, seed=0, log=None, init="synth", density=None, pool=None, local=True):
     """Returns a trained-like network (eval mode, on the GPU) and its loss curve.
-    density: (k_lo, k_hi) nuclei per painted input tile (default: painted_tiles' 6..22)."""
+    density: (k_lo, k_hi) nuclei per painted input tile (default: painted_tiles' 6..22).
+    local=True: this process fits ALONE even when torch.distributed is initialised (bench.py --gpus N: every rank makes its own
+    checkpoint; without this `train_step` would all-reduce the gradients of the N fits, i.e. run data-parallel training inside a
+    benchmark's set-up)."""
+    import os
+
     from . import net_desc, run_desc, targets
     from .optim import FusedAdam
     from .synth import synth_state_dict
@@ -92,14 +97,25 @@ def fit(mode="fast", nr_types=None, steps=240, batch=8, lr=1e-3, seed=0, log=Non
         tp = torch.from_numpy(np.ascontiguousarray(painted[2][:, o:o + out, o:o + out]).astype(np.int64)).cuda()
     rng = np.random.default_rng(seed + 2)
     curve = []
-    for it in range(steps):
-        idx = torch.from_numpy(rng.choice(pool_img.shape[0], batch, replace=False)).cuda()
-        feed = {"img": pool_img_d[idx], "np_map": tg["np_map"][idx], "hv_map": tg["hv_map"][idx]}
-        if tp is not None:
-            feed["tp_map"] = tp[idx]
-        res = run_desc.train_step(feed, run_info)
-        curve.append(float(res["EMA"]["overall_loss"]))
-        if log is not None and (it % 40 == 0 or it == steps - 1):
-            log("step %4d loss %.4f" % (it, curve[-1]))
+    saved_dist, saved_share = run_desc._dist, os.environ.get("HVN_TILE_SHARE")
+    if local:
+        run_desc._dist = lambda: None                  # no gradient all-reduce
+        os.environ["HVN_TILE_SHARE"] = "0"             # no launch-shape broadcast at engine build
+    try:
+        for it in range(steps):
+            idx = torch.from_numpy(rng.choice(pool_img.shape[0], batch, replace=False)).cuda()
+            feed = {"img": pool_img_d[idx], "np_map": tg["np_map"][idx], "hv_map": tg["hv_map"][idx]}
+            if tp is not None:
+                feed["tp_map"] = tp[idx]
+            res = run_desc.train_step(feed, run_info)
+            curve.append(float(res["EMA"]["overall_loss"]))
+            if log is not None and (it % 40 == 0 or it == steps - 1):
+                log("step %4d loss %.4f" % (it, curve[-1]))
+    finally:
+        run_desc._dist = saved_dist
+        if saved_share is None:
+            os.environ.pop("HVN_TILE_SHARE", None)
+        else:
+            os.environ["HVN_TILE_SHARE"] = saved_share
     net.eval()
     return net, curve

@@ -96,7 +96,7 @@ def test_bench_step_on_two_ranks_sharing_the_gpu():
     port = 32000 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-variants",
-           "--no-roofline", "--checkpoint", "random"]
+           "--no-roofline", "--fit-steps", "12"]                   # the default (fitted) checkpoint path, as the driver runs it: every rank fits ALONE
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -105,3 +105,4 @@ def test_bench_step_on_two_ranks_sharing_the_gpu():
     pr = d["config"]["per_rank"]
     assert len(pr["step_ms"]) == 2 and len(pr["gather_ms"]) == 2 and all(t > 0 for t in pr["step_ms"]) and all(t >= 0 for t in pr["gather_ms"])
     assert d["config"]["instances_last_step"] > 0          # rank 0 holds the gathered results of both ranks
+    assert d["config"]["checkpoint"]["kind"].startswith("fitted")
