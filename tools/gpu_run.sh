@@ -73,6 +73,15 @@ PY
     grep -E "^== bench|^value|^roofline" $O > gpurun_out/${R}_dense_ab.txt
     for cfg in "HVN_DENSE_FORM=2" "HVN_DENSE_RUN=4"; do env $cfg timeout 200 python tools/layer_ms.py 2>/dev/null | grep "dense.units.*conv2" | head -12 > gpurun_out/${R}_dense_layers_$(echo $cfg | tr -d ' =A-Z_').txt; done
     ;;
+  trainprof)  # rocprofv3 kernel summary of the training step, per phase
+    for ph in 0 1; do
+      CMD="python tools/train_bench.py --steps 4 --warmup 2 --phase $ph"
+      timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_tprof$ph -o r -- $CMD > gpurun_out/${R}_train_profiled_phase$ph.json 2>/dev/null
+      python tools/kernel_stats.py $(find gpurun_out/${R}_tprof$ph -name "*_results.db" | head -1) "rocprofv3 --kernel-trace --stats -- $CMD" > gpurun_out/${R}_train_kernel_stats_phase$ph.csv 2>/dev/null
+      rm -rf gpurun_out/${R}_tprof$ph
+      head -16 gpurun_out/${R}_train_kernel_stats_phase$ph.csv | cut -c1-140 >> $O
+    done
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
