@@ -32,7 +32,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define XK 32        // reduction elements per k-step
 #define XPITCH 104   // LDS row pitch in bf16 elements (3 planes x 32 + 8)
 
-// x = h + m + l exactly (RNE conversions; x - h and x - h - m are exact in fp32)
+// x = h + m + l exactly (RNE conversions; x - h and x - h - m are exact in fp32) for 2^-110 <= |x| < 3.38e38 and for 0: below, the low
+// planes underflow bf16's denormal grid (absolute error < 2^-133); within 0.3 % of FLT_MAX h rounds to infinity -- a value no fp32
+// accumulation of this network survives either (tests/test_x3_arithmetic.py pins both limits)
 __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 {
     h = (__bf16)x;
