@@ -123,6 +123,63 @@ def _control_flow_selftest(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
+    """The `roofline` object from the plan's timed launches (`timed`: the CONV / CHAIN / WINO_IN / WINO_OUT ops in launch order) and their
+    per-launch times in ms (`per_ms`, same order).  Pure arithmetic (tests/test_bench_roofline.py feeds it made-up times).
+
+    fp32 engine = two matrix pipes: the launches `Plan.mark_x3` put on csrc/hvn_conv_x3.hip issue bf16 MFMAs (6 | 9 per fp32 product: exact
+    three-way bf16 splits of fp32 operands, fp32 accumulation); the rest (d0's chained 1x1 pairs, grouped 5x5, d0's first 1x1) issue fp32
+    MFMAs; the Winograd transforms issue none.  The DOMINANT kernel is the bf16x3 one: `achieved` / `peak` / `frac` describe it on ITS
+    pipe; `other_launches` the fp32-pipe launches + transforms; `whole_step` both, as ideal matrix time (each launch's executed FLOPs / its
+    pipe's peak) over measured time.  Without bf16x3 launches (HVN_X3=0, the bf16 engine): one pipe, round 3's accounting."""
+    convs = [o for o in timed if o.kind in (2, 8)]
+    algo_flops = sum(o.flops() for o in convs) * batch
+    exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in convs) * batch
+    launches, n_conv = len(per_ms), len(convs)
+    ms = float(sum(per_ms))
+    note = ("achieved = MFMA FLOPs executed by the launches (Winograd-domain GEMMs counted as issued; SURVEY 8d's direct-convolution figure is "
+            "`algorithmic_gflop_per_step` / batch) / summed HIP-event time of those launches, per-launch median of %d passes, single stream" % n_prof)
+    x3_ms = x3_eq = x3_bf16 = 0.0
+    rest_ms = rest_flops = 0.0
+    n_x3 = 0
+    if dtype == "fp32" and launches == len(timed):
+        for o, t in zip(timed, per_ms):
+            fl = o.extra.get("exec_flops", o.flops()) * batch if o.kind in (2, 8) else 0.0
+            if o.kind == 2 and o.extra.get("x3"):
+                x3_ms += float(t); x3_eq += fl; x3_bf16 += fl * int(o.extra["x3"]); n_x3 += 1
+            else:
+                rest_ms += float(t); rest_flops += fl
+    if n_x3 == 0:
+        peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+        achieved = exec_flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)" if dtype == "fp32" else "hvn_conv_igemm_bf16",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "flops_per_launch": exec_flops / max(1, n_conv), "avg_launch_ms": ms / max(1, launches),
+                "timed_launches_per_step": launches, "conv_launches_per_step": n_conv, "conv_ms_per_step": ms,
+                "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9,
+                "algorithmic_speedup": algo_flops / exec_flops, "note": note + " (incl. the Winograd transform launches)"}
+    ach_x3 = x3_bf16 / (x3_ms * 1e-3) / 1e12
+    ideal_ms = 1e3 * (x3_bf16 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
+    return {
+        "bound": "mfma", "kernel": "hvn_conv_igemm_x3 (fp32 convolution, products on the bf16 matrix pipe from exact bf16x3 splits of the fp32 operands)",
+        "achieved": ach_x3, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x3 / PEAK_BF16_MATRIX_TFLOPS, "traffic": None,
+        "launches": n_x3, "ms_per_step": x3_ms, "avg_launch_ms": x3_ms / n_x3, "flops_per_launch": x3_bf16 / n_x3,
+        "bf16_mfma_gflop_per_step": x3_bf16 / 1e9, "fp32_products_gflop_per_step": x3_eq / 1e9,
+        "fp32_equivalent_tflops": x3_eq / (x3_ms * 1e-3) / 1e12,
+        "other_launches": {"what": "fp32-MFMA launches (hvn_conv_chain_f32, hvn_conv_igemm_f32, hvn_dense_grouped*) + Winograd transform launches",
+                           "launches": launches - n_x3, "ms_per_step": rest_ms, "executed_gflop_per_step": rest_flops / 1e9,
+                           "achieved": rest_flops / (rest_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                           "frac": rest_flops / (rest_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS},
+        "whole_step": {"conv_ms_per_step": ms, "ideal_matrix_ms": ideal_ms, "frac": ideal_ms / ms,
+                       "fp32_equivalent_tflops": exec_flops / (ms * 1e-3) / 1e12,
+                       "what": "ideal = each launch's executed MFMA FLOPs / the dense peak of the pipe it issues on (bf16 2500, fp32 157.3 TFLOP/s); "
+                               "fp32_equivalent = fp32 multiply-adds of the executed GEMMs (each counted once) / time: comparable with round 3's "
+                               "`achieved` (102.5), not a fraction of any one pipe's peak"},
+        "timed_launches_per_step": launches, "conv_launches_per_step": n_conv, "conv_ms_per_step": ms,
+        "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9, "algorithmic_speedup": algo_flops / exec_flops,
+        "note": note}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -499,12 +556,9 @@ def main():
         eng = net_.engine(batch)
         assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: launch_schedule (1, 0)"
         timed = [o for o in eng.plan.ops if o.kind in (2, 8, 6, 7)]     # CONV, CHAIN (two chained 1x1 convs), WINO_IN, WINO_OUT: the launches hvn_profile times
-        convs = [o for o in timed if o.kind in (2, 8)]
-        algo_flops = sum(o.flops() for o in convs) * batch
-        exec_flops = sum(o.extra.get("exec_flops", o.flops()) for o in convs) * batch
         torch.cuda.synchronize(dev)
         buf = (ctypes.c_double * 4096)()
-        rows, launches = [], 0
+        rows = []
         for _ in range(n_prof):
             L.lib().hvn_profile_enable(1)
             run_desc.infer_step_device(tiles0, net_)            # same checkpoint, plan and kernels as the timed steps, ONE launch stream
@@ -512,60 +566,7 @@ def main():
             L.lib().hvn_profile_enable(0)
             rows.append(np.array(buf[:launches]))
         per = np.median(np.stack(rows), 0)                      # per launch: median of n_prof passes
-        ms = float(per.sum())
-        n_conv = len(convs)
-        note = ("achieved = MFMA FLOPs executed by the launches (Winograd-domain GEMMs counted as issued; SURVEY 8d's direct-convolution figure is "
-                "`algorithmic_gflop_per_step` / batch) / summed HIP-event time of those launches, per-launch median of %d passes, single stream" % n_prof)
-        if dtype != "fp32" or launches != len(timed):
-            peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
-            achieved = exec_flops / (ms * 1e-3) / 1e12
-            return {"bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)" if dtype == "fp32" else "hvn_conv_igemm_bf16",
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                    "flops_per_launch": exec_flops / max(1, n_conv), "avg_launch_ms": ms / max(1, launches),
-                    "timed_launches_per_step": launches, "conv_launches_per_step": n_conv, "conv_ms_per_step": ms,
-                    "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9,
-                    "algorithmic_speedup": algo_flops / exec_flops, "note": note + " (incl. the Winograd transform launches)"}
-        # fp32 engine: two matrix pipes.  The launches Plan.mark_x3 put on csrc/hvn_conv_x3.hip issue bf16 MFMAs (6 | 9 per fp32 product
-        # block: exact three-way bf16 splits of fp32 operands, fp32 accumulation); the rest (chained 1x1 pairs of d0 / d1, grouped 5x5,
-        # d0's first 1x1) issue fp32 MFMAs; the Winograd transforms issue none.  The DOMINANT kernel is the bf16x3 one: `achieved` / `peak` /
-        # `frac` describe it on ITS pipe; `other_launches` the fp32-pipe launches + transforms; `whole_step` both, as ideal matrix time
-        # (each launch's executed FLOPs / its pipe's peak) over measured time.
-        x3_ms = x3_eq = x3_bf16 = 0.0
-        rest_ms = rest_flops = 0.0
-        n_x3 = 0
-        for o, t in zip(timed, per):
-            fl = o.extra.get("exec_flops", o.flops()) * batch if o.kind in (2, 8) else 0.0
-            if o.kind == 2 and o.extra.get("x3"):
-                x3_ms += float(t); x3_eq += fl; x3_bf16 += fl * int(o.extra["x3"]); n_x3 += 1
-            else:
-                rest_ms += float(t); rest_flops += fl
-        if n_x3 == 0:
-            achieved = exec_flops / (ms * 1e-3) / 1e12
-            return {"bound": "mfma", "kernel": "hvn_conv_igemm_f32 (+ hvn_conv_chain_f32)", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "flops_per_launch": exec_flops / max(1, n_conv),
-                    "avg_launch_ms": ms / max(1, launches), "timed_launches_per_step": launches, "conv_launches_per_step": n_conv,
-                    "conv_ms_per_step": ms, "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9,
-                    "algorithmic_speedup": algo_flops / exec_flops, "note": note + " (incl. the Winograd transform launches)"}
-        ach_x3 = x3_bf16 / (x3_ms * 1e-3) / 1e12
-        ideal_ms = 1e3 * (x3_bf16 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
-        return {
-            "bound": "mfma", "kernel": "hvn_conv_igemm_x3 (fp32 convolution, products on the bf16 matrix pipe from exact bf16x3 splits of the fp32 operands)",
-            "achieved": ach_x3, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x3 / PEAK_BF16_MATRIX_TFLOPS, "traffic": None,
-            "launches": n_x3, "ms_per_step": x3_ms, "avg_launch_ms": x3_ms / n_x3, "flops_per_launch": x3_bf16 / n_x3,
-            "bf16_mfma_gflop_per_step": x3_bf16 / 1e9, "fp32_products_gflop_per_step": x3_eq / 1e9,
-            "fp32_equivalent_tflops": x3_eq / (x3_ms * 1e-3) / 1e12,
-            "other_launches": {"what": "fp32-MFMA launches (hvn_conv_chain_f32, hvn_conv_igemm_f32, hvn_dense_grouped*) + Winograd transform launches",
-                               "launches": launches - n_x3, "ms_per_step": rest_ms, "executed_gflop_per_step": rest_flops / 1e9,
-                               "achieved": rest_flops / (rest_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                               "frac": rest_flops / (rest_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS},
-            "whole_step": {"conv_ms_per_step": ms, "ideal_matrix_ms": ideal_ms, "frac": ideal_ms / ms,
-                           "fp32_equivalent_tflops": exec_flops / (ms * 1e-3) / 1e12,
-                           "what": "ideal = each launch's executed MFMA FLOPs / the dense peak of the pipe it issues on (bf16 2500, fp32 157.3 TFLOP/s); "
-                                   "fp32_equivalent = fp32 multiply-adds of the executed GEMMs (each counted once) / time: comparable with round 3's "
-                                   "`achieved` (102.5), not a fraction of any one pipe's peak"},
-            "timed_launches_per_step": launches, "conv_launches_per_step": n_conv, "conv_ms_per_step": ms,
-            "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9, "algorithmic_speedup": algo_flops / exec_flops,
-            "note": note}
+        return roofline_account(timed, per, batch, dtype, n_prof)
 
     def measure_traffic(n_conv):
         """HBM bytes per conv launch, measured NOW: two `rocprofv3 --pmc` child runs of this script (FETCH_SIZE and WRITE_SIZE need
