@@ -1,12 +1,18 @@
 // hvn_train_api.hip -- C ABI of the training step (include/hvn.h, "training" section): descriptor validation and
 // dispatch of hvn_top lists, the loss stages and the Adam update.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
 
 #include "../../include/hvn.h"
 #include "hvn_kernels.h"
+
+// PACK_MULTI's device table is written by the host as hvn_pack_desc (include/hvn.h) and read by the kernel as PackArgs
+static_assert(sizeof(hvn_pack_desc) == sizeof(PackArgs) && offsetof(hvn_pack_desc, gmat) == offsetof(PackArgs, gmat) &&
+              offsetof(hvn_pack_desc, lead_pad) == offsetof(PackArgs, lead_pad) && offsetof(hvn_pack_desc, cout) == offsetof(PackArgs, cout),
+              "hvn_pack_desc must mirror PackArgs");
 
 static thread_local char t_err[256] = "";
 static int tfail(int code, const char *what, long i)
