@@ -233,8 +233,7 @@ def main():
     else:
         # HVN_BENCH_SHARED_GPU=1 (tests/test_gpu_two_ranks_one_gpu.py): every rank on cuda:0, collectives over gloo with device tensors staged
         # through the host -- the driver's exact N-rank command path with the real kernels on a one-GPU box; measures nothing comparable
-        shared = os.environ.get("HVN_BENCH_SHARED_GPU", "0") != "0"
-        local = 0 if shared else local
+        local = 0 if os.environ.get("HVN_BENCH_SHARED_GPU", "0") != "0" else local
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     shared_gpu = (not selftest) and os.environ.get("HVN_BENCH_SHARED_GPU", "0") != "0"
