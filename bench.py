@@ -667,7 +667,6 @@ def main():
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same tiles ------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import net_torch, process_np
-        from oracle import postproc as O
 
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         # torch-CPU does not scale to every hardware thread of a big host: the thread count is calibrated on the REAL work (the oracle
