@@ -521,6 +521,7 @@ def main():
                 variants["fp32_mfma_only"] = {"value": tiles_per_step_global * args.steps / dtn, "unit": "tiles/s", "ms_per_step": 1e3 * dtn / args.steps,
                                               "what": "the timed step with every conv launch on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; HVN_X3=0): "
                                                       "round 3's arithmetic, same checkpoint, same launch schedule"}
+                result["value_fp32_mfma_only"] = variants["fp32_mfma_only"]["value"]       # top level, next to `value` / `value_host_to_host`
                 del pipe_nat, net_nat
                 torch.cuda.empty_cache()
             if extra is None:
