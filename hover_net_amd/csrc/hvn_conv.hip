@@ -639,13 +639,9 @@ static int launch_conv(const ConvArgs &a, hipStream_t stream)
     p.n_tiles = (p.Cout + BN - 1) / BN;
     constexpr size_t stage_fl = (size_t)2 * (BM + BN) * LDS_LD, ep_fl = (size_t)BM * (BN + 4);   // staging buffers / epilogue tile (floats)
     const size_t lds = (stage_fl > ep_fl ? stage_fl : ep_fl) * sizeof(float);
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = hvn_conv_igemm_f32<BM, BN, WAVES_M, WAVES_N, PADDED, ABL, GROUPED, HAS_PRE, HAS_X2>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -2;
-        attr_done = true;
-    }
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long groups = (p.m_tiles + 7) / 8;
     const long grid = groups * 8 * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
@@ -840,12 +836,9 @@ static int launch_dense_grouped(const ConvArgs &a, hipStream_t stream)
 {
     const int tiles_x = (a.Wo + DG_TW - 1) / DG_TW, tiles_y = (a.Ho + DG_TH - 1) / DG_TH;
     const size_t lds = (size_t)(DG_TH + KS - 1) * (DG_TW + KS - 1) * DG_PP * sizeof(float);
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = hvn_dense_grouped_f32<KS>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done = true;
-    }
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long grid = 2L * tiles_x * tiles_y * a.N;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, tiles_x, tiles_y);
@@ -947,12 +940,9 @@ static int launch_dense_grouped2(const ConvArgs &a, hipStream_t stream)
 {
     const int tiles_x = (a.Wo + DG2_TW - 1) / DG2_TW, tiles_y = (a.Ho + DG2_TH - 1) / DG2_TH;
     const size_t lds = (size_t)(DG2_TH + KS - 1) * (DG2_TW + KS - 1) * DG_PP * sizeof(float);
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = hvn_dense_grouped2_f32<KS>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done = true;
-    }
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long grid = 2L * tiles_x * tiles_y * a.N;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, tiles_x, tiles_y);
@@ -1087,12 +1077,9 @@ static int launch_dense_grouped3(const ConvArgs &a, int run, hipStream_t stream)
     const int tiles_x = (a.Wo + DG2_TW - 1) / DG2_TW, tiles_y = (a.Ho + DG2_TH - 1) / DG2_TH;
     const int runs = (tiles_y + run - 1) / run;
     const size_t lds = (size_t)8 * (DG2_TW + KS - 1) * DG_PP * sizeof(float);
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = hvn_dense_grouped3_f32<KS>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done = true;
-    }
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long grid = 2L * tiles_x * runs * a.N;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, tiles_x, tiles_y, run, runs);

@@ -385,12 +385,9 @@ static int launch_bf16w(const ConvArgs &a, hipStream_t stream)
     p.n_tiles = (p.Cout + BN - 1) / BN;
     constexpr size_t stage_b = WIDE ? (size_t)(BM + BN) * LDW * 2 : (size_t)2 * (BM + BN) * LDH * 2, ep_b = (size_t)BM * (BN + 4) * 4;
     const size_t lds = stage_b > ep_b ? stage_b : ep_b;
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = hvn_conv_igemm_bf16<BM, BN, WAVES_M, WAVES_N, PADDED, HAS_PRE, HAS_X2, WIDE>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done = true;
-    }
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long groups = (p.m_tiles + 7) / 8;
     const long grid = groups * 8 * p.n_tiles;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;

@@ -385,12 +385,9 @@ static int launch_chain(const ChainArgs &a, hipStream_t stream)
 {
     constexpr size_t lds = (size_t)(2 * (BM + CH_BN) * 32 + (BM == 64 ? 1 : 2) * N2 * 32) * sizeof(float);
     static_assert((size_t)BM * CH_EP <= (size_t)2 * (BM + CH_BN) * 32, "the epilogue tile must fit the staging buffers it aliases");
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};
     auto kern = hvn_conv_chain_f32<BM, N2, HAS_X2>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done = true;
-    }
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long grid = (a.M + BM - 1) / BM;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
     static unsigned long long *dbg_buf = nullptr;

@@ -3,6 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel instantiation, device), from any
+// host thread.  `done` = one bit per device ordinal (function-local static of the launcher).  Returns 0, or -2 when the runtime refuses.
+static inline int hvn_max_lds_once(const void *kern, int bytes, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -2;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 struct ConvArgs {
     const float *x;
     long xsn, xsy, xsx;

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "../../include/hvn.h"
+#include "hvn_kernels.h"
 
 #define PP_T 256
 
@@ -1375,13 +1376,9 @@ static int postproc_impl(const float *pred, int n, int h, int w, int c, int c0, 
     hipLaunchKernelGGL(ws_list, grid, blk, 0, s, b);
     long maxc = b.P / 10 + 1;
     if (maxc > 2048) maxc = 2048;
-    static bool ws_attr = false;
-    if (!ws_attr) {
-        if (hipFuncSetAttribute((const void *)ws_component, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void *)ws_fallback, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess)
-            return HVN_E_LAUNCH;
-        ws_attr = true;
-    }
+    static std::atomic<unsigned long long> ws_attr_c{0}, ws_attr_f{0};     // per device (hvn_kernels.h)
+    if (hvn_max_lds_once((const void *)ws_component, WS_LDS_BYTES, ws_attr_c) || hvn_max_lds_once((const void *)ws_fallback, WS_LDS_BYTES, ws_attr_f))
+        return HVN_E_LAUNCH;
     if (!ws_mode) {
         hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_SMALL_LDS, s, b, 0, WS_SMALL_LDS);
         hipLaunchKernelGGL(ws_component, dim3((unsigned)maxc, n), dim3(64), WS_LDS_BYTES, s, b, 1, WS_LDS_BYTES);
@@ -1530,6 +1527,24 @@ int hvn_postproc_taps(const float *pred, int n, int h, int w, int c, int c0, int
                       int32_t *marker, void *workspace, size_t workspace_bytes, void *stream)
 {
     return postproc_impl(pred, n, h, w, c, c0, inst, blb, dist, marker, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int hvn_postproc_stats(const void *workspace, size_t workspace_bytes, int n, int h, int w, long long out[10], void *stream)
+{
+    if (!workspace || !out || n <= 0 || h <= 0 || w <= 0) return HVN_E_ARG;
+    if (workspace_bytes < hvn_postproc_workspace_bytes(n, h, w)) return HVN_E_SIZE;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return HVN_E_LAUNCH;
+    std::vector<TileStat> hs(n);            // the per-map reduction slots lead the workspace (carve)
+    if (hipMemcpy(hs.data(), workspace, sizeof(TileStat) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return HVN_E_LAUNCH;
+    for (int k = 0; k < 10; ++k) out[k] = 0;
+    for (int i = 0; i < n; ++i) {
+        out[0] += hs[i].n_comp;
+        out[1] += hs[i].dbg[0]; out[2] += hs[i].dbg[1]; out[3] += hs[i].dbg[2];
+        out[4] += hs[i].dbg[3]; out[5] += hs[i].dbg[4]; out[6] += hs[i].dbg[5]; out[7] += hs[i].dbg[6];
+        out[8] += hs[i].tie != 0;
+        if (hs[i].max_area > out[9]) out[9] = hs[i].max_area;
+    }
+    return HVN_OK;
 }
 
 }  // extern "C"

@@ -378,11 +378,8 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream)
     ksplit = (R + rps - 1) / rps;
     a.rows_per_split = (unsigned)rps;
     auto k = hvn_conv_wgrad_f32<BM, BN, WAVES_M, WAVES_N>;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static std::atomic<unsigned long long> attr{0};
+    if (hvn_max_lds_once(reinterpret_cast<const void *>(k), (int)lds, attr)) return -2;
     hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)ksplit, (unsigned)nb), dim3(256), lds, stream, a);
     return launch_ok();
 }
@@ -1013,11 +1010,8 @@ int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream)
     if (valu < 0) valu = getenv("HVN_CONV0_WGRAD_VALU") ? 1 : 0;
     if (!valu) {
         const size_t lds = (size_t)(W0_P * W0M_PITCH + 64 * 160) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(hvn_conv0_wgrad_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        static std::atomic<unsigned long long> attr{0};
+        if (hvn_max_lds_once(reinterpret_cast<const void *>(hvn_conv0_wgrad_mfma), (int)lds, attr)) return -2;
         long blocks = total < 512 ? total : 512;
         hipLaunchKernelGGL(hvn_conv0_wgrad_mfma, dim3((unsigned)blocks), dim3(256), lds, stream, a, tx, ty, total);
         return launch_ok();

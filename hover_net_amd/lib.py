@@ -64,7 +64,7 @@ class hvn_inst_rec(ctypes.Structure):
 EXPORTS = (
     "hvn_version", "hvn_build_id", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_profile_conv_ms_list", "hvn_postproc_workspace_bytes", "hvn_postproc",
-    "hvn_postproc_taps", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
+    "hvn_postproc_taps", "hvn_postproc_stats", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
     "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
     "hvn_extract_patches", "hvn_gen_targets", "hvn_gen_targets_workspace_bytes", "hvn_augment_shape", "hvn_augment_input",
     "hvn_wsi_merge_normal", "hvn_wsi_merge_fixing",
@@ -102,6 +102,20 @@ def _built_id(path):
     return data[i + 13:j].decode(errors="replace")
 
 
+_HIPCC_VERSION = None
+
+
+def _hipcc_version():
+    """`hipcc --version` (bytes): part of every cached object's key -- an object built by another ROCm must not be linked."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run(["hipcc", "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=60).stdout
+        except (OSError, subprocess.SubprocessError):
+            _HIPCC_VERSION = b"hipcc-unknown"
+    return _HIPCC_VERSION
+
+
 def _compile(out, extra, verbose):
     """One object per source, compiled in parallel and cached by the hash of what it is built from (the source, both headers, the
     flags) under csrc/.obj/, then linked: editing one kernel file recompiles that file only (~30 s instead of ~150 s for all).
@@ -117,19 +131,31 @@ def _compile(out, extra, verbose):
     jobs, objs = [], []
     for src in SOURCES:
         defs = ['-DHVN_BUILD_ID="%s"' % sid] if src == "hvn_api.hip" else []
-        h = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr + " ".join(cflags + defs).encode()).hexdigest()[:16]
+        h = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr + " ".join(cflags + defs).encode() + _hipcc_version()).hexdigest()[:16]
         obj = os.path.join(objdir, "%s.%s.o" % (src, h))
         objs.append(obj)
         if not os.path.exists(obj):
-            for old in os.listdir(objdir):          # one cached object per source and flag set is enough
-                if old.startswith(src + ".") and not extra:
+            tag = os.path.join(objdir, "%s.flags-%s" % (src, hashlib.sha256(" ".join(extra).encode()).hexdigest()[:8]))
+            if os.path.exists(tag):                 # one cached object per (source, flag set): drop the one this flag set built before
+                old = open(tag).read().strip()
+                if old and os.path.exists(os.path.join(objdir, old)):
                     os.remove(os.path.join(objdir, old))
+            open(tag, "w").write(os.path.basename(obj))
             jobs.append(["hipcc", *cflags, *defs, "-c", os.path.join(CSRC, src), "-o", obj])
 
     def run(cmd):
+        # hipcc writes its output in place: compile / link to a private name and rename on success, so that a build killed mid-write
+        # (the GPU scripts wrap everything in `timeout`) or two ranks building at once never leave a truncated file under the final name
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        final = cmd[-1]
+        tmp = "%s.tmp.%d" % (final, os.getpid())
+        try:
+            subprocess.check_call(cmd[:-1] + [tmp])
+            os.replace(tmp, final)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
@@ -195,6 +221,7 @@ def lib():
         L.hvn_postproc_taps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.hvn_postproc_stats.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_instance_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_size_t, ctypes.c_void_p]

@@ -37,8 +37,12 @@ def _align(n, a=64):
 
 
 class TrainEngine:
-    def __init__(self, net, batch, device=None):
+    def __init__(self, net, batch, device=None, share_shapes=True):
+        """share_shapes: data-parallel runs broadcast rank 0's measured launch shapes at the END of this constructor (one small
+        collective, `_share_launch_shapes`): only legal when EVERY rank builds an engine at this point.  `engine_for` passes True for a
+        module's first engine (every rank builds it at its first step) and False for rebuilds, which one rank may do alone."""
         L.require_gpu()
+        self._share_shapes = bool(share_shapes)
         self.net = net
         self.n = int(batch)
         self.device = torch.device(device) if device is not None else next(net.parameters()).device
@@ -197,6 +201,13 @@ class TrainEngine:
                 d.src, d.dst = self.wptr(key), self.packs.data_ptr() + 4 * off
                 d.cout, d.cin_g, d.groups, d.taps, d.mode, d.lead_pad = cout, cin_g, max(1, groups), kh * kw, mode, lead
                 total = 64 * kh * kw * 3 if mode == 2 else (lead * cin_g * max(1, groups) * kh * kw if mode == 0 else lead * cout * kh * kw)
+                # HVN_T_PACK_MULTI runs the table on the device without HVN_T_PACK_W's per-call checks: the same checks, here
+                cin = cin_g * max(1, groups)
+                rows = cout if mode == 0 else cin
+                if (not d.src or not d.dst or d.dst % 16 or (mode == 0 and cin % 32) or (mode == 1 and cout % 32) or
+                        (mode != 2 and lead < rows) or total <= 0):
+                    raise ValueError("weight packing %s mode %d: cout %d cin %d groups %d lead_pad %d is not a shape hvn_pack_w_multi may run"
+                                     % (key, mode, cout, cin, groups, lead))
                 table.append(d)
                 blocks.append(blocks[-1] + (total + 255) // 256)
                 continue
@@ -501,11 +512,15 @@ class TrainEngine:
     def _share_launch_shapes(self):
         """Data-parallel training: every rank times its own launches, and noise could give two ranks different weight-gradient splits,
         i.e. different fp32 summation orders of the same gradient (harmless after the all-reduce, but run-to-run variation nobody asked
-        for).  Rank 0's choices are broadcast (one small int32 tensor at engine build; every rank builds its engine at the same step).
-        HVN_TILE_SHARE=0 keeps the per-rank choices."""
+        for).  Rank 0's choices are broadcast: one small int32 tensor at the build of a module's FIRST engine, which every rank does at
+        its first training step (`engine_for`; train.run_phases makes a new module per phase and drops ragged batches, so each phase's
+        engines are built in lock-step).  A REBUILD -- another batch size or freeze flag on a module that already has an engine, e.g. the
+        ragged last batch of an external loader on ONE rank -- issues no collective (it would pair with the other ranks' gradient
+        all-reduce) and keeps that rank's own timings.  HVN_TILE_SHARE=0 keeps the per-rank choices everywhere."""
         import torch.distributed as dist
 
-        if os.environ.get("HVN_TILE_SHARE", "1") == "0" or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if (not self._share_shapes or os.environ.get("HVN_TILE_SHARE", "1") == "0" or
+                not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)):
             return
         convs = [o for o in self._keep if isinstance(o, L.hvn_op) and o.kind == OP_CONV]
         tops = [self.bwd_ops[i] for i in range(len(self.bwd_ops)) if self.bwd_ops[i].kind == T_WGRAD]
@@ -680,6 +695,6 @@ def engine_for(net, batch):
     """The module's training engine for this batch size (built on first use, rebuilt when the batch size changes)."""
     eng = getattr(net, "_train_engine", None)
     if eng is None or eng.n != int(batch) or eng.plan.freeze != net.freeze:
-        eng = TrainEngine(net, batch)
+        eng = TrainEngine(net, batch, share_shapes=eng is None)      # a rebuild may happen on one rank alone: no collective in it
         net._train_engine = eng
     return eng

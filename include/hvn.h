@@ -137,6 +137,12 @@ HVN_API int hvn_postproc(const float *pred, int n, int h, int w, int c, int c0,
 HVN_API int hvn_postproc_taps(const float *pred, int n, int h, int w, int c, int c0, int32_t *inst,
                               int32_t *blb, double *dist, int32_t *marker,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* which replay the marker-controlled watershed (post_proc.py:88) of the LAST hvn_postproc call on `workspace` took, summed over its
+ * n maps (waits for `stream`): out[0] components that hold a marker, out[1] replayed on the small LDS window, out[2] on the bitmap
+ * window, out[3] on the HBM window, out[4] handed to the one-lane heap by a mixed-label marker tie, out[5] by a full frontier,
+ * out[6] component heap replays, out[7] WHOLE-TILE replays (a tie the component replay could not prove harmless), out[8] maps
+ * flagged with such a tie, out[9] largest component bounding box. */
+HVN_API int hvn_postproc_stats(const void *workspace, size_t workspace_bytes, int n, int h, int w, long long out[10], void *stream);
 
 /* -- per-instance table: post_proc.py:119-181 process() (bbox, centroid, type vote) ----- */
 typedef struct hvn_inst_rec {
@@ -208,7 +214,9 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *                p[0] = A^T [4][8], kh x kw = tile grid
  *   WINO_DW      grad g [cout][25][cin] (p[1]) += G^T dU G of dU [64][cout][cin] (p[0]), p[2] = G [8][5]; cout, cin_g
  *   PACK_MULTI   every mode 0 / 1 / 2 PACK_W of a step in one launch: p[0] = dev table of hvn_pack_desc [cout], p[1] = dev int32
- *                [cout + 1] first workgroup (of 256 outputs) of each packing, batch_stride[0] = workgroups in total
+ *                [cout + 1] first workgroup (of 256 outputs) of each packing, batch_stride[0] = workgroups in total.  The table lives
+ *                in device memory, so PACK_W's shape checks (cin % 32 / cout % 32, lead_pad >= rows, non-null pointers) cannot be
+ *                made at the call: the CALLER makes them when it builds the table (train_engine._pack_ops raises on a bad entry)
  *   SPLIT_X3     p[0] = fp32 weight packings (batch_stride[0] granules of 32 floats, any concatenation of PACK_W outputs), p[1] = their
  *                three bf16 planes, [3][32] bf16 per granule: what a CONV with act_dtype 2 | 3 reads (the weights of a training step
  *                change every step, so the planes are made on the device after the PACK_W ops)
