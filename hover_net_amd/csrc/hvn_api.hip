@@ -177,7 +177,13 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         if (g_prof) prof_mark(s);
         const bool x3 = op->act_dtype == 2 || op->act_dtype == 3;
         if (x3 && (a.groups > 1 || (a.nbatch > 1 && (a.wb & 7)))) return fail(HVN_E_ARG, "conv(bf16x3): no grouped convs; batch stride of the planes must keep 16-byte alignment%s", "");
-        int rc = bf16 ? hvn_launch_conv_bf16(a, op->tile_n, s) : x3 ? hvn_launch_conv_x3(a, op->tile_n, op->act_dtype == 3 ? 6 : 9, s) : hvn_launch_conv(a, op->tile_n, s);
+        int rc;
+        if (bf16)
+            rc = hvn_launch_conv_bf16(a, op->tile_n, s);
+        else if (x3 && (op->tile_n == 896 || op->tile_n == 640))      // LDS-DMA form, 256 | 128 pixels x 128 channels (hvn_conv_x3g.hip)
+            rc = hvn_launch_conv_x3g(a, op->tile_n == 896 ? 256 : 128, op->act_dtype == 3 ? 6 : 9, s);
+        else
+            rc = x3 ? hvn_launch_conv_x3(a, op->tile_n, op->act_dtype == 3 ? 6 : 9, s) : hvn_launch_conv(a, op->tile_n, s);
         if (g_prof) prof_mark(s);
         if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "conv: launch failed (tile_n=%s%ld)", "", op->tile_n);
         return 0;

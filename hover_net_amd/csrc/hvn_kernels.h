@@ -82,6 +82,9 @@ int hvn_chain_supported(int c, int n2);
 int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream);   // x, res, y, x2, w are bf16; bias / scales fp32
 // fp32 in / out; w = [cout_pad][k-step][3][32] bf16 planes of the fp32 weights; terms = 9 | 6 partial products (hvn_conv_x3.hip)
 int hvn_launch_conv_x3(const ConvArgs &a, int tile_n, int terms, hipStream_t stream);
+// the same convolution (same packing, same bits) with both operands staged by LDS-DMA, bm = 256 | 128 pixels x 128 channels (hvn_conv_x3g.hip)
+int hvn_launch_conv_x3g(const ConvArgs &a, int bm, int terms, hipStream_t stream);
+int hvn_conv_x3g_supported(const ConvArgs &a, int bm);
 // fp32 packings ([...][32]-float granules) -> their bf16 planes [3][32] per granule (training: weights change every step)
 int hvn_launch_split_x3(const float *src, uint16_t *dst, long granules, hipStream_t stream);
 

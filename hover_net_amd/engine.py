@@ -56,6 +56,30 @@ def pick_tile_n(op, batch):
     return 64 if narrow < wide else 128
 
 
+X3G_256, X3G_128 = 128 + 0x300, 128 + 0x200     # hvn_op.tile_n of the LDS-DMA forms of the bf16x3 convolution (include/hvn.h)
+
+
+def x3g_forms_for(op):
+    """The LDS-DMA workgroup shapes (csrc/hvn_conv_x3g.hip) a bf16x3 CONV launch may run on besides hvn_conv_x3.hip's, as tile_n codes:
+    they need >= 128 output channels and, with a prologue, its two per-channel vectors next to the operand rings in the CU's 160 KB of
+    LDS.  Same packing, same bits (tests/test_gpu_x3.py): which one runs is a timing decision (`Engine.autotune_tiles`).  HVN_X3G=0
+    keeps hvn_conv_x3.hip everywhere; HVN_X3G=896 | 640 offers one form only."""
+    import os
+
+    want = os.environ.get("HVN_X3G", "1")
+    if want == "0" or op.cout < 128 or int(op.extra.get("groups", 1)) != 1:
+        return ()
+    cin = op.x.c
+    forms = []
+    for code, bm, na in ((X3G_256, 256, 3), (X3G_128, 128, 2)):
+        if want not in ("1", str(code)):
+            continue
+        if op.pre is not None and na * bm * 128 + 2 * 3 * 128 * 64 + 2 * cin * 4 > 160 * 1024:
+            continue
+        forms.append(code)
+    return tuple(forms)
+
+
 def to_bf16_bits(a):
     """float32 array -> bfloat16 bit patterns (uint16), round to nearest even."""
     u = np.ascontiguousarray(a, np.float32).view(np.uint32)
@@ -142,7 +166,8 @@ class Engine:
             if len(tiles) != len(self.ops):
                 raise ValueError("HVN_TILE_FILE holds %d entries for a plan of %d ops" % (len(tiles), len(self.ops)))
             for o, op, tn in zip(self.ops, plan.ops, tiles):
-                if op.kind == PL.OP_CONV and ((op.tile_n == 128 and tn in (64, 128)) or (op.tile_n == 64 and tn in (64, 320) and not op.extra.get("x3"))):
+                if op.kind == PL.OP_CONV and ((op.tile_n == 128 and (tn in (64, 128) or (op.extra.get("x3") and tn in x3g_forms_for(op)))) or
+                                              (op.tile_n == 64 and tn in (64, 320) and not op.extra.get("x3"))):
                     o.tile_n = tn
                 if op.kind == PL.OP_CHAIN and tn in (64, 128):
                     o.tile_n = tn
@@ -318,13 +343,30 @@ class Engine:
                 continue                                   # the fused-shortcut and bf16x3 instantiations exist for 128 x 128 and 128 x 64 tiles only
             key = key + (int(op.extra.get("x3", 0)),)
             cands = (128, 64) if op.tile_n == 128 else (64, 320)
+            if op.tile_n == 128 and op.extra.get("x3") and x3g_forms_for(op):
+                # + the LDS-DMA forms of the bf16x3 kernel (csrc/hvn_conv_x3g.hip): 256 | 128 pixels x 128 channels, same bits
+                forced = os.environ.get("HVN_X3G_FORCE")       # tests / A-B runs: that form wherever it exists, no timing
+                if forced and int(forced) in x3g_forms_for(op):
+                    self.ops[i].tile_n = int(forced)
+                    try:
+                        time_op(i)
+                        continue
+                    except L.HvnError:
+                        self.ops[i].tile_n = 128
+                cands = cands + x3g_forms_for(op)
             if key not in self.tile_choice:
                 o = self.ops[i]
                 t = {}
                 for tn in cands:
                     o.tile_n = tn
-                    t[tn] = time_op(i)
-                self.tile_choice[key] = (cands[1] if t[cands[1]] < margin * t[cands[0]] else cands[0], t[cands[0]], t[cands[1]])
+                    try:
+                        t[tn] = time_op(i)
+                    except L.HvnError:
+                        if tn in (128, 64, 320):
+                            raise
+                        t[tn] = float("inf")       # an LDS-DMA form the launcher refuses for this geometry (32-bit reach of a 256-row tile)
+                best = min(cands[1:], key=lambda tn: t[tn])
+                self.tile_choice[key] = (best if t[best] < margin * t[cands[0]] else cands[0], t[cands[0]], t[best], dict(t))
             self.ops[i].tile_n = self.tile_choice[key][0]
         torch.cuda.synchronize(self.device)
 

@@ -93,7 +93,9 @@ typedef struct hvn_op {
                             holds the three bf16 planes of the fp32 packing, [cout_pad][k-step][3][32] bf16 (k-step = (x.c/32 slab,
                             tap), the fp32 packing's order) and batch_stride[1] counts bf16 elements; 2 = all nine partial
                             products (the fp32 dot product in another summation order), 3 = the six that carry more than 2^-24
-                            of a product */
+                            of a product.  tile_n of such a CONV: 128 | 64 = 128 pixels x tile_n channels per workgroup
+                            (hvn_conv_x3.hip); 128 + 0x300 (896) | 128 + 0x200 (640) = 256 | 128 pixels x 128 channels with both operands
+                            staged by LDS-DMA (csrc/hvn_conv_x3g.hip; cout >= 128; same bits as the other forms) */
     /* CHAIN only: the second conv's output view, packed weights, bias (or NULL) and channel count */
     hvn_view y2;
     const float *w2, *bias2; /* dev */

@@ -150,6 +150,125 @@ def test_winograd_domain_product(m, k, cin, cout, s, pad, terms):
     _check(eng.buffer(PL.View(ybuf), n).cpu()[..., 32:], want, 5e-4)
 
 
+# ---- csrc/hvn_conv_x3g.hip: the same convolution with both operands staged by LDS-DMA and the split at the fragment read; tile_n codes
+#      896 (256 pixels x 128 channels, 8 waves) and 640 (128 x 128, 4 waves).  Same packing, same k-slot assignment, same MFMA order per
+#      accumulator: BIT-IDENTICAL to hvn_conv_x3.hip's 128 x 128 form, for every launch class the plan puts on it. ---------------------------
+X3G_FORMS = [896, 640]
+X3G_CASES = {
+    # name: run_conv_case keywords (M = 338 .. 1323 pixels: partial last tiles of 128 and of 256 rows, tiles straddling samples)
+    "1x1_64_256_bn": dict(n=2, xbuf_shape=(13, 13, 64), xview=(0, 0, 13, 13, 0, 64), ybuf_shape=(13, 13, 256), yview=(0, 0, 13, 13, 0, 256), w=(256, 64, 1), bn=True, relu=1),
+    "1x1_2048_1024": dict(n=2, xbuf_shape=(13, 13, 2048), xview=(0, 0, 13, 13, 0, 2048), ybuf_shape=(13, 13, 1024), yview=(0, 0, 13, 13, 0, 1024), w=(1024, 2048, 1), bn=True, relu=1),
+    "1x1_288_128_window": dict(n=3, xbuf_shape=(21, 21, 320), xview=(1, 2, 19, 18, 0, 288), ybuf_shape=(19, 18, 160), yview=(0, 0, 19, 18, 32, 128), w=(128, 288, 1), bn=True, relu=1),
+    "res_post": dict(n=2, xbuf_shape=(17, 17, 64), xview=(0, 0, 17, 17, 0, 64), ybuf_shape=(17, 17, 256), yview=(0, 0, 17, 17, 0, 256), w=(256, 64, 1), res=True, post=True),
+    "res_inplace": dict(n=1, xbuf_shape=(20, 20, 64), xview=(0, 0, 20, 20, 0, 64), ybuf_shape=(20, 20, 128), yview=(0, 0, 20, 20, 0, 128), w=(128, 64, 1), res=True, inplace_res=True),
+    "prologue_1024_256": dict(n=2, xbuf_shape=(17, 17, 1024), xview=(0, 0, 17, 17, 0, 1024), ybuf_shape=(17, 17, 256), yview=(0, 0, 17, 17, 0, 256), w=(256, 1024, 1), pre=True, bn=True, relu=1),
+    "prologue_2048_512": dict(n=1, xbuf_shape=(12, 12, 2048), xview=(0, 0, 12, 12, 0, 2048), ybuf_shape=(12, 12, 512), yview=(0, 0, 12, 12, 0, 512), w=(512, 2048, 1), pre=True, bn=True, relu=1),
+    "1x1_stride2": dict(n=2, xbuf_shape=(24, 24, 256), xview=(0, 0, 24, 24, 0, 256), ybuf_shape=(12, 12, 512), yview=(0, 0, 12, 12, 0, 512), w=(512, 256, 1), stride=2),
+    "3x3_same": dict(n=2, xbuf_shape=(18, 18, 128), xview=(0, 0, 18, 18, 0, 128), ybuf_shape=(18, 18, 128), yview=(0, 0, 18, 18, 0, 128), w=(128, 128, 3), pad=(1, 1), bn=True, relu=1),
+    "3x3_same_stride2": dict(n=2, xbuf_shape=(18, 18, 128), xview=(0, 0, 18, 18, 0, 128), ybuf_shape=(9, 9, 128), yview=(0, 0, 9, 9, 0, 128), w=(128, 128, 3), stride=2, pad=(0, 1), bn=True, relu=1),
+    "5x5_valid_1024_256": dict(n=1, xbuf_shape=(12, 12, 1024), xview=(0, 0, 12, 12, 0, 1024), ybuf_shape=(8, 8, 512), yview=(0, 0, 8, 8, 0, 256), w=(256, 1024, 5)),
+}
+
+
+@pytest.mark.parametrize("form", X3G_FORMS)
+@pytest.mark.parametrize("case", sorted(X3G_CASES))
+def test_lds_dma_form_gives_the_bits_of_the_staged_form(case, form):
+    kw = dict(X3G_CASES[case])
+    cout, cin, k = kw.pop("w")
+    kw.update(wt=_w(cout, cin, k, seed=3), seed=9, x3=6)
+    ref, want = _case(force_tile=128, **kw)
+    got, _ = _case(force_tile=form, **kw)
+    _check(ref, want, TOL[6])
+    assert torch.equal(got, ref), "max abs difference %g" % (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("form", X3G_FORMS)
+def test_lds_dma_form_nine_terms_fused_shortcut_and_winograd_product(form):
+    import plan_interp
+    from gpu_util import MiniPlan, rand_conv_weight
+    from hover_net_amd import plan as PL
+    from hover_net_amd.engine import Engine
+
+    # nine partial products (the other instantiation family)
+    kw = dict(n=2, xbuf_shape=(13, 13, 128), xview=(0, 0, 13, 13, 0, 128), ybuf_shape=(13, 13, 512), yview=(0, 0, 13, 13, 0, 512),
+              wt=_w(512, 128, 1), bn=True, relu=1, res=True, seed=4, x3=9)
+    ref, want = _case(force_tile=128, **kw)
+    got, _ = _case(force_tile=form, **kw)
+    _check(ref, want, TOL[9])
+    assert torch.equal(got, ref)
+    # the strided 1x1 shortcut as a second K source (d1 .. d3 unit 0)
+    rng = np.random.default_rng(5)
+    outs = []
+    for tile in (128, form):
+        P = MiniPlan()
+        x = PL.View(P.buf("t2", 13, 13, 64))
+        x2 = PL.View(P.buf("xin", 26, 26, 256))
+        y = PL.View(P.buf("y", 13, 13, 512))
+        rng = np.random.default_rng(5)
+        op = P.conv("fused", x, y, rand_conv_weight(rng, 512, 64, 1), x2=x2, wt2=rand_conv_weight(rng, 512, 256, 1), stride2=2,
+                    post=(rng.uniform(0.5, 1.5, 512), rng.normal(0, 0.3, 512)))
+        op.extra["x3"] = 6
+        P.pack()
+        eng = Engine(P, max_batch=2, n_split=1)
+        eng.arena.copy_(torch.randn(eng.arena.shape, generator=torch.Generator().manual_seed(1)))
+        eng.ops[0].tile_n = tile
+        if tile == 128:
+            A = plan_interp.Arena(P, 2)
+            A.flat.copy_(eng.arena.cpu())
+            want = plan_interp.conv_ref(op, A.view(op.x).clone(), None, A.view(x2).clone())
+        eng.run_raw(2)
+        torch.cuda.synchronize()
+        outs.append(eng.buffer(op.y, 2).cpu().clone())
+    _check(outs[0], want, TOL[6])
+    assert torch.equal(outs[0], outs[1])
+    # the batched transform-domain product of a Winograd convolution (blockIdx.y = position)
+    outs = []
+    for tile in (128, form):
+        P = MiniPlan()
+        x = PL.View(P.buf("x", 33, 33, 512))
+        ybuf = P.buf("y", 33, 33, 512)
+        P.conv_winograd("w", x, PL.View(ybuf), rand_conv_weight(np.random.default_rng(7), 512, 512, 3), pad=(1, 1), m=6)
+        gi = [i for i, o in enumerate(P.ops) if o.kind == PL.OP_CONV][0]
+        P.ops[gi].extra["x3"] = 6
+        ybuf.first = 0
+        P.pack()
+        eng = Engine(P, max_batch=2, n_split=1)
+        eng.arena.copy_(torch.randn(eng.arena.shape, generator=torch.Generator().manual_seed(3)))
+        eng.ops[gi].tile_n = tile
+        eng.run_raw(2)
+        torch.cuda.synchronize()
+        outs.append(eng.buffer(PL.View(ybuf), 2).cpu().clone())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name", ["orig5", "fast6"])
+def test_network_with_the_lds_dma_forms_forced_is_bit_equal(name, monkeypatch):
+    """Every bf16x3 launch that has an LDS-DMA form on that form (HVN_X3G_FORCE = 896 | 640) against hvn_conv_x3.hip everywhere (HVN_X3G=0):
+    the logits carry the same bits -- which form a launch runs on is a timing decision of the engine, invisible in the results."""
+    from test_oracle_net import load_case
+    from hover_net_amd import net_desc, plan as PL, run_desc
+
+    mode, nt, sd, tiles, crop, logits, pmap = load_case(name)
+    x = torch.from_numpy(tiles)
+    outs, counts = [], []
+    for env in ({"HVN_X3G": "0"}, {"HVN_X3G_FORCE": "896"}, {"HVN_X3G_FORCE": "640"}):
+        for k in ("HVN_X3G", "HVN_X3G_FORCE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
+        net.load_state_dict(sd, strict=True)
+        net = net.to("cuda").eval()
+        run_desc.infer_step_device(x, net)
+        eng = net.engine(x.shape[0])
+        counts.append(sum(1 for o in eng.ops if o.kind == PL.OP_CONV and o.tile_n in (896, 640)))
+        outs.append({k: eng.logits[k][:x.shape[0]].cpu().clone() for k in eng.logits})
+    assert counts[0] == 0 and counts[1] > 40 and counts[2] > 40, counts
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], o[k]), k
+
+
 @pytest.mark.parametrize("terms", ["9", "6"])
 @pytest.mark.parametrize("name", ["orig5", "fast6"])
 def test_network_on_the_bf16x3_kernels_matches_reference_golden(name, terms, monkeypatch):

@@ -3,7 +3,7 @@
 # what is to be judged is copied to profiles/ afterwards.  tools/refresh_profiles.sh is the round-end target set.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-T=${1:-bench}; R=${2:-r04}; O=gpurun_out/${R}_${T}.log; : > $O
+T=${1:-bench}; R=${2:-r05}; O=gpurun_out/${R}_${T}.log; : > $O
 bench() {   # bench <name> [env / args ...]: one bench.py run -> gpurun_out/<R>_<name>.json + its summary in the log
   local name=$1; shift
   SECONDS=0
@@ -81,6 +81,16 @@ PY
       rm -rf gpurun_out/${R}_tprof$ph
       head -16 gpurun_out/${R}_train_kernel_stats_phase$ph.csv | cut -c1-140 >> $O
     done
+    ;;
+  x3g)        # round 5: the LDS-DMA forms of the bf16x3 kernel (csrc/hvn_conv_x3g.hip): bit-equality tests, per-launch tables with every
+              # eligible launch forced onto hvn_conv_x3.hip | the 256-pixel form | the 128-pixel form, then bench lines without / with them
+    timeout 900 python -m pytest tests/test_gpu_x3.py -q -k "lds_dma" --tb=line 2>&1 | tail -40 >> $O
+    for cfg in "HVN_X3G=0" "HVN_X3G_FORCE=896" "HVN_X3G_FORCE=640"; do
+      f=gpurun_out/${R}_layers_$(echo $cfg | tr -d ' =A-Z_').txt
+      env $cfg timeout 300 python tools/layer_ms.py > $f 2>&1; echo "== $cfg: $(tail -1 $f)" >> $O
+    done
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for cfg in "HVN_X3G=0" "HVN_X3G=1"; do ENVV=($cfg); bench x3g_$(echo $cfg | tr -d ' =A-Z_') $Q; done
     ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
