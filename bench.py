@@ -34,11 +34,18 @@ runs the network + instance separation on its own batch (weak scaling, global ba
 are gathered to rank 0 INSIDE the timed step (`infer_tile.gather_to_rank0`, the collective north_star names).
 `--scaling strong` keeps a fixed set of --strong-tiles tiles and splits it over the ranks instead.
 
-`roofline` is for the dominant kernel (`hvn_conv_igemm_f32`, fp32 MFMA): achieved = MFMA FLOPs the conv
-launches of one step EXECUTE (after the Winograd transforms: that is what the matrix pipe issues) / summed
-HIP-event duration of those launches, measured on the single-stream engine (same plan, same kernels).
-`algorithmic_speedup` = direct-convolution FLOPs / executed FLOPs (what Winograd removes) is reported
-beside it, never folded into `frac`.  `cpu_baseline` (N = 1 only) times the CPU oracle -- torch fp32
+`roofline` is for the dominant kernel -- the bf16x3 convolution (`hvn_conv_igemm_x3` / its LDS-DMA form `hvn_conv_igemm_x3g`: fp32
+operands and accumulation, products on the bf16 matrix pipe): achieved = bf16 MFMA FLOPs its launches of one step ISSUE (6 per fp32
+multiply-add, after the Winograd transforms) / summed HIP-event duration of those launches, measured on the single-stream engine (same
+plan, same kernels), against the 2.5 PFLOP/s dense bf16 peak; `fp32_equivalent_tflops` counts each fp32 product once (comparable with
+round 3's `achieved`); `other_launches` = the fp32-pipe launches and the Winograd transforms.  `algorithmic_speedup` =
+direct-convolution FLOPs / executed FLOPs (what Winograd removes) is reported beside it, never folded into `frac`.
+`variants.train_step` (BASELINE cfg 5 at N = 1: both phases of the two-stage schedule) and `variants.wsi_8k` (cfg 4 scaled to one GPU:
+an 8192^2 synthetic slide) are timed outside the headline's timed region; `flood_whole_tile_replays` counts the watershed's exact
+whole-tile replays over the network's own output of the timed step.
+
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts itself under
+`python -m torch.distributed.run --nproc-per-node N`; under the launcher it runs as one rank.  `cpu_baseline` (N = 1 only) times the CPU oracle -- torch fp32
 restatement of the network + the C / python restatement of `process()` -- on a bounded sample of the same
 tiles on this box's host cores.  The reference itself is python under /root/reference and cannot travel to
 the GPU box, so kind = "port"; profiles/ holds the reference's own timing taken in the build container.
@@ -123,6 +130,21 @@ def _control_flow_selftest(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run this very command line as N ranks of one node (one process per GPU) under
+    torch.distributed.run, on a free local port; returns its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
 def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
     """The `roofline` object from the plan's timed launches (`timed`: the CONV / CHAIN / WINO_IN / WINO_OUT ops in launch order) and their
     per-launch times in ms (`per_ms`, same order).  Pure arithmetic (tests/test_bench_roofline.py feeds it made-up times).
@@ -161,8 +183,13 @@ def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
     ach_x3 = x3_bf16 / (x3_ms * 1e-3) / 1e12
     ideal_ms = 1e3 * (x3_bf16 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
     return {
-        "bound": "mfma", "kernel": "hvn_conv_igemm_x3 (fp32 convolution, products on the bf16 matrix pipe from exact bf16x3 splits of the fp32 operands)",
+        "bound": "mfma", "kernel": "hvn_conv_igemm_x3 / hvn_conv_igemm_x3g (fp32 convolution, products on the bf16 matrix pipe from exact bf16x3 splits of "
+                                   "the fp32 operands; the second stages both operands by LDS-DMA -- same bits, picked per launch shape by time)",
         "achieved": ach_x3, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach_x3 / PEAK_BF16_MATRIX_TFLOPS, "traffic": None,
+        "achieved_counts": "bf16 MFMA FLOPs ISSUED by the bf16x3 launches (%d per fp32 multiply-add) -- not comparable with rounds 1-3's `achieved` "
+                           "(fp32 MFMA FLOPs): that quantity is `fp32_equivalent_tflops` here and `whole_step.fp32_equivalent_tflops` for all launches"
+                           % (int(x3_bf16 / x3_eq + 0.5) if x3_eq else 0),
+        "launches_on_lds_dma_form": sum(1 for o in timed if o.kind == 2 and o.extra.get("x3") and o.extra.get("tile_form") in (896, 640)),
         "launches": n_x3, "ms_per_step": x3_ms, "avg_launch_ms": x3_ms / n_x3, "flops_per_launch": x3_bf16 / n_x3,
         "bf16_mfma_gflop_per_step": x3_bf16 / 1e9, "fp32_products_gflop_per_step": x3_eq / 1e9,
         "fp32_equivalent_tflops": x3_eq / (x3_ms * 1e-3) / 1e12,
@@ -216,7 +243,12 @@ def main():
                          "a stand-in for the GPU pipeline that moves correctly shaped dummy results.  Measures nothing; the JSON line says so.")
     ap.add_argument("--dtype", default="fp32", choices=("fp32", "bf16"),
                     help="fp32 = the headline configuration (BASELINE cfg 2); bf16 = cfg 3 (use with --mode fast --nr-types 6 --batch 64)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip variants.train_step (BASELINE cfg 5: both phases of the training schedule)")
+    ap.add_argument("--no-wsi-leg", action="store_true", help="skip variants.wsi_8k (BASELINE cfg 4 scaled to one GPU)")
+    ap.add_argument("--wsi-size", type=int, default=8192)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(_self_launch(args.gpus))       # no launcher around us: become N ranks
 
     import numpy as np
     import torch
@@ -267,15 +299,29 @@ def main():
         if not fitted:
             return synth_state_dict(mode, nr_types, seed=seed), {"kind": "random-init (seeded)"}
         t_fit = time.perf_counter()
-        tnet, curve = synth_fit.fit(mode, nr_types, steps=args.fit_steps, batch=8, lr=1e-3, seed=seed, init=args.fit_init,
-                                    density=synth_fit.consep_density(sz))
-        sd_ = {k: v.detach().cpu().clone() for k, v in tnet.state_dict().items()}
-        tnet._train_engine = None
-        del tnet
-        torch.cuda.empty_cache()
-        return sd_, {"kind": "fitted at bench start: %d steps of run_desc.train_step (batch 8, Adam 1e-3, init %s) on painted tiles"
-                             % (args.fit_steps, args.fit_init),
-                     "loss_first10": float(np.mean(curve[:10])), "loss_last10": float(np.mean(curve[-10:])), "seconds": time.perf_counter() - t_fit}
+        info = None
+        if rank == 0:            # ONE fit per job: the other ranks receive rank 0's weights (N x 25 s of identical fitting otherwise)
+            tnet, curve = synth_fit.fit(mode, nr_types, steps=args.fit_steps, batch=8, lr=1e-3, seed=seed, init=args.fit_init,
+                                        density=synth_fit.consep_density(sz))
+            sd_ = {k: v.detach().cpu().clone() for k, v in tnet.state_dict().items()}
+            tnet._train_engine = None
+            del tnet
+            torch.cuda.empty_cache()
+            info = {"kind": "fitted at bench start%s: %d steps of run_desc.train_step (batch 8, Adam 1e-3, init %s) on painted tiles"
+                            % (" on rank 0 and broadcast" if world > 1 else "", args.fit_steps, args.fit_init),
+                    "loss_first10": float(np.mean(curve[:10])), "loss_last10": float(np.mean(curve[-10:]))}
+        else:
+            sd_ = {k: v.detach().cpu().clone() for k, v in net_desc.create_model(mode=mode, nr_types=nr_types, input_ch=3).state_dict().items()}
+        if world > 1:
+            for k in sd_:           # same keys in the same order on every rank (the module's own state_dict)
+                t = sd_[k].to(cdev).contiguous()
+                dist.broadcast(t, 0)
+                sd_[k] = t.cpu()
+            box = [info]
+            dist.broadcast_object_list(box, 0)
+            info = box[0]
+        info["seconds"] = time.perf_counter() - t_fit
+        return sd_, info
 
     def make_tiles(n, sz, seed):
         if not fitted:
@@ -367,6 +413,9 @@ def main():
         pipe.gather_ms()                 # drop the warm-up's gather timings
     dt, out = timed(step, args.steps)
     n_inst = int(out[2].sum().item()) if (rank == 0 and out is not None) else 0
+    # which replay the marker-controlled watershed of the LAST timed step's network output took on this rank (every timed step sees the
+    # same tiles): whole-tile replays are the exact one-lane fallback a mixed-label marker tie forces (csrc/hvn_postproc.hip)
+    flood = pipe.flood_stats() if extra is None else None
     if rank == 0 and world > 1:
         assert out[0].shape[0] == world * args.batch, "rank 0 must hold every rank's instance maps after the gather"
     per_rank = None
@@ -418,6 +467,11 @@ def main():
     }
     if per_rank is not None:
         result["config"]["per_rank"] = per_rank
+    if flood is not None:
+        result["flood_whole_tile_replays"] = flood["whole_tile_replays"]
+        result["config"]["flood"] = dict(flood, what="marker-controlled watershed of the network's own output, last timed step, rank 0: mask components "
+                                                     "by the replay that flooded them; whole_tile_replays = exact whole-tile fallbacks (a marker tie between labels "
+                                                     "that the component replay could not prove harmless)")
 
     # ---- per-stage split of one batch (rank 0): each stage ALONE on the launch stream, warmed, median of 5 passes ------
     # (a stage alone is not a share of the pipelined step: there the post-processing of batch i runs under the network of
@@ -439,7 +493,7 @@ def main():
             return sorted(ts)[len(ts) // 2], out_
 
         torch.cuda.synchronize(dev)
-        net_ms, pred = med_ms(lambda: run_desc.infer_step_device(tiles[0], net), inner=4)
+        net_ms, pred = med_ms(lambda: run_desc.infer_step_device(tiles[0], net), reps=7, warm=2, inner=max(4, args.steps // 2))
         pred = pred.clone()
         ppn_ms, (inst_n, _r, counts_n) = med_ms(lambda: post_proc.process_batch_device(pred, nr_types=nt, return_centroids=True))
         pp_ms, (inst, rec, counts) = med_ms(lambda: post_proc.process_batch_device(structured, nr_types=nt, return_centroids=True))
@@ -451,7 +505,8 @@ def main():
         result["config"]["stage_ms"] = {"network": net_ms, "postproc_network_output": ppn_ms, "instances_in_network_output": int(counts_n.sum().item()),
                                         "postproc_structured": pp_ms, "d2h_results": d2h_ms,
                                         "host_contours_and_dict": dict_ms, "instances_in_dicts": sum(len(d) for d in dicts),
-                                        "how": "each stage alone on the launch stream, median of 5 warmed measurements (network: 4 back-to-back passes per measurement)"}
+                                        "how": "each stage alone on the launch stream, median of 5 warmed measurements (network: median of 7 measurements of %d back-to-back "
+                                               "passes on the timed step's launch schedule)" % max(4, args.steps // 2)}
 
     # ---- variants (untimed by the driver; same K steps each) ---------------------------------------------------------
     net_rf = None              # the single-stream engine of the same checkpoint (roofline leg, single_stream_schedule variant)
@@ -531,6 +586,23 @@ def main():
                 variants["plus_structured_maps"] = {"value": tiles_per_step_global * args.steps / dt3, "unit": "tiles/s", "ms_per_step": 1e3 * dt3 / args.steps,
                                                     "what": "the timed step + instance separation and table of a resident batch of structured synthetic maps "
                                                             "(2..8 nuclei per 80x80), i.e. round 3's step on this round's checkpoint"}
+        if world == 1 and fitted:
+            # rounds 1-3's step, for comparisons across rounds: seeded random-init checkpoint on noise tiles (0 instances in the network
+            # output) + instance separation of the resident batch of structured maps
+            net_r3 = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
+            net_r3.load_state_dict(synth_state_dict(args.mode, nt, seed=0), strict=True)
+            net_r3.max_batch, net_r3.compute_dtype, net_r3.launch_schedule = args.batch, args.dtype, None
+            net_r3 = net_r3.to(dev).eval()
+            pipe_r3 = TilePipeline(net_r3, nr_types=nt, return_centroids=True)
+            noise = [torch.from_numpy(synth_tiles(args.batch, size, seed=1)).to(dev)]
+            for _ in range(args.warmup):
+                step(noise, structured, pipe_r3)
+            dt4, _ = timed(lambda: step(noise, structured, pipe_r3), args.steps)
+            variants["round3_step_random_checkpoint"] = {"value": tiles_per_step_global * args.steps / dt4, "unit": "tiles/s", "ms_per_step": 1e3 * dt4 / args.steps,
+                                                         "what": "the headline step of rounds 1-3 on this round's kernels: random-init checkpoint, noise tiles, "
+                                                                 "instance separation of a resident batch of structured synthetic maps (r03: 535 tiles/s)"}
+            del pipe_r3, net_r3
+            torch.cuda.empty_cache()
         reps, t_end = 0, time.perf_counter() + args.sustain_seconds
         fence()
         t0 = time.perf_counter()
@@ -555,6 +627,8 @@ def main():
 
         eng = net_.engine(batch)
         assert eng.n_split == 1 and eng.n_lane_streams == 0, "the roofline leg times launches on ONE stream: launch_schedule (1, 0)"
+        for o, eo in zip(eng.plan.ops, eng.ops):
+            o.extra["tile_form"] = int(eo.tile_n)                     # which workgroup shape / kernel form the engine picked (roofline_account)
         timed = [o for o in eng.plan.ops if o.kind in (2, 8, 6, 7)]     # CONV, CHAIN (two chained 1x1 convs), WINO_IN, WINO_OUT: the launches hvn_profile times
         torch.cuda.synchronize(dev)
         buf = (ctypes.c_double * 4096)()
@@ -664,6 +738,39 @@ def main():
             "instances_last_step": int(out3_[2].sum().item()), "roofline": roof3}
         del pipe3, net3
         torch.cuda.empty_cache()
+
+    # ---- BASELINE cfg 5 / cfg 4 as driver-visible legs (outside every timed region of the headline) ---------------------------------
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    if not args.no_variants and not args.no_train_leg and not shared_gpu:
+        # training step, both phases of the two-stage schedule (/root/reference/models/hovernet/opt.py:23-142, run_desc.py:12-109):
+        # every rank runs it (N > 1: the data-parallel step with the gradient slab's all-reduce), rank 0 reports
+        import train_bench
+
+        torch.cuda.empty_cache()
+        legs = {}
+        for ph in (0, 1):
+            r_ = train_bench.measure(ph, steps=5, warmup=2, mode=args.mode, nt=nt, device=dev)
+            if world > 1:
+                allr = [None] * world
+                dist.all_gather_object(allr, {k: r_[k] for k in ("ms_per_step", "forward_ms", "loss_backward_ms", "optimizer_ms", "allreduce_slab_alone_ms")})
+                r_["per_rank"] = allr
+                r_["ms_per_step"] = max(a_["ms_per_step"] for a_ in allr)
+                r_["tiles_per_s"] = world * r_["batch"] * 1000.0 / r_["ms_per_step"]
+            legs["phase%d" % ph] = r_
+        if rank == 0:
+            result.setdefault("variants", {})["train_step"] = dict(
+                legs, what="BASELINE cfg 5 on %d GPU(s): one training step (forward in train mode, the reference's loss table, backward, FusedAdam) of "
+                           "phase 0 (frozen encoder, batch 16 per GPU) and phase 1 (all layers, batch 4 per GPU), CoNSeP '%s' mode, %s types, "
+                           "synthetic batch; 5 steps after 2 warm-up steps each; N > 1: SUM all-reduce of the loss partial sums and of the "
+                           "gradient slab in two buckets inside the step (ms_per_step = slowest rank)" % (world, args.mode, nt))
+    if rank == 0 and world == 1 and not args.no_variants and not args.no_wsi_leg:
+        import wsi_bench
+
+        w_ = wsi_bench.measure(args.wsi_size, args.mode, nt, args.batch, "fp32", device=dev)
+        result.setdefault("variants", {})["wsi_8k"] = dict(
+            w_, what="BASELINE cfg 4 scaled to one GPU: a synthetic %d^2 slide -- stage 1 = every patch through the network into the HBM-resident "
+                     "prediction map (infer/wsi.py:449-709), stage 2 = tile-wise instance separation on the GPU + the three-phase merge of a "
+                     "structured prediction map of the same size (40 000^2 on one GPU: profiles/r0*_wsi_40k.json)" % args.wsi_size)
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same tiles ------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

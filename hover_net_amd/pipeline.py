@@ -117,6 +117,11 @@ class TilePipeline:
                 b.copy_(t, non_blocking=True)
         return bufs
 
+    def flood_stats(self):
+        """Replay statistics of the watershed of the last network output this pipeline post-processed (waits for the side stream)."""
+        self.side.synchronize()
+        return self._pp.flood_stats(self.side)
+
     def gather_ms(self):
         """Mean duration (ms) of the timed `gather` calls since the last call of this method (side stream synchronised first)."""
         self.side.synchronize()

@@ -46,6 +46,7 @@ class PostProc:
         if c not in (3, 4):
             raise ValueError("prediction map must have 3 ([p,h,v]) or 4 ([type,p,h,v]) channels, got %d" % c)
         ws = self._workspace(n, h, w)
+        self._last_nhw = (n, h, w)
         inst = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if not taps:
@@ -58,6 +59,19 @@ class PostProc:
         L.check(L.lib().hvn_postproc_taps(pred.data_ptr(), n, h, w, c, c - 3, inst.data_ptr(), blb.data_ptr(), dist.data_ptr(),
                                           marker.data_ptr(), ws.data_ptr(), ws.numel(), stream), "hvn_postproc_taps")
         return inst, blb, dist, marker
+
+    def flood_stats(self, stream=None):
+        """Which replay the marker-controlled watershed of the LAST `separate` call took, summed over its maps (hvn_postproc_stats):
+        dict of component counts; `whole_tile_replays` are the exact one-lane whole-tile fallbacks."""
+        if self._ws is None or getattr(self, "_last_nhw", None) is None:
+            return None
+        n, h, w = self._last_nhw
+        out = (ctypes.c_longlong * 10)()
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        L.check(L.lib().hvn_postproc_stats(self._ws.data_ptr(), self._ws.numel(), n, h, w, out, ctypes.c_void_p(st.cuda_stream)), "hvn_postproc_stats")
+        keys = ("components", "small_window", "bitmap_window", "hbm_window", "to_heap_by_marker_tie", "to_heap_by_full_frontier",
+                "component_heap_replays", "whole_tile_replays", "maps_flagged", "largest_component_box")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def table(self, inst, pred, nr_types):
         """-> (records uint8 view [N,max_inst,sizeof(rec)], counts int32 [N]) on the device."""

@@ -24,7 +24,22 @@ def test_bench_two_rank_control_flow():
     assert out["config"]["world_size"] == 2 and out["config"]["global_batch"] == 64 and out["config"]["sustained_steps"] >= 4
 
 
+def test_bench_launches_itself_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` (the shape of the driver's N = 1 command with another N): no WORLD_SIZE in the environment, so the script
+    starts itself under torch.distributed.run on a free port and the two ranks run the same control flow; ONE json line comes back."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--control-flow-selftest"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["world_size"] == 2
+
+
 def test_bench_refuses_a_world_size_mismatch():
+    """Under a launcher whose world size is not --gpus the script stops (it does not silently run another job)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33000 + os.getpid() % 2000))
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--control-flow-selftest"], capture_output=True, text=True,
-                       timeout=300, cwd=REPO)
+                       timeout=300, cwd=REPO, env=env)
     assert r.returncode != 0 and "nproc-per-node 2" in r.stderr

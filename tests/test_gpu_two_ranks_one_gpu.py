@@ -79,7 +79,8 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
         assert np.array_equal(a[0], b[0]) and a[1] == b[1]
 
 
-def test_bench_step_on_two_ranks_sharing_the_gpu():
+@pytest.mark.parametrize("launch", ["torchrun", "self"])
+def test_bench_step_on_two_ranks_sharing_the_gpu(launch):
     """The driver's exact N > 1 command path -- `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` -- with the REAL
     kernels and bench.py's OWN step (network, instance separation, the per-batch gather to rank 0 on the side stream inside the timed
     step, D2H), on this box's one GPU: HVN_BENCH_SHARED_GPU=1 puts both ranks on cuda:0 and the collectives on gloo (device tensors
@@ -94,9 +95,12 @@ def test_bench_step_on_two_ranks_sharing_the_gpu():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     port = 32000 + os.getpid() % 2000
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-variants",
-           "--no-roofline", "--fit-steps", "12"]                   # the default (fitted) checkpoint path, as the driver runs it: every rank fits ALONE
+    # launch = "torchrun": under the launcher, as the driver starts N > 1; "self": `python bench.py --gpus 2` alone -- the script becomes
+    # its own launcher (the shape of the driver's N = 1 command).  The default (fitted) checkpoint path: rank 0 fits, the others receive it.
+    args = [os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-variants",
+            "--no-roofline", "--fit-steps", "12"]
+    cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                               "--master-port", str(port)] if launch == "torchrun" else []) + args
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -105,4 +109,4 @@ def test_bench_step_on_two_ranks_sharing_the_gpu():
     pr = d["config"]["per_rank"]
     assert len(pr["step_ms"]) == 2 and len(pr["gather_ms"]) == 2 and all(t > 0 for t in pr["step_ms"]) and all(t >= 0 for t in pr["gather_ms"])
     assert d["config"]["instances_last_step"] > 0          # rank 0 holds the gathered results of both ranks
-    assert d["config"]["checkpoint"]["kind"].startswith("fitted")
+    assert d["config"]["checkpoint"]["kind"].startswith("fitted") and "rank 0 and broadcast" in d["config"]["checkpoint"]["kind"]

@@ -53,6 +53,80 @@ def conv_flops(eng, n):
     return af, ab, ef, eb
 
 
+def measure(phase, steps=10, warmup=3, mode="original", nt=5, device="cuda", seed_sd=None):
+    """One phase of the two-stage schedule (opt.py:23-142: phase 0 = frozen encoder, batch 16; phase 1 = all layers, batch 4) on `device`:
+    a dict with ms per step split into forward / loss+backward / optimizer and the step's MFMA work.  With torch.distributed
+    initialised (world > 1) the step is the data-parallel one of run_desc.train_step -- SUM all-reduce of the loss partial sums and of
+    the gradient slab in two buckets, the decoder's under the encoder's backward pass -- and the dict also holds the time of the
+    slab's all-reduce ALONE (no overlap) on this rank."""
+    import torch.distributed as dist
+
+    freeze, bs = ((True, 16), (False, 4))[phase]
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
+    net.load_state_dict(synth_state_dict(mode, nt, seed=0) if seed_sd is None else seed_sd, strict=True)
+    net = net.to(device)
+    eng = TrainEngine(net, bs)
+    opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    rank = dist.get_rank() if world > 1 else 0
+    eng.load_batch(synth_train_batch(bs, mode, nt, seed=1 + rank))
+    ar = (lambda t, async_op=False: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)) if world > 1 else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    tf = tb = to = 0.0
+    for i in range(warmup + steps):
+        ev[0].record()
+        eng.forward()
+        ev[1].record()
+        eng.loss_and_backward(world=world, all_reduce=ar)
+        ev[2].record()
+        opt.step()
+        ev[3].record()
+        torch.cuda.synchronize()
+        if i >= warmup:
+            tf += ev[0].elapsed_time(ev[1])
+            tb += ev[1].elapsed_time(ev[2])
+            to += ev[2].elapsed_time(ev[3])
+    k = steps
+    # summed HIP-event time of the step's CONV launches (forward + data-gradient implicit GEMMs; the weight-gradient kernel, BatchNorm,
+    # transforms, losses and Adam are the rest of the step)
+    import ctypes
+
+    from hover_net_amd import lib as L
+    L.lib().hvn_profile_enable(1)
+    eng.forward()
+    eng.loss_and_backward(world=world, all_reduce=ar)
+    buf = (ctypes.c_double * 8192)()
+    n_conv = L.lib().hvn_profile_conv_ms_list(buf, 8192)
+    L.lib().hvn_profile_enable(0)
+    conv_ms = float(sum(buf[:n_conv]))
+    af, ab, ef, eb = conv_flops(eng, bs)
+    ms = (tf + tb + to) / k
+    slab_mb = eng.gslab.numel() * 4 / 1e6
+    out = {"phase": phase, "freeze": freeze, "batch": bs, "ms_per_step": ms, "forward_ms": tf / k, "loss_backward_ms": tb / k,
+           "optimizer_ms": to / k, "steps_per_s": 1000.0 / ms, "tiles_per_s": world * bs * 1000.0 / ms,
+           "executed_gflop_forward": ef / 1e9, "executed_gflop_backward": eb / 1e9,
+           "algorithmic_gflop_forward": af / 1e9, "algorithmic_gflop_backward": ab / 1e9,
+           "algorithmic_speedup": (af + ab) / (ef + eb),
+           "timed_conv_launches": int(n_conv), "timed_conv_launch_ms": conv_ms, "timed_conv_launch_share_of_step": conv_ms / ms,
+           "plan_ops_per_step": len(eng.fwd_ops) + len(eng.bwd_ops),
+           "gradient_slab_mb": slab_mb, "world_size": world,
+           "loss": eng.loss_terms()["overall_loss"], "arena_gb": eng.arena.numel() * 4 / 1e9, "grad_gb": eng.gmem.numel() * 4 / 1e9}
+    if world > 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0.record()
+        for _ in range(3):
+            dist.all_reduce(eng.gslab, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        out["allreduce_slab_alone_ms"] = e0.elapsed_time(e1) / 3
+    eng.gmem.zero_()
+    del eng, net, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)

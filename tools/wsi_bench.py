@@ -21,33 +21,26 @@ from hover_net_amd import infer_wsi, net_desc  # noqa: E402
 from hover_net_amd.synth import synth_pred_maps, synth_state_dict  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--mode", default="original")
-    ap.add_argument("--nr-types", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--dtype", default="fp32")
-    ap.add_argument("--skip-stage1", action="store_true")
-    args = ap.parse_args()
-    nt = args.nr_types if args.nr_types > 0 else None
-    S = args.size
-    sd = synth_state_dict(args.mode, nt, seed=0)
+def measure(size=8192, mode="original", nt=5, batch=32, dtype="fp32", skip_stage1=False, device="cuda"):
+    """-> dict (see the module docstring): stage 1 = network over every patch of a synthetic size x size slide into the HBM-resident
+    prediction map, stage 2 = tile-wise instance separation + the three-phase merge of a structured prediction map of the same size."""
+    S = size
+    sd = synth_state_dict(mode, nt, seed=0)
     sd["decoder.np.u0.conv.bias"] = torch.tensor([8.0, -8.0])
-    net = net_desc.create_model(mode=args.mode, nr_types=nt, input_ch=3)
+    net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
     net.load_state_dict(sd, strict=True)
-    net.max_batch = args.batch
-    net.compute_dtype = args.dtype
-    net = net.to("cuda").eval()
+    net.max_batch = batch
+    net.compute_dtype = dtype
+    net = net.to(device).eval()
     rng = np.random.default_rng(0)
     tile = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
     slide = infer_wsi.TiledSlide(tile, (S, S))
-    wsi = infer_wsi.WsiInference(net, nr_types=nt, batch_size=args.batch)
+    wsi = infer_wsi.WsiInference(net, nr_types=nt, batch_size=batch)
     mask = np.ones((S // 32, S // 32), np.uint8)
     wsi.raw_prediction(infer_wsi.TiledSlide(tile, (1024, 1024)), np.ones((32, 32), np.uint8))   # warm-up (plan, arena)
     torch.cuda.synchronize()
     t1 = float("nan")
-    if not args.skip_stage1:
+    if not skip_stage1:
         torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
         pm = wsi.raw_prediction(slide, mask)
@@ -59,9 +52,9 @@ def main():
     peak1 = torch.cuda.max_memory_allocated() / 2 ** 30
     # stage 2 on a structured map: 512^2 painted blocks tiled over the slide (nuclei at CoNSeP density: 3.8 per 80^2)
     # (assembled on the device: the 40 000^2 map is 25.6 GB)
-    blk = torch.from_numpy(synth_pred_maps(4, 512, 512, nt, seed=3, k_lo=2, k_hi=6)[0]).to("cuda")
+    blk = torch.from_numpy(synth_pred_maps(4, 512, 512, nt, seed=3, k_lo=2, k_hi=6)[0]).to(device)
     reps = S // 512 + 1
-    full = torch.empty((S, S, blk.shape[-1]), dtype=torch.float32, device="cuda")
+    full = torch.empty((S, S, blk.shape[-1]), dtype=torch.float32, device=device)
     for r in range(reps):
         for c in range(reps):
             y0, x0 = r * 512, c * 512
@@ -76,10 +69,25 @@ def main():
     torch.cuda.synchronize()
     t2 = time.perf_counter() - t0
     grid, boundary, cross = infer_wsi.get_tile_info(np.array([S, S]), wsi.tile_shape, wsi.ambiguous_size)
-    print(json.dumps({"slide": [S, S], "mode": args.mode, "dtype": args.dtype, "patches": n_patch, "stage1_s": t1, "patches_per_s": n_patch / t1,
-                      "stage2_s": t2, "tiles": [int(grid.shape[0]), int(boundary.shape[0]), int(cross.shape[0])], "instances": len(info),
-                      "mpix_per_s_stage2": S * S / 1e6 / t2, "stage2_breakdown_s": wsi.timing, "peak_hbm_gib_stage1": peak1,
-                      "peak_hbm_gib_stage2": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    out = {"slide": [S, S], "mode": mode, "dtype": dtype, "patches": n_patch, "stage1_s": t1, "patches_per_s": n_patch / t1,
+           "stage2_s": t2, "tiles": [int(grid.shape[0]), int(boundary.shape[0]), int(cross.shape[0])], "instances": len(info),
+           "mpix_per_s_stage2": S * S / 1e6 / t2, "stage2_breakdown_s": wsi.timing, "peak_hbm_gib_stage1": peak1,
+           "peak_hbm_gib_stage2": torch.cuda.max_memory_allocated() / 2 ** 30}
+    del full, inst_map, info, wsi, net
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--mode", default="original")
+    ap.add_argument("--nr-types", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--skip-stage1", action="store_true")
+    args = ap.parse_args()
+    print(json.dumps(measure(args.size, args.mode, args.nr_types if args.nr_types > 0 else None, args.batch, args.dtype, args.skip_stage1)))
 
 
 if __name__ == "__main__":
