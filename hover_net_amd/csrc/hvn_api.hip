@@ -210,7 +210,8 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.N = batch; a.Ho = op->y.h; a.Wo = op->y.w;
         a.M = (long)batch * a.Ho * a.Wo;
         a.bm = op->tile_n == 64 ? 64 : 128;      // CHAIN: tile_n = pixels per workgroup (0 / 128: 128)
-        if (op->act_dtype != 0) return fail(HVN_E_ARG, "chain: fp32 only%s", "");
+        const bool cx3 = op->act_dtype == 2 || op->act_dtype == 3;       // products on the bf16 pipe from bf16x3 splits: w / w2 = plane packings
+        if (op->act_dtype != 0 && !cx3) return fail(HVN_E_ARG, "chain: fp32 activations only (act_dtype 0, or 2 | 3 for bf16x3 products)%s", "");
         if (!a.x || !a.w1 || !a.y || !a.w2 || !a.y2) return fail(HVN_E_ARG, "chain: null pointer%s", "");
         if (op->kh != 1 || op->kw != 1 || op->stride != 1 || op->pad_t || op->pad_l || op->relu || op->bias)
             return fail(HVN_E_ARG, "chain: the first conv is a plain 1x1 (no bias / relu of its own)%s", "");
@@ -228,7 +229,7 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
             (a.post_s && (!aligned16(a.post_s) || !aligned16(a.post_b))) || (a.bias2 && !aligned16(a.bias2)))
             return fail(HVN_E_ARG, "chain: per-channel vectors must be 16-byte aligned and come in pairs%s", "");
         if (g_prof) prof_mark(s);
-        int rc = hvn_launch_conv_chain(a, s);
+        int rc = cx3 ? hvn_launch_conv_chain_x3(a, op->act_dtype == 3 ? 6 : 9, s) : hvn_launch_conv_chain(a, s);
         if (g_prof) prof_mark(s);
         if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "chain: launch failed (cout2=%s%ld)", "", a.N2);
         return 0;

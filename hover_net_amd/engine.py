@@ -194,15 +194,21 @@ class Engine:
                 off16[i] = tot16
                 w16.append((tot16, wb))
                 tot16 += (wb.size + 127) // 128 * 128
-            elif self.dtype == "fp32" and op.kind == PL.OP_CONV and op.extra.get("x3"):
+            elif self.dtype == "fp32" and op.kind in (PL.OP_CONV, PL.OP_CHAIN) and op.extra.get("x3"):
                 wb = pack_conv_x3(op.w).ravel()          # fp32 weights as three bf16 planes (csrc/hvn_conv_x3.hip)
                 off16[i] = tot16
                 w16.append((tot16, wb))
                 tot16 += (wb.size + 127) // 128 * 128
+                if op.kind == PL.OP_CHAIN:               # + the second conv's (csrc/hvn_conv_chain_x3.hip)
+                    wb2 = pack_conv_x3(op.extra["w2"]).ravel()
+                    off16[(i, "w2")] = tot16
+                    w16.append((tot16, wb2))
+                    tot16 += (wb2.size + 127) // 128 * 128
             else:
                 put((i, "w"), op.w)
             put((i, "bias"), op.bias)
-            put((i, "w2"), op.extra.get("w2"))
+            if not (op.kind == PL.OP_CHAIN and op.extra.get("x3") and self.dtype == "fp32"):
+                put((i, "w2"), op.extra.get("w2"))
             put((i, "bias2"), op.extra.get("bias2"))
             if op.pre is not None:
                 put((i, "pre_s"), op.pre[0])
@@ -259,6 +265,10 @@ class Engine:
                     raise ValueError("OP_CHAIN is fp32 only: build the bf16 plan with chain=False")
                 o.cout2 = int(op.extra["cout2"])
                 o.w2, o.bias2 = self._pptr(i, "w2"), self._pptr(i, "bias2")
+                if op.extra.get("x3"):
+                    o.w2 = self.params16.data_ptr() + 2 * self._poff16[(i, "w2")]
+                    o.act_dtype = 2 if int(op.extra["x3"]) == 9 else 3
+                    o.tile_n = 128
             for fld, v in (("x", op.x), ("res", op.res), ("y", op.y), ("x2", op.extra.get("x2")), ("y2", op.extra.get("y2"))):
                 if v is None:
                     continue
@@ -317,6 +327,8 @@ class Engine:
             return best
 
         for i, op in enumerate(self.plan.ops):
+            if op.kind == PL.OP_CHAIN and op.extra.get("x3"):
+                continue                                   # the bf16x3 chain has one workgroup shape (128 pixels)
             if op.kind == PL.OP_CHAIN:                     # chained 1x1 convs: 128 or 64 pixels per workgroup (same bits)
                 if os.environ.get("HVN_CHAIN_BM"):         # A/B runs: force one
                     self.ops[i].tile_n = int(os.environ["HVN_CHAIN_BM"])

@@ -276,7 +276,7 @@ class Plan:
                bias=None if b is None else np.asarray(b, np.float32), relu=relu, cout=cout, extra={"tiles": (ty, tx), "m": m, "r": r})
         return self.add(o)
 
-    def mark_x3(self, terms, d1=True):
+    def mark_x3(self, terms, d1=True, chain="d0"):
         """Which CONV launches run on csrc/hvn_conv_x3.hip (fp32 in / out, products on the bf16 matrix pipe from exact bf16x3 splits,
         `terms` = 9 | 6 partial products per product): every dense (ungrouped) conv with a 128- or 64-wide column tile EXCEPT the 1x1
         convs of d0 (+ d1's first conv1, chained to d0's last conv3) -- HBM-bound, they stay chained pairs on the fp32 pipe
@@ -289,11 +289,20 @@ class Plan:
         for op in self.ops:
             if op.kind != OP_CONV or int(op.extra.get("groups", 1)) != 1 or op.tile_n not in (128, 64):
                 continue
+            seam = False
             if re.match(r"^d0\.units\.\d+\.conv[13]$", op.name) or op.name == "d1.units.0.conv1":
-                continue
-            if not d1 and re.match(r"^d1\.units\.\d+\.conv[13]$", op.name):
-                continue                # d1=True (default; HVN_X3_D1=0 chains them on the fp32 pipe instead): measured 655 -> 674 tiles/s
+                # round 5: d0's seams (conv3 -> next conv1, + d0's last conv3 -> d1's first conv1) run CHAINED on the bf16 pipe
+                # (csrc/hvn_conv_chain_x3.hip; chain = "d0" | "d0d1"); chain = "" keeps them chained on the fp32 pipe (rounds 3-4)
+                if not chain or op.name == "d0.units.0.conv1":
+                    continue
+                seam = True
+            if re.match(r"^d1\.units\.\d+\.conv[13]$", op.name) and op.name != "d1.units.0.conv1":
+                if not d1:
+                    continue            # d1=True (default; HVN_X3_D1=0 chains them on the fp32 pipe instead): measured 655 -> 674 tiles/s
+                seam = chain == "d0d1"
             op.extra["x3"] = terms
+            if seam:
+                op.extra["x3_chain"] = True     # `fuse_chains` may merge two such ops into one OP_CHAIN on the bf16 pipe
 
     def reindex(self):
         """Recompute every buffer's live interval from the op list (after a pass that merged / removed ops)."""
@@ -315,9 +324,9 @@ class Plan:
 
             def plain1x1(o):
                 return (o is not None and o.kind == OP_CONV and o.kh == 1 and o.kw == 1 and o.stride == 1 and o.pad_t == 0 and
-                        not o.extra.get("nbatch") and o.extra.get("groups", 1) == 1 and not o.extra.get("x3"))
+                        not o.extra.get("nbatch") and o.extra.get("groups", 1) == 1 and (not o.extra.get("x3") or o.extra.get("x3_chain")))
 
-            ok = (plain1x1(a) and plain1x1(b) and (a.res is not None or a.extra.get("x2") is not None) and a.pre is None and
+            ok = (plain1x1(a) and plain1x1(b) and int(a.extra.get("x3", 0)) == int(b.extra.get("x3", 0)) and (a.res is not None or a.extra.get("x2") is not None) and a.pre is None and
                   a.bias is None and not a.relu and a.cout % 64 == 0 and a.x.c + (a.extra["x2"].c if a.extra.get("x2") is not None else 0) >= 64 and
                   b.res is None and b.extra.get("x2") is None and b.post is None and b.relu == 1 and
                   b.cout in (64, 128) and b.cout <= max_n2 and
@@ -331,6 +340,8 @@ class Plan:
             op = Op(OP_CHAIN, a.name + "+" + b.name.split(".", 1)[1] if b.name.split(".")[0] == a.name.split(".")[0] else a.name + "+" + b.name,
                     x=a.x, y=a.y, res=a.res, w=a.w, post=a.post, pre=b.pre, cout=a.cout, tile_n=0)
             op.extra.update(cin_real=a.extra["cin_real"], groups=1, cout2=b.cout, w2=b.w, bias2=b.bias, y2=b.y, parts=(a, b))
+            if a.extra.get("x3"):
+                op.extra["x3"] = int(a.extra["x3"])      # both GEMMs on the bf16 pipe (csrc/hvn_conv_chain_x3.hip)
             if a.extra.get("x2") is not None:
                 op.extra.update(x2=a.extra["x2"], stride2=a.extra["stride2"], reads=a.extra.get("reads", []))
             out.append(op)
@@ -518,7 +529,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     if x3 is None:
         x3 = int(os.environ.get("HVN_X3", "6"))       # default since round 4: six partial products (measured: the fp32-MFMA path's own error band)
     if x3:
-        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "1") != "0")
+        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "1") != "0", chain=os.environ.get("HVN_X3_CHAIN", "d0") if chain else "")
     if chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
     if os.environ.get("HVN_FUSE_UPADD", "0") != "0":

@@ -107,6 +107,55 @@ def test_chain_matches_reference_and_unfused_launches(case, bm):
     assert torch.equal(eng2.buffer(t1_q, n), eng.buffer(t1, n))
 
 
+@pytest.mark.parametrize("terms", [6, 9])
+@pytest.mark.parametrize("case", CASES)
+def test_chain_on_the_bf16_pipe_matches_reference_and_unfused_bf16x3_launches(case, terms):
+    """csrc/hvn_conv_chain_x3.hip: the same op with both GEMMs' products on the bf16 matrix pipe (bf16x3 splits).  Against the torch
+    interpreter at the bf16x3 kernel's tolerance, and BIT-EQUAL to the two bf16x3 CONV launches it replaces."""
+    n, h, w, k1, c, n2, res, x2, post, pre = case
+
+    def build(fuse):
+        P, views = _two_convs(n, h, w, k1, c, n2, res=res, x2=x2, post=post, pre=pre, seed=7, inplace=not post)
+        for o in P.ops:
+            o.extra["x3"] = terms
+            o.extra["x3_chain"] = True
+        if fuse:
+            P.fuse_chains()
+        return P, views
+
+    P, (t2, acc, out, t1) = build(True)
+    assert [o.kind for o in P.ops] == [PL.OP_CHAIN] and P.ops[0].extra["x3"] == terms
+    eng, start = _run(P, n, seed=11)
+    assert eng.ops[0].act_dtype == (2 if terms == 9 else 3)
+    got = eng.arena.cpu()
+    A = plan_interp.Arena(P, n)
+    A.flat.copy_(start)
+    op = P.ops[0]
+    r = A.view(op.res).clone() if op.res is not None else None
+    xx2 = A.view(op.extra["x2"]).clone() if op.extra.get("x2") is not None else None
+    y, y2 = plan_interp.chain_ref(op, A.view(op.x).clone(), r, xx2)
+    A.view(op.y).copy_(y)
+    A.view(op.extra["y2"]).copy_(y2)
+    want = A.flat
+    live = ~torch.isnan(want)
+    assert torch.equal(live, ~torch.isnan(got))
+    scale = float(want[live].abs().max())
+    assert float((got[live] - want[live]).abs().max()) < 6e-5 * max(1.0, scale)
+    untouched = torch.ones_like(start, dtype=torch.bool)
+    for v in (op.y, op.extra["y2"]):
+        b = v.buf
+        m = untouched[:, b.offset:b.offset + b.size].view(n, b.h, b.w, b.c)
+        m[:, v.y0:v.y0 + v.h, v.x0:v.x0 + v.w, v.c0:v.c0 + v.c] = False
+    untouched &= live
+    assert torch.equal(got[untouched], start[untouched])
+    Q, (_, _, out_q, t1_q) = build(False)
+    assert [o.kind for o in Q.ops] == [PL.OP_CONV, PL.OP_CONV]
+    eng2, _ = _run(Q, n, seed=11)
+    assert all(o.act_dtype in (2, 3) for o in eng2.ops)
+    assert torch.equal(eng2.buffer(out_q, n), eng.buffer(out, n))
+    assert torch.equal(eng2.buffer(t1_q, n), eng.buffer(t1, n))
+
+
 def test_network_with_and_without_chains_is_bit_equal(monkeypatch):
     from hover_net_amd import net_desc
     from hover_net_amd.synth import synth_state_dict, synth_tiles

@@ -92,6 +92,18 @@ PY
     Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
     for cfg in "HVN_X3G=0" "HVN_X3G=1"; do ENVV=($cfg); bench x3g_$(echo $cfg | tr -d ' =A-Z_') $Q; done
     ;;
+  chainx3)    # round 5: d0's seams chained on the bf16 pipe (csrc/hvn_conv_chain_x3.hip): parity, goldens, trained-like margins, per-launch tables
+              # and bench lines for HVN_X3_CHAIN = "" (fp32-pipe chains, rounds 3-4) | d0 | d0d1
+    timeout 900 python -m pytest tests/test_gpu_chain.py tests/test_gpu_net.py -q --tb=line 2>&1 | tail -15 >> $O
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for c in "" d0 d0d1; do
+      f=gpurun_out/${R}_layers_chain_${c:-fp32}.txt
+      HVN_X3_CHAIN=$c timeout 300 python tools/layer_ms.py > $f 2>&1; echo "== HVN_X3_CHAIN=$c: $(tail -1 $f)" >> $O
+      grep -E "^d0|^d1.units.0|\+" $f | head -24 >> $O
+      ENVV=(HVN_X3_CHAIN=$c); bench chain_${c:-fp32} $Q
+    done
+    timeout 900 python -m pytest tests/test_gpu_trained_like.py -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
