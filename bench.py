@@ -675,6 +675,11 @@ def main():
             red = pmc_traffic.reduce(dbs["FETCH_SIZE"], dbs["WRITE_SIZE"], n_conv)
             if red["launches"] != n_conv:
                 return None, "expected %d conv dispatches under the counters, saw %d" % (n_conv, red["launches"])
+            keep = os.environ.get("HVN_KEEP_PMC_TABLE")          # path: the per-launch-class traffic table of the same two passes (tools/traffic_table.py)
+            if keep:
+                import traffic_table
+                with open(keep, "w") as fh:
+                    fh.write(traffic_table.table(dbs["FETCH_SIZE"], dbs["WRITE_SIZE"], net_rf.engine(args.batch), args.batch))
             return red, None
         except subprocess.TimeoutExpired:
             return None, "PMC child run exceeded %.0f s" % args.traffic_timeout

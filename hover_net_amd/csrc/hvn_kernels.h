@@ -185,6 +185,9 @@ struct WgradArgs {
     int want_wgs;         // workgroups the K split aims at (0: the default)
 };
 int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream);
+// the same sum with its products on the bf16 matrix pipe from bf16x3 splits of both operands (hvn_wgrad_x3.hip): 128 x 128 channel tiles
+int hvn_wgrad_x3_supported(const WgradArgs &a);
+int hvn_launch_wgrad_x3(WgradArgs a, int terms, hipStream_t stream);
 int hvn_launch_wino_dy(const struct WinoArgs &a, hipStream_t stream);
 int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, int cin, hipStream_t stream);
 

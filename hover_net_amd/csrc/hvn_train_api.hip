@@ -81,7 +81,9 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
         a.xb = t->batch_stride[0]; a.db = t->batch_stride[1]; a.wb = t->batch_stride[2];
         a.want_wgs = t->mode > 0 ? t->mode : 0;
         if ((long)batch * a.Ho * a.Wo >= (1L << 31)) return tfail(HVN_E_ARG, "wgrad: too many rows", idx);
-        int rc = hvn_launch_wgrad(a, s);
+        const int x3 = t->_pad;     // 6 | 9: products on the bf16 pipe (bf16x3 splits of both operands) where the shape has that form
+        if (x3 != 0 && x3 != 6 && x3 != 9) return tfail(HVN_E_ARG, "wgrad: _pad selects the bf16x3 form with 6 or 9 partial products (0: fp32 pipe)", idx);
+        int rc = (x3 && hvn_wgrad_x3_supported(a)) ? hvn_launch_wgrad_x3(a, x3, s) : hvn_launch_wgrad(a, s);
         if (rc == -1) return tfail(HVN_E_ARG, "wgrad: unsupported channel counts", idx);
         return rc;
     }

@@ -115,6 +115,10 @@ class HoVerNet(nn.Module):
         # launch schedule of the inference engine: None = the engine's default (fp32: two encoder sub-batches + decoder branch
         # streams), or (n_split, n_lanes); (1, 0) = one launch stream (every launch can then be timed alone: bench.py's roofline leg)
         self.launch_schedule = None
+        # how the fp32 network is lowered: "default" (bf16x3 products with six partial products, F(6x6) Winograd tiles where the
+        # trained-like parity test keeps a 3 - 4x margin) or "conservative" (nine partial products, F(4x4) tiles everywhere) for
+        # checkpoints with hotter activations than the qualified range (plan.build_plan); set before the first forward
+        self.lowering = "default"
 
     def _apply(self, fn, *a, **k):
         # .to() / .cuda() / .float() replace the parameter storage: the bound plans (and the training engine's slabs
@@ -138,11 +142,12 @@ class HoVerNet(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("HoVerNet runs on MI355X only: call .to('cuda') first (no CPU fallback)")
-        key = (self._weights_version(), str(dev), self.compute_dtype, self.launch_schedule)
+        key = (self._weights_version(), str(dev), self.compute_dtype, self.launch_schedule, self.lowering)
         if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             bf16 = self.compute_dtype == "bf16"
-            plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None, chain=False if bf16 else None, x3=0 if bf16 else None)
+            plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None, chain=False if bf16 else None, x3=0 if bf16 else None,
+                                 lowering=self.lowering)
             self._engine = None  # free the old arena first
             ns, nl = self.launch_schedule if self.launch_schedule is not None else (None, None)
             self._engine = E.Engine(plan, max(self.max_batch, batch), dev, dtype=self.compute_dtype, n_split=ns, n_lanes=nl)

@@ -396,7 +396,10 @@ class Plan:
         return sum(o.flops() for o in self.ops)
 
 
-def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None, chain=None, x3=None):
+LOWERINGS = ("default", "conservative")
+
+
+def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=None, chain=None, x3=None, lowering="default"):
     """sd: reference-format state_dict (torch tensors or numpy arrays).
     winograd: output tile m (2 or 4) of the Winograd F(m x m, 5x5) form of the 5x5 decoder convs; 0 / False = direct
     convolution; default 4 (env HVN_WINOGRAD).
@@ -405,20 +408,29 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     x3: 0 = every fp32 conv on the fp32 matrix pipe; 9 | 6 = the MFMA-bound conv launches form their products on the bf16 matrix pipe
     from exact three-way bf16 splits of the fp32 operands (csrc/hvn_conv_x3.hip, `Plan.mark_x3`); default env HVN_X3; fp32 only."""
     import os
+    if lowering not in LOWERINGS:
+        raise ValueError("lowering must be one of %s, got %r" % (LOWERINGS, lowering))
+    conservative = lowering == "conservative"
+    # lowering="conservative" (HoVerNet.lowering; no environment involved): for checkpoints whose activations run hotter than the ones the
+    # default was qualified on (tests/test_gpu_trained_like.py: logits within 1e-3 of the fp32 oracle up to max |activation| ~ 10^2) --
+    # F(4x4, .) Winograd tiles everywhere (the smallest transform constants) and all NINE partial products of the bf16x3 convolution
+    # (the fp32 dot product in another summation order, nothing dropped).  ~15 % slower (DESIGN section 2).
     if chain is None:
         chain = os.environ.get("HVN_CHAIN", "1") != "0"
     if winograd is None:
-        winograd = int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
+        winograd = 4 if conservative else int(os.environ.get("HVN_WINOGRAD", "4"))      # output tile m of F(m x m, 5x5); 0 = direct conv
     wino_m = 4 if winograd is True else int(winograd)
     # per decoder stage override of the 5x5 output tile, e.g. HVN_WINOGRAD_STAGES="u3:6" (F(6x6,5x5) for u3.conva only, the rest as
     # HVN_WINOGRAD says): F(6x6,5x5) costs ~8x the fp32 error of F(4x4,5x5) (tests/test_gpu_trained_like.py), which stage carries it matters
     # Default since round 4: u3 (1024 -> 256 @62^2, the largest product) as F(6x6,5x5): 1.95e-4 on the trained-like checkpoint against
     # 1.70e-4 without and 1.95e-4 for direct convolutions; u2 (4.0e-4) and u1 (1.15e-3: it feeds the logits directly) keep F(4x4,5x5).
     wino_stage = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in os.environ.get("HVN_WINOGRAD_STAGES", "u3:6").split(",") if ":" in kv}
-    if not winograd:
+    if not winograd or conservative:
         wino_stage = {}
     wino3 = int(os.environ.get("HVN_WINOGRAD3", "128"))      # minimum channel count for the Winograd form of the encoder's 3x3 convs; 0 = off
     wino3_m = int(os.environ.get("HVN_WINOGRAD3_M", "6"))     # its output tile: F(6x6,3x3) (default since round 4: same logit error, 1.78 instead of 2.25 multiplies per output) or F(4x4,3x3)
+    if conservative:
+        wino3_m = 4
     P = Plan(mode, nr_types)
     g = P.geo
     k = g["k"]
@@ -527,9 +539,10 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         P.pred_map = pm
         P.add(Op(OP_PREDMAP, "infer_step.epilogue", y=View(pm), extra={"branches": list(arch.branch_names(nr_types))}))
     if x3 is None:
-        x3 = int(os.environ.get("HVN_X3", "6"))       # default since round 4: six partial products (measured: the fp32-MFMA path's own error band)
+        x3 = 9 if conservative else int(os.environ.get("HVN_X3", "6"))       # default since round 4: six partial products (measured: the fp32-MFMA path's own error band)
     if x3:
-        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "1") != "0", chain=os.environ.get("HVN_X3_CHAIN", "d0") if chain else "")
+        # (which pipe a layer's products run on is a rule by LAYER, never by what the chain pass did: HVN_CHAIN=0 runs the same bits unchained)
+        P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "1") != "0", chain=os.environ.get("HVN_X3_CHAIN", "d0"))
     if chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
     if os.environ.get("HVN_FUSE_UPADD", "0") != "0":

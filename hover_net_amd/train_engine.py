@@ -178,6 +178,8 @@ class TrainEngine:
         # three-way bf16 splits; the planes of the step's weight packings are made on the device right after the packing
         # (HVN_TRAIN_X3 = 6 (default) | 9 partial products per product, 0 = every conv on the fp32 pipe)
         self.x3_terms = int(os.environ.get("HVN_TRAIN_X3", "6"))
+        # round 5: the weight gradients too (csrc/hvn_wgrad_x3.hip: both operands split on the fly; HVN_TRAIN_WGRAD_X3=0 keeps the fp32 pipe)
+        self.wgrad_x3 = self.x3_terms if os.environ.get("HVN_TRAIN_WGRAD_X3", "1") != "0" else 0
         self.packs_x3 = torch.zeros(3 * total, dtype=torch.int16, device=self.device) if self.x3_terms else None
 
     def pack_ptr(self, key, mode):
@@ -391,6 +393,7 @@ class TrainEngine:
             t.p[0] = self._at_ptr
             g = L.hvn_top()
             g.kind, g.kh, g.kw, g.stride, g.groups, g.nbatch = T_WGRAD, 1, 1, 1, 1, 64
+            g._pad = self.wgrad_x3
             g.x = self._tview(self.wino_vs[op.wkey].data_ptr(), t1, 1, cin)
             g.dy = self._tview(self.wino_m.data_ptr(), t1, 1, cout)
             g.p[0] = du
@@ -401,6 +404,7 @@ class TrainEngine:
             return [t, g, w]
         if op.kind == "wgrad":
             t.kind = T_WGRAD
+            t._pad = self.wgrad_x3 if op.groups <= 1 else 0
             t.kh, t.kw, t.stride, t.pad_t, t.pad_l, t.groups = op.kh, op.kw, op.stride, op.pad[0], op.pad[0], op.groups
             t.x, t.dy = self._view(op.x), self._view(op.dy)
             t.p[0] = self.gptr(op.wkey)
@@ -468,12 +472,20 @@ class TrainEngine:
             key = (self.n, o.kh, o.kw, o.stride, o.pad_t, o.x.c, o.cout, o.y.h, o.y.w, o.x.h, o.x.w, bool(o.res.base), int(o.nbatch),
                    bool(o.pre_scale), int(o.x2.c) if o.x2.base else 0, int(o.act_dtype))
             cands = (128, 64) if o.tile_n == 128 else (64, 320)
+            if (o.tile_n == 128 and o.act_dtype in (2, 3) and o.cout >= 128 and not o.pre_scale and os.environ.get("HVN_X3G", "1") != "0"):
+                cands = cands + (896, 640)                 # + the LDS-DMA forms of the bf16x3 convolution (csrc/hvn_conv_x3g.hip): same packing, same bits
             if key not in _TILE_CHOICE:
                 t = {}
                 for tn in cands:
                     o.tile_n = tn
-                    t[tn] = time_op(o)
-                _TILE_CHOICE[key] = (cands[1] if t[cands[1]] < margin * t[cands[0]] else cands[0], t[cands[0]], t[cands[1]])
+                    try:
+                        t[tn] = time_op(o)
+                    except L.HvnError:
+                        if tn in (128, 64, 320):
+                            raise
+                        t[tn] = float("inf")               # a form the launcher refuses for this geometry
+                best = min(cands[1:], key=lambda tn: t[tn])
+                _TILE_CHOICE[key] = (best if t[best] < margin * t[cands[0]] else cands[0], t[cands[0]], t[best])
             o.tile_n = _TILE_CHOICE[key][0]
         # weight gradients: the split of the pixel sum (hvn_top.mode = workgroups aimed at; csrc/hvn_train.hip: launch_wgrad)
         tsz = ctypes.sizeof(L.hvn_top)
@@ -496,7 +508,7 @@ class TrainEngine:
             t = self.bwd_ops[i]
             if t.kind != T_WGRAD:
                 continue
-            key = ("wgrad", self.n, t.kh, t.kw, t.stride, t.pad_t, t.x.c, t.dy.c, t.dy.h, t.dy.w, t.x.h, t.x.w, t.groups, int(t.nbatch))
+            key = ("wgrad", self.n, t.kh, t.kw, t.stride, t.pad_t, t.x.c, t.dy.c, t.dy.h, t.dy.w, t.x.h, t.x.w, t.groups, int(t.nbatch), int(t._pad))
             if key not in _TILE_CHOICE:
                 ms = {}
                 for want in WGRAD_TARGETS:

@@ -206,7 +206,9 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *                p[3] = grad gamma (+=), p[4] = grad beta (+=), p[5] = coef[3c] scratch
  *   WGRAD        p[0][cout][kh*kw][cin_g] += sum_pixels dy (x) x: x = conv input view, dy = output-gradient view;
  *                kh, kw, stride, pad_t, pad_l, groups; mode = workgroups the split of the pixel sum aims at (0: default;
- *                a tuning hint, the result is the same sum in another order)
+ *                a tuning hint, the result is the same sum in another order); `_pad` = 6 | 9: the products run on the bf16 matrix
+ *                pipe from exact three-way bf16 splits of both fp32 operands (csrc/hvn_wgrad_x3.hip; 9 = every partial product, 6 =
+ *                those above 2^-24 of a product) where the shape has that form (ungrouped, cout >= 128, x.c % 128 == 0), 0 = fp32 pipe
  *   CONV0_WGRAD  x = uint8 image view, dy = grad of the conv0 output, p[0] = grad [64][7][7][3] (+=); pad_t
  *   UPADD_BWD    dy = grad of nearest2x(lo) + skip; dx = grad lo (+= 2x2 sums, nullable), y = grad skip (+=, nullable)
  *   HEAD_BWD     x = head input [h][w][64], dx = its grad (+=), p[0] = logit grad NCHW, p[1] = W [cout][64],

@@ -119,6 +119,51 @@ WG_CASES = [  # n, H, W, cin, cout, k, stride, pad(lo,hi), groups, dy step
 ]
 
 
+WGX3_CASES = [  # the shapes csrc/hvn_wgrad_x3.hip has a form for (ungrouped, cout >= 128, cin % 128 == 0) + a cout that ends inside a tile
+    (2, 24, 24, 128, 256, 1, 1, (0, 0), 1),
+    (2, 24, 24, 128, 128, 3, 2, (0, 1), 2),
+    (1, 40, 40, 1024, 256, 5, 1, (0, 0), 1),
+    (3, 13, 11, 256, 192, 3, 1, (1, 1), 1),
+    (2, 9, 7, 384, 512, 1, 1, (0, 0), 1),
+]
+
+
+@pytest.mark.parametrize("terms", [6, 9])
+@pytest.mark.parametrize("n,H,W,cin,cout,k,stride,pad,step", WGX3_CASES)
+def test_wgrad_on_the_bf16_pipe_matches_torch(n, H, W, cin, cout, k, stride, pad, step, terms):
+    """HVN_T_WGRAD with `_pad` = 6 | 9 (csrc/hvn_wgrad_x3.hip): the same sum with its products formed on the bf16 matrix pipe from exact
+    bf16x3 splits of both operands -- held to the fp32 kernel's tolerance (9 terms: the fp32 products in another order) or 1.5x it."""
+    import train_interp
+    from hover_net_amd import lib as L
+    from hover_net_amd.train_plan import TOp
+    g = torch.Generator().manual_seed(2)
+    wo = (W + pad[0] + pad[1] - k) // stride + 1
+    ho = (H + pad[0] + pad[1] - k) // stride + 1
+    xb = torch.randn(n, H + 3, W + 2, cin + 32, generator=g).cuda()
+    dyb = torch.randn(n, ho * step, wo * step, cout, generator=g).cuda()
+    xv = view_of(xb, 2, 1, H, W, 32, cin)
+    dyv = view_of(dyb, 0, 0, ho, wo, 0, cout, step=step)
+    dw = torch.zeros(cout * k * k * cin, device="cuda")
+    t = L.hvn_top()
+    t.kind, t.kh, t.kw, t.stride, t.pad_t, t.pad_l, t.groups = 5, k, k, stride, pad[0], pad[0], 1
+    t._pad = terms
+    t.x, t.dy = xv, dyv
+    t.p[0] = dw.data_ptr()
+    run_tops([t], n)
+    op = TOp("wgrad", "t", stride=stride, pad=pad, groups=1)
+    x = xb.cpu()[:, 2:2 + H, 1:1 + W, 32:]
+    dy = dyb.cpu()[:, ::step, ::step]
+    want = train_interp.wgrad_ref(op, x, dy, (cout, cin, k, k))
+    tol = 2e-4 if terms == 9 else 3e-4
+    close(dw.cpu().view(cout, k, k, cin).permute(0, 3, 1, 2), want, tol, "wgrad bf16x3")
+    run_tops([t], n)          # accumulates
+    close(dw.cpu().view(cout, k, k, cin).permute(0, 3, 1, 2), 2 * want, tol, "wgrad bf16x3 accumulate")
+    for bad in (3, 7):        # _pad names the number of partial products: anything else is refused
+        t._pad = bad
+        with pytest.raises(Exception):
+            run_tops([t], n)
+
+
 @pytest.mark.parametrize("n,H,W,cin,cout,k,stride,pad,groups,step", WG_CASES)
 def test_wgrad_matches_torch(n, H, W, cin, cout, k, stride, pad, groups, step):
     import train_interp

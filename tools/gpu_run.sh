@@ -104,6 +104,19 @@ PY
     done
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
+  wgradx3)    # round 5: weight gradients on the bf16 pipe (csrc/hvn_wgrad_x3.hip) + the LDS-DMA conv forms in the training step: kernel tests,
+              # then the training step with / without them on one box
+    timeout 900 python -m pytest tests/test_gpu_train.py -q --tb=line -k "wgrad" 2>&1 | tail -8 >> $O
+    for cfg in "HVN_TRAIN_WGRAD_X3=0 HVN_X3G=0" "HVN_TRAIN_WGRAD_X3=1 HVN_X3G=0" "HVN_TRAIN_WGRAD_X3=1 HVN_X3G=1"; do
+      env $cfg timeout 400 python tools/train_bench.py --steps 8 --warmup 3 2>/dev/null | grep "^{" | sed "s/^/$cfg /" >> gpurun_out/${R}_train_ab.jsonl
+    done
+    python - >> $O <<PY
+import json
+for l in open("gpurun_out/${R}_train_ab.jsonl"):
+    i = l.index("{"); tag, d = l[:i], json.loads(l[i:])
+    print(tag, "phase", d.get("phase"), "batch", d.get("batch"), "ms/step %.2f" % d.get("ms_per_step", 0), {k: round(v, 2) for k, v in d.items() if k.endswith("_ms")})
+PY
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
