@@ -178,7 +178,9 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         const bool x3 = op->act_dtype == 2 || op->act_dtype == 3;
         if (x3 && (a.groups > 1 || (a.nbatch > 1 && (a.wb & 7)))) return fail(HVN_E_ARG, "conv(bf16x3): no grouped convs; batch stride of the planes must keep 16-byte alignment%s", "");
         int rc;
-        if (bf16)
+        if (bf16 && (op->tile_n == 896 || op->tile_n == 640))            // LDS-DMA form of the bf16 convolution (hvn_conv_bf16g.hip)
+            rc = hvn_launch_conv_bf16g(a, op->tile_n == 896 ? 256 : 128, s);
+        else if (bf16)
             rc = hvn_launch_conv_bf16(a, op->tile_n, s);
         else if (x3 && (op->tile_n == 896 || op->tile_n == 640))      // LDS-DMA form, 256 | 128 pixels x 128 channels (hvn_conv_x3g.hip)
             rc = hvn_launch_conv_x3g(a, op->tile_n == 896 ? 256 : 128, op->act_dtype == 3 ? 6 : 9, s);

@@ -82,6 +82,8 @@ int hvn_chain_supported(int c, int n2);
 // the same op with w1 / w2 = bf16 planes of the fp32 packings and both GEMMs' products on the bf16 matrix pipe (hvn_conv_chain_x3.hip)
 int hvn_launch_conv_chain_x3(const ChainArgs &a, int terms, hipStream_t stream);
 int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream);   // x, res, y, x2, w are bf16; bias / scales fp32
+// the same convolution (same packing, same bits) with both operands staged by LDS-DMA: bm = 256 | 128 pixels x 128 channels (hvn_conv_bf16g.hip)
+int hvn_launch_conv_bf16g(const ConvArgs &a, int bm, hipStream_t stream);
 // fp32 in / out; w = [cout_pad][k-step][3][32] bf16 planes of the fp32 weights; terms = 9 | 6 partial products (hvn_conv_x3.hip)
 int hvn_launch_conv_x3(const ConvArgs &a, int tile_n, int terms, hipStream_t stream);
 // the same convolution (same packing, same bits) with both operands staged by LDS-DMA, bm = 256 | 128 pixels x 128 channels (hvn_conv_x3g.hip)

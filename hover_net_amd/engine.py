@@ -173,6 +173,8 @@ class Engine:
                     o.tile_n = tn
         elif dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
             self.autotune_tiles()
+        elif dtype == "bf16" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and os.environ.get("HVN_BF16G", "1") != "0":
+            self.autotune_bf16_forms()
 
     # ---------------------------------------------------------------------------------
     def _upload_params(self):
@@ -379,6 +381,54 @@ class Engine:
                         t[tn] = float("inf")       # an LDS-DMA form the launcher refuses for this geometry (32-bit reach of a 256-row tile)
                 best = min(cands[1:], key=lambda tn: t[tn])
                 self.tile_choice[key] = (best if t[best] < margin * t[cands[0]] else cands[0], t[cands[0]], t[best], dict(t))
+            self.ops[i].tile_n = self.tile_choice[key][0]
+        torch.cuda.synchronize(self.device)
+
+    def autotune_bf16_forms(self, reps=3, margin=0.985):
+        """bf16 engine (BASELINE cfg 3): every CONV launch with >= 128 output channels and no prologue is timed once per distinct
+        shape on csrc/hvn_conv_bf16.hip (tile_n 128) and on the two LDS-DMA forms of csrc/hvn_conv_bf16g.hip (256 | 128 pixels x 128
+        channels) and keeps the fastest -- same packing and same bits for all three (tests/test_gpu_bf16.py).  HVN_BF16G=0 keeps
+        hvn_conv_bf16.hip everywhere, HVN_BF16G_FORCE=896 | 640 takes that form wherever it exists (tests, A/B runs)."""
+        import os
+
+        lib = L.lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        osz = ctypes.sizeof(L.hvn_op)
+        base = ctypes.addressof(self.ops)
+        forced = os.environ.get("HVN_BF16G_FORCE")
+
+        def time_op(i):
+            best = float("inf")
+            for r in range(reps + 1):
+                e0.record()
+                L.check(lib.hvn_run_op(base + i * osz, self.max_batch, ctypes.c_void_p(stream)), "hvn_run_op (autotune)")
+                e1.record()
+                e1.synchronize()
+                if r:
+                    best = min(best, e0.elapsed_time(e1))
+            return best
+
+        for i, op in enumerate(self.plan.ops):
+            if op.kind != PL.OP_CONV or self.ops[i].tile_n != 128 or op.pre is not None or op.cout < 128 or int(op.extra.get("nbatch", 1)) > 1:
+                continue
+            x2 = op.extra.get("x2")
+            key = ("bf16", self.max_batch, op.kh, op.kw, op.stride, op.x.c, op.cout, op.y.h, op.y.w, op.x.h, op.x.w, op.res is not None,
+                   op.post is not None, x2.c if x2 is not None else 0, int(op.extra.get("groups", 1)))
+            if key not in self.tile_choice:
+                t = {}
+                for tn in ((int(forced),) if forced else (128, X3G_256, X3G_128)):
+                    self.ops[i].tile_n = tn
+                    try:
+                        t[tn] = time_op(i)
+                    except L.HvnError:
+                        if tn == 128:
+                            raise
+                        t[tn] = float("inf")           # a form the launcher refuses for this geometry
+                best = min(t, key=t.get)
+                if t[best] == float("inf") or (not forced and best != 128 and t[best] >= margin * t[128]):
+                    best = 128
+                self.tile_choice[key] = (best, t.get(128, float("nan")), t[best], dict(t))
             self.ops[i].tile_n = self.tile_choice[key][0]
         torch.cuda.synchronize(self.device)
 

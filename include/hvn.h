@@ -97,7 +97,9 @@ typedef struct hvn_op {
                             products (the fp32 dot product in another summation order), 3 = the six that carry more than 2^-24
                             of a product.  tile_n of such a CONV: 128 | 64 = 128 pixels x tile_n channels per workgroup
                             (hvn_conv_x3.hip); 128 + 0x300 (896) | 128 + 0x200 (640) = 256 | 128 pixels x 128 channels with both operands
-                            staged by LDS-DMA (csrc/hvn_conv_x3g.hip; cout >= 128; same bits as the other forms) */
+                            staged by LDS-DMA (csrc/hvn_conv_x3g.hip; cout >= 128; same bits as the other forms); a CONV with act_dtype 1
+                            takes the same two codes for the LDS-DMA form of the bf16 convolution (csrc/hvn_conv_bf16g.hip: no
+                            prologue, cout >= 128, same bits as tile_n 128) */
     /* CHAIN only: the second conv's output view, packed weights, bias (or NULL) and channel count */
     hvn_view y2;
     const float *w2, *bias2; /* dev */

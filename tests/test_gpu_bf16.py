@@ -84,6 +84,80 @@ def _run_net(name, dtype):
     return g, nt, logits, pred.cpu()
 
 
+# ---- csrc/hvn_conv_bf16g.hip: the same bf16 convolution with both operands staged by LDS-DMA; tile_n codes 896 (256 pixels x 128 channels)
+#      and 640 (128 x 128).  Same packing and summation order: BIT-IDENTICAL to hvn_conv_bf16.hip for every launch class it takes. --------
+BF16G_CASES = {
+    "1x1_64_256_bn": dict(n=2, xbuf_shape=(13, 13, 64), xview=(0, 0, 13, 13, 0, 64), ybuf_shape=(13, 13, 256), yview=(0, 0, 13, 13, 0, 256), w=(256, 64, 1), bn=True, relu=1),
+    "1x1_2048_1024": dict(n=2, xbuf_shape=(13, 13, 2048), xview=(0, 0, 13, 13, 0, 2048), ybuf_shape=(13, 13, 1024), yview=(0, 0, 13, 13, 0, 1024), w=(1024, 2048, 1), bn=True, relu=1),
+    "1x1_288_128_window_tail32": dict(n=3, xbuf_shape=(21, 21, 320), xview=(1, 2, 19, 18, 0, 288), ybuf_shape=(19, 18, 160), yview=(0, 0, 19, 18, 32, 128), w=(128, 288, 1), bn=True, relu=1),
+    "res_post": dict(n=2, xbuf_shape=(17, 17, 64), xview=(0, 0, 17, 17, 0, 64), ybuf_shape=(17, 17, 256), yview=(0, 0, 17, 17, 0, 256), w=(256, 64, 1), res=True, post=True),
+    "res_inplace": dict(n=1, xbuf_shape=(20, 20, 64), xview=(0, 0, 20, 20, 0, 64), ybuf_shape=(20, 20, 128), yview=(0, 0, 20, 20, 0, 128), w=(128, 64, 1), res=True, inplace_res=True),
+    "1x1_stride2": dict(n=2, xbuf_shape=(24, 24, 256), xview=(0, 0, 24, 24, 0, 256), ybuf_shape=(12, 12, 512), yview=(0, 0, 12, 12, 0, 512), w=(512, 256, 1), stride=2),
+    "3x3_same": dict(n=2, xbuf_shape=(18, 18, 128), xview=(0, 0, 18, 18, 0, 128), ybuf_shape=(18, 18, 128), yview=(0, 0, 18, 18, 0, 128), w=(128, 128, 3), pad=(1, 1), bn=True, relu=1),
+    "3x3_same_stride2_tail32": dict(n=2, xbuf_shape=(18, 18, 160), xview=(0, 0, 18, 18, 0, 160), ybuf_shape=(9, 9, 128), yview=(0, 0, 9, 9, 0, 128), w=(128, 160, 3), stride=2, pad=(0, 1), bn=True, relu=1),
+    "3x3_valid_1024_256": dict(n=1, xbuf_shape=(12, 12, 1024), xview=(0, 0, 12, 12, 0, 1024), ybuf_shape=(10, 10, 512), yview=(0, 0, 10, 10, 0, 256), w=(256, 1024, 3)),
+}
+
+
+@pytest.mark.parametrize("form", [896, 640])
+@pytest.mark.parametrize("case", sorted(BF16G_CASES))
+def test_bf16_lds_dma_form_gives_the_bits_of_the_staged_form(case, form):
+    from gpu_util import run_conv_case
+
+    kw = dict(BF16G_CASES[case])
+    cout, cin, k = kw.pop("w")
+    kw.update(wt=_w(cout, cin, k, seed=3), seed=9, dtype="bf16")
+    ref, want = run_conv_case(force_tile=128, **kw)
+    got, _ = run_conv_case(force_tile=form, **kw)
+    _close(ref, want)
+    assert torch.equal(got, ref), "max abs difference %g" % (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("form", [896, 640])
+def test_bf16_lds_dma_form_fused_shortcut_and_whole_network(form, monkeypatch):
+    from gpu_util import MiniPlan, rand_conv_weight
+    from hover_net_amd import net_desc, plan as PL, run_desc
+    from hover_net_amd.engine import Engine
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+
+    outs = []
+    for tile in (128, form):            # the strided 1x1 shortcut as a second K source (d1 .. d3 unit 0)
+        P = MiniPlan()
+        x = PL.View(P.buf("t2", 13, 13, 64))
+        x2 = PL.View(P.buf("xin", 26, 26, 256))
+        y = PL.View(P.buf("y", 13, 13, 512))
+        rng = np.random.default_rng(5)
+        P.conv("fused", x, y, rand_conv_weight(rng, 512, 64, 1), x2=x2, wt2=rand_conv_weight(rng, 512, 256, 1), stride2=2,
+               post=(rng.uniform(0.5, 1.5, 512), rng.normal(0, 0.3, 512)))
+        P.pack()
+        eng = Engine(P, max_batch=2, n_split=1, dtype="bf16")
+        eng.arena.view(torch.bfloat16).copy_(torch.randn(eng.arena.shape, generator=torch.Generator().manual_seed(1)))
+        eng.ops[0].tile_n = tile
+        eng.run_raw(2)
+        torch.cuda.synchronize()
+        outs.append(eng.buffer(y, 2).float().cpu().clone())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    # the whole 'fast' network: every launch that has the form on it vs hvn_conv_bf16.hip everywhere
+    tiles = torch.from_numpy(synth_tiles(3, 256, seed=5)).cuda()
+    res, counts = [], []
+    for env in ({"HVN_BF16G": "0"}, {"HVN_BF16G_FORCE": str(form)}):
+        for k in ("HVN_BF16G", "HVN_BF16G_FORCE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = net_desc.create_model(mode="fast", nr_types=6, input_ch=3)
+        net.load_state_dict(synth_state_dict("fast", 6, seed=2), strict=True)
+        net.compute_dtype = "bf16"
+        net = net.cuda().eval()
+        run_desc.infer_step_device(tiles, net)
+        eng = net.engine(3)
+        counts.append(sum(1 for o in eng.ops if o.kind == PL.OP_CONV and o.tile_n in (896, 640)))
+        res.append({k: eng.logits[k][:3].cpu().clone() for k in eng.logits})
+    assert counts[0] == 0 and counts[1] > 20, counts
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
 @pytest.mark.parametrize("name", ["fast6", "orig5"])
 def test_bf16_network_within_declared_tolerance(name):
     g, nt, logits, pred = _run_net(name, "bf16")

@@ -152,10 +152,12 @@ def test_every_conv_launch_stays_inside_the_kernels_32bit_reach(mode, nt):
 
 
 def test_bf16x3_lowering_rule_and_weight_planes(monkeypatch):
-    """Round 4: which launches go to csrc/hvn_conv_x3.hip is a STATIC rule by layer (`Plan.mark_x3`): every dense conv with a 128- / 64-wide
-    column tile except d0's 1x1 convs and d1's first conv1 (the fp32-pipe chain partners); d1's other 1x1 convs run there unchained.  The
-    chained and the unchained lowering mark the same layers; HVN_X3=0 marks none.  And the three bf16 planes the engine uploads for such a
-    launch sum back to the fp32 weights EXACTLY (h + m + l == w in fp32 arithmetic), in the k-step order the kernel walks."""
+    """Which launches form their products on the bf16 pipe is a STATIC rule by layer (`Plan.mark_x3`): every dense conv with a 128- /
+    64-wide column tile except d0's very first 1x1; since round 5 d0's seams (conv3 -> next conv1, the last one into d1's first conv1)
+    are bf16x3 too and run CHAINED on csrc/hvn_conv_chain_x3.hip (HVN_X3_CHAIN="" keeps rounds 3-4's fp32-pipe chains); d1's other 1x1
+    convs run unchained.  The chained and the unchained lowering mark the same layers; HVN_X3=0 marks none.  And the three bf16 planes
+    the engine uploads for such a launch sum back to the fp32 weights EXACTLY (h + m + l == w in fp32 arithmetic), in the k-step order
+    the kernel walks."""
     import re
 
     from hover_net_amd.engine import pack_conv_x3, split_bf16x3
@@ -164,14 +166,21 @@ def test_bf16x3_lowering_rule_and_weight_planes(monkeypatch):
     P = PL.build_plan(sd, "original", 5)
     x3 = [o for o in P.ops if o.kind == PL.OP_CONV and o.extra.get("x3")]
     assert len(x3) == 93 and all(o.extra["x3"] == 6 for o in x3)
-    assert [o.name for o in P.ops if o.kind == PL.OP_CHAIN] == ["d0.units.0.conv3+units.1.conv1", "d0.units.1.conv3+units.2.conv1",
-                                                                "d0.units.2.conv3+d1.units.0.conv1"]
-    assert not any(re.match(r"^d0\.units\.\d+\.conv[13]$", o.name) or o.name == "d1.units.0.conv1" for o in x3)
+    chains = [o for o in P.ops if o.kind == PL.OP_CHAIN]
+    assert [o.name for o in chains] == ["d0.units.0.conv3+units.1.conv1", "d0.units.1.conv3+units.2.conv1", "d0.units.2.conv3+d1.units.0.conv1"]
+    assert all(o.extra.get("x3") == 6 for o in chains)                    # both GEMMs of a seam on the bf16 pipe
+    assert not any(re.match(r"^d0\.units\.\d+\.conv[13]$", o.name) or o.name == "d1.units.0.conv1" for o in x3)      # (they are inside the chains)
     assert not any(int(o.extra.get("groups", 1)) != 1 for o in x3)
     monkeypatch.setenv("HVN_CHAIN", "0")
     P0 = PL.build_plan(sd, "original", 5)
-    assert sorted(o.name for o in P0.ops if o.extra.get("x3")) == sorted(o.name for o in x3)          # the rule does not depend on the chain pass
+    parts = sorted(p_.name for o in chains for p_ in o.extra["parts"])
+    assert sorted(o.name for o in P0.ops if o.extra.get("x3")) == sorted([o.name for o in x3] + parts)   # the rule does not depend on the chain pass
     monkeypatch.delenv("HVN_CHAIN")
+    monkeypatch.setenv("HVN_X3_CHAIN", "")                               # rounds 3-4: d0's seams chained on the fp32 pipe
+    Pf = PL.build_plan(sd, "original", 5)
+    assert sorted(o.name for o in Pf.ops if o.kind == PL.OP_CONV and o.extra.get("x3")) == sorted(o.name for o in x3)
+    assert [bool(o.extra.get("x3")) for o in Pf.ops if o.kind == PL.OP_CHAIN] == [False] * 3
+    monkeypatch.delenv("HVN_X3_CHAIN")
     monkeypatch.setenv("HVN_X3", "0")
     assert not any(o.extra.get("x3") for o in PL.build_plan(sd, "original", 5).ops)
     # the planes: exact three-way split, and the packing's layout [cout_pad][k-step][3][32]
