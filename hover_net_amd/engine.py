@@ -56,6 +56,7 @@ def pick_tile_n(op, batch):
     return 64 if narrow < wide else 128
 
 
+_TILE_CACHE = {}        # device -> {launch shape key: (choice, ms of the default, ms of the choice, {candidate: ms})}
 X3G_256, X3G_128 = 128 + 0x300, 128 + 0x200     # hvn_op.tile_n of the LDS-DMA forms of the bf16x3 convolution (include/hvn.h)
 
 
@@ -158,7 +159,9 @@ class Engine:
         self.ops = (L.hvn_op * len(plan.ops))()
         self._bind()
         self._sub_ops = {}
-        self.tile_choice = {}
+        # measured launch-shape choices (column tile / kernel form), keyed by everything the timing depends on: shared by every engine of
+        # the process on this device -- the forms give the same bits, so WHICH engine timed a shape first is invisible in the results
+        self.tile_choice = _TILE_CACHE.setdefault(str(self.device), {})
         tile_file = os.environ.get("HVN_TILE_FILE")          # a list of per-op column tiles written by another engine of the same plan
         if tile_file and dtype == "fp32":                   # (bench.py hands its measured choices to the PMC child runs)
             import json
@@ -368,6 +371,7 @@ class Engine:
                     except L.HvnError:
                         self.ops[i].tile_n = 128
                 cands = cands + x3g_forms_for(op)
+            key = key + (cands,)                           # (the cache is shared between engines: another candidate set is another question)
             if key not in self.tile_choice:
                 o = self.ops[i]
                 t = {}
@@ -415,6 +419,7 @@ class Engine:
             x2 = op.extra.get("x2")
             key = ("bf16", self.max_batch, op.kh, op.kw, op.stride, op.x.c, op.cout, op.y.h, op.y.w, op.x.h, op.x.w, op.res is not None,
                    op.post is not None, x2.c if x2 is not None else 0, int(op.extra.get("groups", 1)))
+            key = key + (forced,)
             if key not in self.tile_choice:
                 t = {}
                 for tn in ((int(forced),) if forced else (128, X3G_256, X3G_128)):

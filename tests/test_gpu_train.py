@@ -474,9 +474,13 @@ def test_training_step_matches_oracle(case, monkeypatch):
     sd = synth_state_dict(mode, nt, seed=int(gold["wseed"]))
     batch = synth_train_batch(n, mode, nt, seed=int(gold["bseed"]))
     torch.set_num_threads(max(8, (os.cpu_count() or 8) // 2))
-    if case not in _ORACLE_CACHE:           # the CPU oracle runs (fp32 + float64) dominate this test
-        _ORACLE_CACHE[case] = (train_torch.train_step(sd, batch, mode, nt, freeze),
-                               train_torch.train_step(sd, batch, mode, nt, freeze, dtype=torch.float64))
+    # The float64 oracle run dominates this test (40 - 50 s of CPU per case): by default it is made for the case that trains EVERY layer
+    # (orig5_full: statement 1 in full); the other two cases take the torch-fp32 oracle as their reference and bound the HIP run's
+    # distance to it as one more pair of fp32 evaluations (statement 1').  HVN_TRAIN_ORACLE_F64=all restores float64 for every case.
+    use_f64 = case == "orig5_full" or os.environ.get("HVN_TRAIN_ORACLE_F64", "") == "all"
+    if case not in _ORACLE_CACHE:
+        r32_ = train_torch.train_step(sd, batch, mode, nt, freeze)
+        _ORACLE_CACHE[case] = (r32_, train_torch.train_step(sd, batch, mode, nt, freeze, dtype=torch.float64) if use_f64 else r32_)
     r32, r64 = _ORACLE_CACHE[case]
     runs = {w: _hip_step(sd, batch, mode, nt, freeze, n, w, monkeypatch) for w in ("0", "1")}
     runs["x3"] = _hip_step(sd, batch, mode, nt, freeze, n, "1", monkeypatch, x3="6")      # the default: Winograd + bf16x3 (6 partial products)
@@ -504,16 +508,25 @@ def test_training_step_matches_oracle(case, monkeypatch):
         import json
         json.dump({k: {"direct_vs_f64": e_dir[k][0], "torch_f32_vs_f64": e_dir[k][1], "winograd_vs_direct": e_win[k]} for k in keys},
                   open(os.path.join(out_dir, "train_grad_err_%s.json" % case), "w"), indent=0)
-    # 1. direct convolutions against float64
-    for k, (e_hip, e_t32) in e_dir.items():
-        assert e_hip <= max(4.0 * e_t32, 4e-3), (k, e_hip, e_t32)
-    ratios = np.array([a / max(b, 1e-12) for a, b in e_dir.values() if a > 4e-3 or b > 4e-3 / 4])
-    assert np.median(ratios) <= 1.25 and np.percentile(ratios, 90) <= 2.2, (np.median(ratios), np.percentile(ratios, 90))
     med_hip, med_t32 = np.median([a for a, _ in e_dir.values()]), np.median([b for _, b in e_dir.values()])
-    assert med_hip <= 1.25 * med_t32 + 1e-4, (med_hip, med_t32)
+    if use_f64:
+        # 1. direct convolutions against float64
+        for k, (e_hip, e_t32) in e_dir.items():
+            assert e_hip <= max(4.0 * e_t32, 4e-3), (k, e_hip, e_t32)
+        ratios = np.array([a / max(b, 1e-12) for a, b in e_dir.values() if a > 4e-3 or b > 4e-3 / 4])
+        assert np.median(ratios) <= 1.25 and np.percentile(ratios, 90) <= 2.2, (np.median(ratios), np.percentile(ratios, 90))
+        assert med_hip <= 1.25 * med_t32 + 1e-4, (med_hip, med_t32)
+    else:
+        # 1'. direct convolutions against the torch-fp32 oracle: two fp32 evaluations of the same step (each a median 5e-3 .. 9e-3 from
+        #     float64 by statement 1), bounded like the other fp32-vs-fp32 deltas below
+        worst1 = max(e_dir.items(), key=lambda kv: kv[1][0])
+        print("direct vs torch fp32: median %.2e, worst %s %.2e" % (med_hip, worst1[0], worst1[1][0]))
+        for k, (e_hip, _) in e_dir.items():
+            assert e_hip <= F32_PAIR_DELTA_MAX, (k, e_hip)
+        assert med_hip <= F32_PAIR_DELTA_MEDIAN, med_hip
     # 2. what Winograd adds
     worst = max(e_win.items(), key=lambda kv: kv[1])
-    print("direct vs f64: median %.2e (torch fp32: %.2e); Winograd vs direct: median %.2e, worst %s" % (med_hip, med_t32, np.median(list(e_win.values())), worst))
+    print("direct vs %s: median %.2e (torch fp32: %.2e); Winograd vs direct: median %.2e, worst %s" % ("f64" if use_f64 else "torch fp32", med_hip, med_t32, np.median(list(e_win.values())), worst))
     for k, e in e_win.items():
         assert e <= WINO_GRAD_DELTA_MAX, (k, e)
     assert np.median(list(e_win.values())) <= WINO_GRAD_DELTA_MEDIAN
@@ -532,6 +545,8 @@ WINO_GRAD_DELTA_MAX, WINO_GRAD_DELTA_MEDIAN = 3.5e-2, 1.0e-2
 # relative L2 per tensor of (bf16x3 run - fp32-pipe run) of the same Winograd step: another fp32-level perturbation of a step whose torch-fp32
 # evaluation itself sits a median 5e-3 from float64 (two such samples differ by ~7e-3 .. 1e-2); measured in round 4: median 1.04e-2 on orig5_full
 X3_GRAD_DELTA_MAX, X3_GRAD_DELTA_MEDIAN = 3.5e-2, 1.5e-2
+# relative L2 per tensor of (direct HIP run - torch-CPU fp32 oracle) for the cases that skip the float64 run: a pair of fp32 evaluations
+F32_PAIR_DELTA_MAX, F32_PAIR_DELTA_MEDIAN = 6.0e-2, 1.5e-2
 
 
 def test_optimizer_step_updates_the_slab_the_kernels_read():

@@ -142,9 +142,9 @@ def test_fp32_parity_on_a_trained_like_checkpoint(mode, nr_types, monkeypatch):
 
 def test_parity_margin_against_activation_scale(monkeypatch):
     """Where does the margin end?  The fitted 'original' checkpoint made HOTTER: gamma and beta of the block-closing BatchNorms of d1, d2, d3
-    (net_utils.py:262-266 -- what every later stage and every skip connection is fed with) scaled by s = 1, 2, 4.  For each: max
-    |activation| and max |logit| of the fp32 oracle, and max |logit - oracle| of the shipped lowering, of the fp32 matrix pipe, of direct
-    convolutions on the fp32 pipe and of `HoVerNet.lowering = "conservative"`.  Two fp32 evaluations of a hotter network differ by more
+    (net_utils.py:262-266 -- what every later stage and every skip connection is fed with) scaled by s = 2, 4.  For each: max
+    |activation| and max |logit| of the fp32 oracle, and max |logit - oracle| of the shipped lowering, of the fp32 matrix pipe and of
+    `HoVerNet.lowering = "conservative"` (direct convolutions on the fp32 pipe, measured once: 3.1e-3 / 3.4e-2, profiles/r05_trained_like_margins.txt).  Two fp32 evaluations of a hotter network differ by more
     (the error is relative to the activations, the 1e-3 of BASELINE north_star is absolute), so what is asserted is that the shipped and
     the conservative lowering stay within max(1e-3, 2 x the fp32 pipe's own distance from the oracle); the table (`-s`) is what
     DESIGN.md section 2 quotes for the logit magnitude at which the default leaves 1e-3."""
@@ -157,7 +157,7 @@ def test_parity_margin_against_activation_scale(monkeypatch):
     imgs = fit_util.painted_tiles(2, size, seed=777, k_lo=dens[0], k_hi=dens[1], nr_types=nr_types)[0]
     tiles = torch.from_numpy(imgs)
     rows = []
-    for s in (1.0, 2.0, 4.0):
+    for s in (2.0, 4.0):                 # (x1 is the test above: default 2.1e-4 .. 2.9e-4)
         sd = {k: v.clone() for k, v in sd0.items()}
         for blk in ("d1", "d2", "d3"):
             for leaf in ("weight", "bias"):
@@ -167,8 +167,7 @@ def test_parity_margin_against_activation_scale(monkeypatch):
         act = max(float(v.abs().max()) for v in taps.values())
         logit = max(float(v.abs().max()) for v in want.values())
         errs = {}
-        for name, env, low in (("default", {}, "default"), ("fp32 pipe", {"HVN_X3": "0"}, "default"),
-                               ("direct, fp32 pipe", {"HVN_X3": "0", "HVN_WINOGRAD": "0"}, "default"), ("conservative", {}, "conservative")):
+        for name, env, low in (("default", {}, "default"), ("fp32 pipe", {"HVN_X3": "0"}, "default"), ("conservative", {}, "conservative")):
             got, _ = _hip_logits(sd, mode, nr_types, tiles, env, monkeypatch, lowering=low)
             errs[name] = max(float((got[k] - want[k]).abs().max()) for k in want)
         rows.append((s, act, logit, errs))
@@ -177,4 +176,3 @@ def test_parity_margin_against_activation_scale(monkeypatch):
     for s, act, logit, errs in rows:
         bound = max(TOL, 2.0 * errs["fp32 pipe"])
         assert errs["default"] <= bound and errs["conservative"] <= bound, (s, errs)
-    assert rows[0][3]["default"] <= TOL
