@@ -117,6 +117,17 @@ for l in open("gpurun_out/${R}_train_ab.jsonl"):
     print(tag, "phase", d.get("phase"), "batch", d.get("batch"), "ms/step %.2f" % d.get("ms_per_step", 0), {k: round(v, 2) for k, v in d.items() if k.endswith("_ms")})
 PY
     ;;
+  bf16g)      # round 5: the LDS-DMA form of the bf16 convolution (csrc/hvn_conv_bf16g.hip), cfg 3: bit-equality tests, per-launch tables
+              # forced old | 256-pixel | 128-pixel form, bench lines without / with the forms
+    timeout 900 python -m pytest tests/test_gpu_bf16.py -q -k "lds_dma" --tb=line 2>&1 | tail -12 >> $O
+    A="--dtype bf16 --mode fast --nr-types 6 --batch 64"
+    for cfg in "HVN_BF16G=0" "HVN_BF16G_FORCE=896" "HVN_BF16G_FORCE=640"; do
+      f=gpurun_out/${R}_layers_cfg3_$(echo $cfg | tr -d ' =A-Z_').txt
+      env $cfg timeout 300 python tools/layer_ms.py $A 2>/dev/null | grep -v amdgpu.ids > $f; echo "== $cfg: $(tail -1 $f)" >> $O
+    done
+    Q="$A --steps 10 --warmup 2 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for cfg in "HVN_BF16G=0" "HVN_BF16G=1"; do ENVV=($cfg); bench bf16g_$(echo $cfg | tr -d ' =A-Z_') $Q; done
+    ;;
   trained)
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -x -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
