@@ -162,13 +162,16 @@ def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
     note = ("achieved = MFMA FLOPs executed by the launches (Winograd-domain GEMMs counted as issued; SURVEY 8d's direct-convolution figure is "
             "`algorithmic_gflop_per_step` / batch) / summed HIP-event time of those launches, per-launch median of %d passes, single stream" % n_prof)
     x3_ms = x3_eq = x3_bf16 = 0.0
+    ch_ms = ch_eq = ch_bf16 = 0.0          # round 5: the chained seams on the bf16 pipe (hvn_conv_chain_x3), their own kernel
     rest_ms = rest_flops = 0.0
-    n_x3 = 0
+    n_x3 = n_ch = 0
     if dtype == "fp32" and launches == len(timed):
         for o, t in zip(timed, per_ms):
             fl = o.extra.get("exec_flops", o.flops()) * batch if o.kind in (2, 8) else 0.0
             if o.kind == 2 and o.extra.get("x3"):
                 x3_ms += float(t); x3_eq += fl; x3_bf16 += fl * int(o.extra["x3"]); n_x3 += 1
+            elif o.kind == 8 and o.extra.get("x3"):
+                ch_ms += float(t); ch_eq += fl; ch_bf16 += fl * int(o.extra["x3"]); n_ch += 1
             else:
                 rest_ms += float(t); rest_flops += fl
     if n_x3 == 0:
@@ -181,7 +184,14 @@ def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
                 "executed_gflop_per_step": exec_flops / 1e9, "algorithmic_gflop_per_step": algo_flops / 1e9,
                 "algorithmic_speedup": algo_flops / exec_flops, "note": note + " (incl. the Winograd transform launches)"}
     ach_x3 = x3_bf16 / (x3_ms * 1e-3) / 1e12
-    ideal_ms = 1e3 * (x3_bf16 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
+    ideal_ms = 1e3 * ((x3_bf16 + ch_bf16) / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
+    chained = None
+    if n_ch:
+        chained = {"what": "hvn_conv_chain_x3: d0's residual seams (conv3 + residual -> next conv1 in one launch), both GEMMs on the bf16 pipe",
+                   "launches": n_ch, "ms_per_step": ch_ms, "bf16_mfma_gflop_per_step": ch_bf16 / 1e9, "achieved": ch_bf16 / (ch_ms * 1e-3) / 1e12,
+                   "peak": PEAK_BF16_MATRIX_TFLOPS, "frac": ch_bf16 / (ch_ms * 1e-3) / 1e12 / PEAK_BF16_MATRIX_TFLOPS,
+                   "fp32_equivalent_tflops": ch_eq / (ch_ms * 1e-3) / 1e12,
+                   "note": "HBM-bound by construction (4.0 .. 6.3 GB of compulsory bytes per seam at batch 32): see profiles/r05_traffic_by_kernel.txt"}
     return {
         "bound": "mfma", "kernel": "hvn_conv_igemm_x3 / hvn_conv_igemm_x3g (fp32 convolution, products on the bf16 matrix pipe from exact bf16x3 splits of "
                                    "the fp32 operands; the second stages both operands by LDS-DMA -- same bits, picked per launch shape by time)",
@@ -193,8 +203,9 @@ def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
         "launches": n_x3, "ms_per_step": x3_ms, "avg_launch_ms": x3_ms / n_x3, "flops_per_launch": x3_bf16 / n_x3,
         "bf16_mfma_gflop_per_step": x3_bf16 / 1e9, "fp32_products_gflop_per_step": x3_eq / 1e9,
         "fp32_equivalent_tflops": x3_eq / (x3_ms * 1e-3) / 1e12,
-        "other_launches": {"what": "fp32-MFMA launches (hvn_conv_chain_f32, hvn_conv_igemm_f32, hvn_dense_grouped*) + Winograd transform launches",
-                           "launches": launches - n_x3, "ms_per_step": rest_ms, "executed_gflop_per_step": rest_flops / 1e9,
+        "chained_seams": chained,
+        "other_launches": {"what": "fp32-MFMA launches (hvn_conv_igemm_f32, hvn_dense_grouped*, hvn_conv_chain_f32 when HVN_X3_CHAIN is off) + Winograd transform launches",
+                           "launches": launches - n_x3 - n_ch, "ms_per_step": rest_ms, "executed_gflop_per_step": rest_flops / 1e9,
                            "achieved": rest_flops / (rest_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
                            "frac": rest_flops / (rest_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS},
         "whole_step": {"conv_ms_per_step": ms, "ideal_matrix_ms": ideal_ms, "frac": ideal_ms / ms,

@@ -22,12 +22,15 @@ def _timed(P):
 def test_mixed_pipe_accounting_recovers_the_rates_it_was_fed():
     P = PL.build_plan(synth_state_dict("original", 5, seed=0), "original", 5)
     timed, batch = _timed(P), 32
-    # made-up machine: bf16x3 launches run at 1000 TFLOP/s of bf16 MFMA, fp32-pipe launches at 78.65 (half the peak), every transform 0.05 ms
+    # made-up machine: bf16x3 conv launches run at 1000 TFLOP/s of bf16 MFMA, the bf16x3 chained seams (round 5) at 500, fp32-pipe launches
+    # at 78.65 (half the peak), every transform 0.05 ms
     per = []
     for o in timed:
         fl = o.extra.get("exec_flops", o.flops()) * batch if o.kind in (PL.OP_CONV, PL.OP_CHAIN) else 0.0
         if o.kind == PL.OP_CONV and o.extra.get("x3"):
             per.append(fl * o.extra["x3"] / 1000e12 * 1e3)
+        elif o.kind == PL.OP_CHAIN and o.extra.get("x3"):
+            per.append(fl * o.extra["x3"] / 500e12 * 1e3)
         elif fl:
             per.append(fl / 78.65e12 * 1e3)
         else:
@@ -40,11 +43,13 @@ def test_mixed_pipe_accounting_recovers_the_rates_it_was_fed():
     o = r["other_launches"]
     t_fp32 = o["executed_gflop_per_step"] * 1e9 / 78.65e12 * 1e3
     assert abs(o["ms_per_step"] - (t_fp32 + 0.05 * n_tr)) < 1e-9 and abs(o["achieved"] - o["executed_gflop_per_step"] / o["ms_per_step"]) < 1e-6
+    ch = r["chained_seams"]
+    assert ch["launches"] == 3 and abs(ch["achieved"] - 500.0) < 1e-6 and abs(ch["frac"] - 0.2) < 1e-9 and abs(ch["fp32_equivalent_tflops"] - 500.0 / 6) < 1e-6
     w = r["whole_step"]
-    assert abs(w["conv_ms_per_step"] - sum(per)) < 1e-9 and abs(r["ms_per_step"] + o["ms_per_step"] - sum(per)) < 1e-9
-    ideal = 0.4 * r["ms_per_step"] + 0.5 * t_fp32
+    assert abs(w["conv_ms_per_step"] - sum(per)) < 1e-9 and abs(r["ms_per_step"] + ch["ms_per_step"] + o["ms_per_step"] - sum(per)) < 1e-9
+    ideal = 0.4 * r["ms_per_step"] + 0.2 * ch["ms_per_step"] + 0.5 * t_fp32
     assert abs(w["ideal_matrix_ms"] - ideal) < 1e-9 and abs(w["frac"] - ideal / sum(per)) < 1e-12
-    assert abs(r["executed_gflop_per_step"] - (r["fp32_products_gflop_per_step"] + o["executed_gflop_per_step"])) < 1e-6
+    assert abs(r["executed_gflop_per_step"] - (r["fp32_products_gflop_per_step"] + ch["bf16_mfma_gflop_per_step"] / 6 + o["executed_gflop_per_step"])) < 1e-6
     assert abs(r["algorithmic_gflop_per_step"] / batch - (392.17 - 1.31 - 0.006)) < 0.01           # SURVEY 8d's figure minus conv0 and the heads
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):                                # the bench contract's keys
         assert k in r

@@ -40,7 +40,7 @@ if [ -n "$WSI40K" ]; then
 fi
 cat gpurun_out/${R}_gpu_tests.log gpurun_out/${R}_smoke.log 2>/dev/null | tail -8
 python tools/bench_summary.py gpurun_out/${R}_bench.json
-tail -1 gpurun_out/${R}_layers_fp32_pipe.txt gpurun_out/${R}_layers_default.txt gpurun_out/${R}_layers_cfg3_bf16.txt
+for f in gpurun_out/${R}_layers_fp32_pipe.txt gpurun_out/${R}_layers_default.txt gpurun_out/${R}_layers_cfg3_bf16.txt; do tail -n 1 $f; done
 cat gpurun_out/${R}_traffic_by_kernel.txt 2>/dev/null
 cat gpurun_out/${R}_train_roofline_phase0.json gpurun_out/${R}_train_roofline_phase1.json 2>/dev/null | cut -c1-400
 cut -c1-300 gpurun_out/${R}_wsi_40k.json 2>/dev/null
