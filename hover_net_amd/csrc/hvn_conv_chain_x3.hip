@@ -17,7 +17,8 @@
 //
 // LDS: GEMM1 staging 2 x (128 x 128 B of A + 12 KB of planes) = 56 KB, aliased by the epilogue / GEMM2-A tile [128][68] floats; the W1'
 // chunk's planes behind it: both k-steps of 32 for cout2 = 64 (24 KB), ONE at a time for cout2 = 128 (24 KB; the second waits in registers).
-// 80 KB: two workgroups per CU.
+// 80 KB: two workgroups per CU.  Registers: 232 - 244 VGPRs for cout2 = 64; the cout2 = 128 instantiations (one launch per step: d0's last
+// seam into d1) sit at the 256 cap with 9 - 27 spilled VGPRs (40 - 112 B of scratch, hipcc -Rpass-analysis=kernel-resource-usage).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -64,7 +64,7 @@ def compulsory(op, batch):
 
 
 def table(fetch_db, write_db, eng, batch):
-    ops = [o for o in eng.plan.ops if o.kind != 5 or True]
+    ops = list(eng.plan.ops)                 # one hvn_* dispatch per plan op, in launch order (single launch stream)
     f, w = _dispatches(fetch_db, "FETCH_SIZE"), _dispatches(write_db, "WRITE_SIZE")
     n = len(ops)
     f, w = f[-n:], w[-n:]
