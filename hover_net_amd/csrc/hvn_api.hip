@@ -231,7 +231,11 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
             (a.post_s && (!aligned16(a.post_s) || !aligned16(a.post_b))) || (a.bias2 && !aligned16(a.bias2)))
             return fail(HVN_E_ARG, "chain: per-channel vectors must be 16-byte aligned and come in pairs%s", "");
         if (g_prof) prof_mark(s);
-        int rc = cx3 ? hvn_launch_conv_chain_x3(a, op->act_dtype == 3 ? 6 : 9, s) : hvn_launch_conv_chain(a, s);
+        int rc;
+        if (cx3 && op->tile_n == 1152)           // input tile resident in registers, operands a chunk ahead (hvn_conv_chain_x3r.hip)
+            rc = hvn_launch_conv_chain_x3r(a, op->act_dtype == 3 ? 6 : 9, s);
+        else
+            rc = cx3 ? hvn_launch_conv_chain_x3(a, op->act_dtype == 3 ? 6 : 9, s) : hvn_launch_conv_chain(a, s);
         if (g_prof) prof_mark(s);
         if (rc) return fail(rc == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "chain: launch failed (cout2=%s%ld)", "", a.N2);
         return 0;

@@ -81,6 +81,10 @@ int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream);
 int hvn_chain_supported(int c, int n2);
 // the same op with w1 / w2 = bf16 planes of the fp32 packings and both GEMMs' products on the bf16 matrix pipe (hvn_conv_chain_x3.hip)
 int hvn_launch_conv_chain_x3(const ChainArgs &a, int terms, hipStream_t stream);
+// the same op, same bits, conv3's input tile resident in registers and every other operand a chunk ahead in flight (hvn_conv_chain_x3r.hip);
+// exists for K1 = 64 (+ K1b = 64 without a residual view and with N2 = 64)
+int hvn_chain_x3r_supported(const ChainArgs &a);
+int hvn_launch_conv_chain_x3r(const ChainArgs &a, int terms, hipStream_t stream);
 int hvn_launch_conv_bf16(const ConvArgs &a, int tile_n, hipStream_t stream);   // x, res, y, x2, w are bf16; bias / scales fp32
 // the same convolution (same packing, same bits) with both operands staged by LDS-DMA: bm = 256 | 128 pixels x 128 channels (hvn_conv_bf16g.hip)
 int hvn_launch_conv_bf16g(const ConvArgs &a, int bm, hipStream_t stream);

@@ -58,6 +58,7 @@ def pick_tile_n(op, batch):
 
 _TILE_CACHE = {}        # device -> {launch shape key: (choice, ms of the default, ms of the choice, {candidate: ms})}
 X3G_256, X3G_128 = 128 + 0x300, 128 + 0x200     # hvn_op.tile_n of the LDS-DMA forms of the bf16x3 convolution (include/hvn.h)
+X3R = 128 + 0x400                               # hvn_op.tile_n of the bf16x3 CHAIN with a register-resident input tile (include/hvn.h)
 
 
 def x3g_forms_for(op):
@@ -172,7 +173,7 @@ class Engine:
                 if op.kind == PL.OP_CONV and ((op.tile_n == 128 and (tn in (64, 128) or (op.extra.get("x3") and tn in x3g_forms_for(op)))) or
                                               (op.tile_n == 64 and tn in (64, 320) and not op.extra.get("x3"))):
                     o.tile_n = tn
-                if op.kind == PL.OP_CHAIN and tn in (64, 128):
+                if op.kind == PL.OP_CHAIN and (tn in (64, 128) or (tn == X3R and op.extra.get("x3"))):
                     o.tile_n = tn
         elif dtype == "fp32" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and not os.environ.get("HVN_FORCE_TILE_N"):
             self.autotune_tiles()
@@ -333,7 +334,25 @@ class Engine:
 
         for i, op in enumerate(self.plan.ops):
             if op.kind == PL.OP_CHAIN and op.extra.get("x3"):
-                continue                                   # the bf16x3 chain has one workgroup shape (128 pixels)
+                # bf16x3 chain: csrc/hvn_conv_chain_x3.hip (tile_n 128) or, where it exists (conv3 with 64 input channels), the form with the
+                # input tile resident in registers and every other operand a chunk ahead in flight (csrc/hvn_conv_chain_x3r.hip, tile_n
+                # X3R) -- same bits (tests/test_gpu_chain.py), picked by time.  HVN_CHAIN_X3R=0 | force: never | wherever it exists.
+                mode = os.environ.get("HVN_CHAIN_X3R", "1")
+                x2 = op.extra.get("x2")
+                if mode == "0" or op.x.c != 64 or (x2 is not None and (x2.c != 64 or op.res is not None or op.extra["cout2"] != 64)):
+                    continue
+                key = ("chain_x3", sub_n if (i < enc_end or self.split_decoder) else self.max_batch, op.x.c, x2.c if x2 is not None else 0, op.cout, op.extra["cout2"],
+                       op.y.h, op.y.w, op.res is not None, op.post is not None, op.pre is not None, int(op.extra.get("x3", 0)), mode)
+                if key not in self.tile_choice:
+                    o = self.ops[i]
+                    t = {}
+                    for tn in ((X3R,) if mode == "force" else (128, X3R)):
+                        o.tile_n = tn
+                        t[tn] = time_op(i)
+                    best = X3R if (mode == "force" or t[X3R] < margin * t[128]) else 128
+                    self.tile_choice[key] = (best, t.get(128, float("nan")), t[X3R], dict(t))
+                self.ops[i].tile_n = self.tile_choice[key][0]
+                continue
             if op.kind == PL.OP_CHAIN:                     # chained 1x1 convs: 128 or 64 pixels per workgroup (same bits)
                 if os.environ.get("HVN_CHAIN_BM"):         # A/B runs: force one
                     self.ops[i].tile_n = int(os.environ["HVN_CHAIN_BM"])

@@ -73,7 +73,9 @@ enum { HVN_OP_CONV0 = 1, HVN_OP_CONV = 2, HVN_OP_UPADD = 3, HVN_OP_HEAD = 4, HVN
  *           res (optional, may alias y) must have y's strides; x.c + x2.c >= 64, cout % 64 == 0.  Bit-identical to the two CONV
  *           launches it replaces.  act_dtype 2 | 3: both GEMMs form their products on the bf16 matrix pipe from bf16x3 splits
  *           (csrc/hvn_conv_chain_x3.hip): w / w2 then hold the bf16 planes of the fp32 packings ([rows][k-step][3][32] bf16, see
- *           act_dtype below), 128 pixels per workgroup; bit-identical to the two CONV launches with the same act_dtype.
+ *           act_dtype below), 128 pixels per workgroup; bit-identical to the two CONV launches with the same act_dtype.  tile_n = 128 + 0x400
+ *           (1152) of such a CHAIN selects the form with conv3's input tile resident in registers and every other operand a chunk
+ *           ahead in flight (csrc/hvn_conv_chain_x3r.hip: x.c = 64, and x2.c = 64 with cout2 = 64 and no res; same bits; HVN_E_ARG otherwise).
  *   UPADD   y = nearest2x(x) + res
  *   HEAD    y.base = NCHW logits [n][cout][h][w];  w = [cout][64], bias[cout]
  *   PREDMAP y.base = [n][h][w][3|4] = [argmax(tp)?, softmax(np)[1], hv0, hv1]

@@ -107,12 +107,33 @@ def test_chain_matches_reference_and_unfused_launches(case, bm):
     assert torch.equal(eng2.buffer(t1_q, n), eng.buffer(t1, n))
 
 
-@pytest.mark.parametrize("terms", [6, 9])
-@pytest.mark.parametrize("case", CASES)
-def test_chain_on_the_bf16_pipe_matches_reference_and_unfused_bf16x3_launches(case, terms):
-    """csrc/hvn_conv_chain_x3.hip: the same op with both GEMMs' products on the bf16 matrix pipe (bf16x3 splits).  Against the torch
-    interpreter at the bf16x3 kernel's tolerance, and BIT-EQUAL to the two bf16x3 CONV launches it replaces."""
+X3R_CASES = [  # + shapes only csrc/hvn_conv_chain_x3r.hip's walk distinguishes (32-channel chunks: cout = 64 is two of them)
+    (2, 9, 10, 64, 64, 64, True, None, False, True),          # two chunks, ragged tail
+    (1, 31, 33, 64, 128, 128, True, None, True, True),        # block-closing BN-ReLU AND a pre-activation, cout2 = 128
+    (2, 12, 14, 64, 256, 64, False, (64, 2), False, True),    # fused shortcut sampled at stride 2
+    (1, 7, 5, 64, 64, 64, False, None, False, False),         # one partial tile, no optional operand at all
+]
+
+
+def _x3r_exists(case):
     n, h, w, k1, c, n2, res, x2, post, pre = case
+    return k1 == 64 and (x2 is None or (x2[0] == 64 and not res and n2 == 64))
+
+
+@pytest.mark.parametrize("terms", [6, 9])
+@pytest.mark.parametrize("form", ["x3", "x3r"])
+@pytest.mark.parametrize("case", CASES + X3R_CASES)
+def test_chain_on_the_bf16_pipe_matches_reference_and_unfused_bf16x3_launches(case, form, terms):
+    """csrc/hvn_conv_chain_x3.hip: the same op with both GEMMs' products on the bf16 matrix pipe (bf16x3 splits).  Against the torch
+    interpreter at the bf16x3 kernel's tolerance, and BIT-EQUAL to the two bf16x3 CONV launches it replaces.  form "x3r": the same
+    through csrc/hvn_conv_chain_x3r.hip (input tile resident in registers, operands a chunk ahead in flight; hvn_op.tile_n = X3R) where
+    that form exists -- and a refused launch where it does not."""
+    from hover_net_amd import lib as L
+    from hover_net_amd.engine import X3R
+
+    n, h, w, k1, c, n2, res, x2, post, pre = case
+    if form == "x3" and case in X3R_CASES and terms == 9:
+        pytest.skip("covered with six terms")
 
     def build(fuse):
         P, views = _two_convs(n, h, w, k1, c, n2, res=res, x2=x2, post=post, pre=pre, seed=7, inplace=not post)
@@ -125,8 +146,12 @@ def test_chain_on_the_bf16_pipe_matches_reference_and_unfused_bf16x3_launches(ca
 
     P, (t2, acc, out, t1) = build(True)
     assert [o.kind for o in P.ops] == [PL.OP_CHAIN] and P.ops[0].extra["x3"] == terms
-    eng, start = _run(P, n, seed=11)
-    assert eng.ops[0].act_dtype == (2 if terms == 9 else 3)
+    if form == "x3r" and not _x3r_exists(case):
+        with pytest.raises(L.HvnError):
+            _run(P, n, seed=11, bm=X3R)
+        return
+    eng, start = _run(P, n, seed=11, bm=X3R if form == "x3r" else 128)
+    assert eng.ops[0].act_dtype == (2 if terms == 9 else 3) and eng.ops[0].tile_n == (X3R if form == "x3r" else 128)
     got = eng.arena.cpu()
     A = plan_interp.Arena(P, n)
     A.flat.copy_(start)
@@ -161,18 +186,23 @@ def test_network_with_and_without_chains_is_bit_equal(monkeypatch):
     from hover_net_amd.synth import synth_state_dict, synth_tiles
 
     tiles = torch.from_numpy(synth_tiles(2, 270, seed=3)).cuda()
+    from hover_net_amd.engine import X3R
+
     outs = []
-    for chain in ("1", "0"):
+    for chain, x3r in (("1", "force"), ("1", "0"), ("0", "0")):     # chained seams on hvn_conv_chain_x3r.hip | hvn_conv_chain_x3.hip | two launches
         monkeypatch.setenv("HVN_CHAIN", chain)
+        monkeypatch.setenv("HVN_CHAIN_X3R", x3r)
         net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
         net.load_state_dict(synth_state_dict("original", 5, seed=2), strict=True)
         net = net.cuda().eval()
         eng = net.engine(2)
         assert any(o.kind == PL.OP_CHAIN for o in eng.plan.ops) == (chain == "1")
+        on_x3r = [i for i, o in enumerate(eng.plan.ops) if o.kind == PL.OP_CHAIN and eng.ops[i].tile_n == X3R]
+        assert (len(on_x3r) == 3) == (x3r == "force"), on_x3r          # d0's three seams all have the form
         logits, pred = eng.run(tiles)
         outs.append({k: v.clone() for k, v in logits.items()})
     for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k
 
 
 def test_network_with_and_without_upadd_fusion_is_bit_equal(monkeypatch):

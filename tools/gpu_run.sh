@@ -104,6 +104,17 @@ PY
     done
     timeout 900 python -m pytest tests/test_gpu_trained_like.py -q -s 2>&1 | grep -v "^$" | tail -25 >> $O
     ;;
+  chainx3r)   # round 5: the bf16x3 chain with a register-resident input tile (csrc/hvn_conv_chain_x3r.hip): bit-equality tests (under a
+              # short timeout: counted waits + raw barriers), then d0's per-launch rows and bench lines with the form off | forced | timed
+    timeout 600 python -m pytest tests/test_gpu_chain.py -q --tb=short -x 2>&1 | tail -15 >> $O
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for c in 0 force 1; do
+      f=gpurun_out/${R}_layers_x3r_$c.txt
+      HVN_CHAIN_X3R=$c timeout 300 python tools/layer_ms.py > $f 2>&1; echo "== HVN_CHAIN_X3R=$c: $(tail -1 $f)" >> $O
+      grep -E "\+" $f | head -6 >> $O
+    done
+    for c in 0 1; do ENVV=(HVN_CHAIN_X3R=$c); bench x3r_$c $Q; done
+    ;;
   wgradx3)    # round 5: weight gradients on the bf16 pipe (csrc/hvn_wgrad_x3.hip) + the LDS-DMA conv forms in the training step: kernel tests,
               # then the training step with / without them on one box
     timeout 900 python -m pytest tests/test_gpu_train.py -q --tb=line -k "wgrad" 2>&1 | tail -8 >> $O
