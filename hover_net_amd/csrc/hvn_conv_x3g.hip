@@ -34,6 +34,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+#ifndef HVN_X3G_RES_PREFETCH
+#define HVN_X3G_RES_PREFETCH 1     // (lib.py VARIANTS "nopf": 0, the A/B build)
+#endif
 #define GK 32               // reduction elements per k-step
 #define GBN 128             // output channels per workgroup
 #define G_BSTAGE (3 * GBN * 64)   // bytes of one B stage: [plane 3][row 128][64 B]
@@ -78,6 +81,9 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     constexpr int B_OFF = NA * A_STAGE;
     constexpr int PRE_OFF = B_OFF + 2 * G_BSTAGE;
     constexpr int EP_LD = GBN + 4;
+    // the prologue's per-channel vectors: parked in LDS where the rings leave room (one 256-row workgroup per CU), read from global
+    // memory a k-step ahead where they do not (two 128-row workgroups per CU fill the 160 KB exactly)
+    constexpr bool PRE_LDS = HAS_PRE && BM == 256, PRE_GLB = HAS_PRE && BM == 128;
     static_assert(GA == 4, "the counted s_waitcnt below leaves exactly one A stage (4 DMA instructions per wave) in flight");
     static_assert(NTERMS == 9 || NTERMS == 6, "nine exact partial products, or the six that carry > 2^-24 of the product");
     extern __shared__ __attribute__((aligned(16))) unsigned char gs[];
@@ -150,11 +156,80 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     }
 
     // ---- optional prologue vectors (pre-activation BN: relu(x * s + b) per input channel) parked in LDS once: [2][Cin] floats -------
-    if constexpr (HAS_PRE) {
+    if constexpr (PRE_LDS) {
         float *pre = (float *)(gs + PRE_OFF);
         for (int c = tid * 4; c < p.Cin; c += NTHR * 4) {
             *(f32x4 *)(pre + c) = *(const f32x4 *)(p.pre_s + c);
             *(f32x4 *)(pre + p.Cin + c) = *(const f32x4 *)(p.pre_b + c);
+        }
+    }
+
+    // PRE_GLB: scale / shift of the 8 channels this lane feeds an MFMA with, for both 16-deep slices of ONE k-step (32 VGPRs), requested
+    // at the top of the k-step before (ahead of that step's DMAs: vector-memory operations complete in issue order) and touched before
+    // its barrier, where everything outstanding is waited for anyway -- the compiler then knows them complete and adds no wait of its own
+    // behind the DMAs it cannot count on (they are conditional)
+    f32x4 pvs[2][2], pvb[2][2];
+    const __amdgpu_buffer_rsrc_t rsrc_ps = __builtin_amdgcn_make_buffer_rsrc((void *)(PRE_GLB ? p.pre_s : p.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_pb = __builtin_amdgcn_make_buffer_rsrc((void *)(PRE_GLB ? p.pre_b : p.x), 0, 0x7fffffff, 0x00020000);
+    auto load_pre = [&](int slab) {
+        if constexpr (PRE_GLB) {
+            const int so = __builtin_amdgcn_readfirstlane(slab * (GK * 4));
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    pvs[q][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_ps, (unsigned)(q * 64 + lh * 32 + h * 16), so, 0));
+                    pvb[q][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_pb, (unsigned)(q * 64 + lh * 32 + h * 16), so, 0));
+                }
+        }
+    };
+    auto touch_pre = [&]() {
+        if constexpr (PRE_GLB) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(pvs[q][h]), "+v"(pvb[q][h]));
+        }
+    };
+    load_pre(0);
+
+    // ---- epilogue coordinates (needed here for the residual prefetch): thread = one 16-byte column piece of rows erow0 + RPP it -------
+    constexpr int CH = GBN / 4;           // float4 chunks per row
+    constexpr int RPP = NTHR / CH;        // rows per pass
+    constexpr int NIT = BM / RPP;         // 16
+    const int ecol = (tid % CH) * 4;
+    const int erow0 = tid / CH;
+    const int co = n0 + ecol;
+    const bool cok = co < p.Cout;         // Cout is a multiple of 4 (validated on the host)
+    const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr;
+    // (the plain instantiation only: launches with a prologue, a fused shortcut or padding taps -- conv1 / unit-0 conv3 / conv2 -- have no
+    //  residual in this network, and their register budgets are tighter)
+    constexpr bool RESPF = HVN_X3G_RES_PREFETCH && !HAS_PRE && !HAS_X2 && !PADDED;
+    // The residual rows of the epilogue's FIRST half are requested now, next to the first operand stage (whose round trip the first
+    // barrier waits for anyway), and held in 32 VGPRs through the main loop: the epilogue of a short-K launch (a unit's conv3: 4 - 8
+    // k-steps) otherwise spends a full HBM round trip per half with nothing of its own to overlap it.  (A residual view that aliases y
+    // is safe: this workgroup alone writes these elements, in its epilogue.)
+    f32x4 rpre[NIT / 2];
+    if constexpr (RESPF) {
+        const unsigned HoWo_e = (unsigned)(p.Ho * p.Wo);
+        const unsigned m = m0 + erow0;
+        unsigned q_n = m / HoWo_e;
+        const unsigned rem = m - q_n * HoWo_e;
+        unsigned q_oy = rem / (unsigned)p.Wo, q_ox = rem - q_oy * (unsigned)p.Wo;
+#pragma unroll
+        for (int it = 0; it < NIT / 2; ++it) {
+            const unsigned mi = m0 + erow0 + it * RPP;
+            rpre[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (has_res && mi < M && cok) rpre[it] = *(const f32x4 *)(p.res + (long)q_n * p.rsn + (long)q_oy * p.rsy + (long)q_ox * p.rsx + co);
+            q_ox += RPP;
+            while (q_ox >= (unsigned)p.Wo) {
+                q_ox -= (unsigned)p.Wo;
+                ++q_oy;
+            }
+            while (q_oy >= (unsigned)p.Ho) {
+                q_oy -= (unsigned)p.Ho;
+                ++q_n;
+            }
         }
     }
 
@@ -232,9 +307,15 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
             for (int pl = 0; pl < 3; ++pl)
                 f.b[j][pl] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(bs + pl * (GBN * 64) + j * 32 * 64 + (((2 * q + lh) ^ bkey) << 4)));
         if constexpr (HAS_PRE) {
-            const float *pre = (const float *)(gs + PRE_OFF) + c_slab * GK + q * 16 + lh * 8;
-            const f32x4 ps0 = *(const f32x4 *)(pre), ps1 = *(const f32x4 *)(pre + 4);
-            const f32x4 pb0 = *(const f32x4 *)(pre + p.Cin), pb1 = *(const f32x4 *)(pre + p.Cin + 4);
+            f32x4 ps0, ps1, pb0, pb1;
+            if constexpr (PRE_LDS) {
+                const float *pre = (const float *)(gs + PRE_OFF) + c_slab * GK + q * 16 + lh * 8;
+                ps0 = *(const f32x4 *)(pre), ps1 = *(const f32x4 *)(pre + 4);
+                pb0 = *(const f32x4 *)(pre + p.Cin), pb1 = *(const f32x4 *)(pre + p.Cin + 4);
+            } else {
+                ps0 = pvs[q][0], ps1 = pvs[q][1];
+                pb0 = pvb[q][0], pb1 = pvb[q][1];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 v0[i].x = fmaxf(fmaf(v0[i].x, ps0.x, pb0.x), 0.f);
@@ -275,7 +356,8 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     // issue order the scheduler is asked for inside a phase: the slice's LDS reads first, then one MFMA : five VALU -- the next slice's
     // split runs in the shadow of this slice's matrix work
     auto interleave = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x100, HAS_PRE ? 14 : 10, 0);
+        if constexpr (PRE_GLB) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);      // the next k-step's prologue vectors (first phase only)
+        __builtin_amdgcn_sched_group_barrier(0x100, PRE_LDS ? 14 : 10, 0);
 #pragma unroll
         for (int g = 0; g < NM; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -292,6 +374,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     //      covers it (hipcc moves a value that is only used behind the loop's back edge to the head of the next iteration).
     issue_b(0);
     issue_a(0);
+    touch_pre();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // + the prologue vectors' ds_writes
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -308,11 +391,13 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
         constexpr bool LAST = decltype(last_tag)::value;
         __builtin_amdgcn_sched_barrier(0);
         prep(f1, kt, 1, c_slab);
+        if constexpr (!LAST) load_pre(c_tap + 1 == taps ? c_slab + 1 : c_slab);      // the next k-step's vectors (this one's are consumed)
         mma(f0, 4, NM);
         mma(f1, 0, 4);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LAST) {
+            touch_pre();
             // (lgkmcnt(0): this wave's reads of stage kt have RETURNED before any wave may restage its slots)
             if (NA == 3 && kt + 2 < KT)
                 asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -351,15 +436,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
                 ep[row * EP_LD + wn * 64 + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
-    constexpr int CH = GBN / 4;           // float4 chunks per row
-    constexpr int RPP = NTHR / CH;        // rows per pass
-    constexpr int NIT = BM / RPP;         // 16
-    const int ecol = (tid % CH) * 4;
-    const int erow0 = tid / CH;
-    const int co = n0 + ecol;
-    const bool cok = co < p.Cout;         // Cout is a multiple of 4 (validated on the host)
     f32x4 bias = {0.f, 0.f, 0.f, 0.f}, qs = {1.f, 1.f, 1.f, 1.f}, qb = bias;
-    const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr;
     if (cok) {
         if (p.bias) bias = *(const f32x4 *)(p.bias + co);
         if (has_post) {
@@ -389,7 +466,9 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
             const unsigned m = m0 + erow0 + (half * HN + it) * RPP;
             oks[it] = m < M && cok;
             rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
+            if (RESPF && half == 0)
+                rall[it] = rpre[it];
+            else if (has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
             yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
             e_ox += RPP;
             while (e_ox >= (unsigned)p.Wo) {
@@ -432,7 +511,7 @@ static int launch_x3g(const ConvArgs &a, hipStream_t stream)
     p.m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = (p.Cout + GBN - 1) / GBN;
     constexpr int NA = BM == 256 ? 3 : 2;
-    const size_t stage_b = (size_t)NA * BM * 128 + 2 * G_BSTAGE + (HAS_PRE ? (size_t)2 * a.Cin * 4 : 0), ep_b = (size_t)BM * (GBN + 4) * 4;
+    const size_t stage_b = (size_t)NA * BM * 128 + 2 * G_BSTAGE + (HAS_PRE && BM == 256 ? (size_t)2 * a.Cin * 4 : 0), ep_b = (size_t)BM * (GBN + 4) * 4;
     const size_t lds = stage_b > ep_b ? stage_b : ep_b;
     if (lds > 160 * 1024) return -1;
     static std::atomic<unsigned long long> attr_done{0};
@@ -458,7 +537,7 @@ int hvn_conv_x3g_supported(const ConvArgs &a, int bm)
 {
     if (bm != 256 && bm != 128) return 0;
     if (a.Cout < 128 || a.groups > 1) return 0;
-    if (a.pre_s && ((size_t)(bm == 256 ? 3 : 2) * bm * 128 + 2 * G_BSTAGE + (size_t)2 * a.Cin * 4 > 160 * 1024)) return 0;
+    if (a.pre_s && bm == 256 && ((size_t)3 * bm * 128 + 2 * G_BSTAGE + (size_t)2 * a.Cin * 4 > 160 * 1024)) return 0;
     return 1;
 }
 

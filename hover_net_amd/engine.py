@@ -63,8 +63,8 @@ X3R = 128 + 0x400                               # hvn_op.tile_n of the bf16x3 CH
 
 def x3g_forms_for(op):
     """The LDS-DMA workgroup shapes (csrc/hvn_conv_x3g.hip) a bf16x3 CONV launch may run on besides hvn_conv_x3.hip's, as tile_n codes:
-    they need >= 128 output channels and, with a prologue, its two per-channel vectors next to the operand rings in the CU's 160 KB of
-    LDS.  Same packing, same bits (tests/test_gpu_x3.py): which one runs is a timing decision (`Engine.autotune_tiles`).  HVN_X3G=0
+    they need >= 128 output channels and -- the 256-row form with a prologue -- its two per-channel vectors next to the operand rings
+    in the CU's 160 KB of LDS.  Same packing, same bits (tests/test_gpu_x3.py): which one runs is a timing decision (`Engine.autotune_tiles`).  HVN_X3G=0
     keeps hvn_conv_x3.hip everywhere; HVN_X3G=896 | 640 offers one form only."""
     import os
 
@@ -76,8 +76,8 @@ def x3g_forms_for(op):
     for code, bm, na in ((X3G_256, 256, 3), (X3G_128, 128, 2)):
         if want not in ("1", str(code)):
             continue
-        if op.pre is not None and na * bm * 128 + 2 * 3 * 128 * 64 + 2 * cin * 4 > 160 * 1024:
-            continue
+        if op.pre is not None and bm == 256 and na * bm * 128 + 2 * 3 * 128 * 64 + 2 * cin * 4 > 160 * 1024:
+            continue                                   # (the 128-row form reads the prologue's vectors from global memory)
         forms.append(code)
     return tuple(forms)
 

@@ -111,7 +111,7 @@ X3R_CASES = [  # + shapes only csrc/hvn_conv_chain_x3r.hip's walk distinguishes 
     (2, 9, 10, 64, 64, 64, True, None, False, True),          # two chunks, ragged tail
     (1, 31, 33, 64, 128, 128, True, None, True, True),        # block-closing BN-ReLU AND a pre-activation, cout2 = 128
     (2, 12, 14, 64, 256, 64, False, (64, 2), False, True),    # fused shortcut sampled at stride 2
-    (1, 7, 5, 64, 64, 64, False, None, False, False),         # one partial tile, no optional operand at all
+    (1, 7, 5, 64, 64, 64, True, None, False, False),          # one partial tile; neither BN-ReLU
 ]
 
 

@@ -163,6 +163,8 @@ X3G_CASES = {
     "res_inplace": dict(n=1, xbuf_shape=(20, 20, 64), xview=(0, 0, 20, 20, 0, 64), ybuf_shape=(20, 20, 128), yview=(0, 0, 20, 20, 0, 128), w=(128, 64, 1), res=True, inplace_res=True),
     "prologue_1024_256": dict(n=2, xbuf_shape=(17, 17, 1024), xview=(0, 0, 17, 17, 0, 1024), ybuf_shape=(17, 17, 256), yview=(0, 0, 17, 17, 0, 256), w=(256, 1024, 1), pre=True, bn=True, relu=1),
     "prologue_2048_512": dict(n=1, xbuf_shape=(12, 12, 2048), xview=(0, 0, 12, 12, 0, 2048), ybuf_shape=(12, 12, 512), yview=(0, 0, 12, 12, 0, 512), w=(512, 2048, 1), pre=True, bn=True, relu=1),
+    "prologue_3x3_valid": dict(n=2, xbuf_shape=(12, 12, 256), xview=(0, 0, 12, 12, 0, 256), ybuf_shape=(10, 10, 128), yview=(0, 0, 10, 10, 0, 128), w=(128, 256, 3), pre=True, bn=True, relu=1),
+    "prologue_res_96_128": dict(n=3, xbuf_shape=(11, 11, 96), xview=(0, 0, 11, 11, 0, 96), ybuf_shape=(11, 11, 128), yview=(0, 0, 11, 11, 0, 128), w=(128, 96, 1), pre=True, res=True),
     "1x1_stride2": dict(n=2, xbuf_shape=(24, 24, 256), xview=(0, 0, 24, 24, 0, 256), ybuf_shape=(12, 12, 512), yview=(0, 0, 12, 12, 0, 512), w=(512, 256, 1), stride=2),
     "3x3_same": dict(n=2, xbuf_shape=(18, 18, 128), xview=(0, 0, 18, 18, 0, 128), ybuf_shape=(18, 18, 128), yview=(0, 0, 18, 18, 0, 128), w=(128, 128, 3), pad=(1, 1), bn=True, relu=1),
     "3x3_same_stride2": dict(n=2, xbuf_shape=(18, 18, 128), xview=(0, 0, 18, 18, 0, 128), ybuf_shape=(9, 9, 128), yview=(0, 0, 9, 9, 0, 128), w=(128, 128, 3), stride=2, pad=(0, 1), bn=True, relu=1),
