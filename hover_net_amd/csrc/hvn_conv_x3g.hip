@@ -20,7 +20,7 @@
 //
 // Workgroups: BM = 256 pixels x 128 channels, 512 threads (8 waves as 4 x 2, one per CU: A ring of 3 x 32 KB + B ring of 2 x 24 KB = 144 KB
 // of the CU's 160 KB; + the prologue's per-channel vectors for K <= 2048), or BM = 128, 256 threads (4 waves as 2 x 2, two per CU: rings of
-// two = exactly 80 KB).  Reference geometry as hvn_conv_x3.hip: /root/reference/models/hovernet/net_utils.py:155-266, net_desc.py:76-99.
+// two = exactly 80 KB; the prologue's vectors then come from global memory, a k-step ahead, 32 VGPRs).  Reference geometry as hvn_conv_x3.hip: /root/reference/models/hovernet/net_utils.py:155-266, net_desc.py:76-99.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,9 +34,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-#ifndef HVN_X3G_RES_PREFETCH
-#define HVN_X3G_RES_PREFETCH 1     // (lib.py VARIANTS "nopf": 0, the A/B build)
-#endif
 #define GK 32               // reduction elements per k-step
 #define GBN 128             // output channels per workgroup
 #define G_BSTAGE (3 * GBN * 64)   // bytes of one B stage: [plane 3][row 128][64 B]
@@ -193,7 +190,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     };
     load_pre(0);
 
-    // ---- epilogue coordinates (needed here for the residual prefetch): thread = one 16-byte column piece of rows erow0 + RPP it -------
+    // ---- epilogue coordinates: thread = one 16-byte column piece of rows erow0 + RPP it -------------------------------------------
     constexpr int CH = GBN / 4;           // float4 chunks per row
     constexpr int RPP = NTHR / CH;        // rows per pass
     constexpr int NIT = BM / RPP;         // 16
@@ -202,36 +199,6 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     const int co = n0 + ecol;
     const bool cok = co < p.Cout;         // Cout is a multiple of 4 (validated on the host)
     const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr;
-    // (the plain instantiation only: launches with a prologue, a fused shortcut or padding taps -- conv1 / unit-0 conv3 / conv2 -- have no
-    //  residual in this network, and their register budgets are tighter)
-    constexpr bool RESPF = HVN_X3G_RES_PREFETCH && !HAS_PRE && !HAS_X2 && !PADDED;
-    // The residual rows of the epilogue's FIRST half are requested now, next to the first operand stage (whose round trip the first
-    // barrier waits for anyway), and held in 32 VGPRs through the main loop: the epilogue of a short-K launch (a unit's conv3: 4 - 8
-    // k-steps) otherwise spends a full HBM round trip per half with nothing of its own to overlap it.  (A residual view that aliases y
-    // is safe: this workgroup alone writes these elements, in its epilogue.)
-    f32x4 rpre[NIT / 2];
-    if constexpr (RESPF) {
-        const unsigned HoWo_e = (unsigned)(p.Ho * p.Wo);
-        const unsigned m = m0 + erow0;
-        unsigned q_n = m / HoWo_e;
-        const unsigned rem = m - q_n * HoWo_e;
-        unsigned q_oy = rem / (unsigned)p.Wo, q_ox = rem - q_oy * (unsigned)p.Wo;
-#pragma unroll
-        for (int it = 0; it < NIT / 2; ++it) {
-            const unsigned mi = m0 + erow0 + it * RPP;
-            rpre[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (has_res && mi < M && cok) rpre[it] = *(const f32x4 *)(p.res + (long)q_n * p.rsn + (long)q_oy * p.rsy + (long)q_ox * p.rsx + co);
-            q_ox += RPP;
-            while (q_ox >= (unsigned)p.Wo) {
-                q_ox -= (unsigned)p.Wo;
-                ++q_oy;
-            }
-            while (q_oy >= (unsigned)p.Ho) {
-                q_oy -= (unsigned)p.Ho;
-                ++q_n;
-            }
-        }
-    }
 
     int ld_r = 0, ld_s = 0, ld_c = 0;  // tap row / col / channel slab of the NEXT A stage to issue
     auto issue_a = [&](int kt) {
@@ -466,9 +433,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
             const unsigned m = m0 + erow0 + (half * HN + it) * RPP;
             oks[it] = m < M && cok;
             rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (RESPF && half == 0)
-                rall[it] = rpre[it];
-            else if (has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
+            if (has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
             yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
             e_ox += RPP;
             while (e_ox >= (unsigned)p.Wo) {

@@ -13,7 +13,6 @@ VARIANTS = {
     "lin": ("-DHVN_EPI_LINEAR=1",),                 # prepared, NOT yet measured: branch-free epilogue addressing for row-contiguous views
     "nt": ("-DHVN_NT=1",),                          # prepared, NOT yet measured: non-temporal hints on the epilogue's residual loads / stores
     "lin_nt": ("-DHVN_EPI_LINEAR=1", "-DHVN_NT=1"),
-    "nopf": ("-DHVN_X3G_RES_PREFETCH=0",),          # A/B: hvn_conv_x3g.hip without the early request of the epilogue's first residual rows
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")

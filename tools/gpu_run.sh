@@ -115,16 +115,6 @@ PY
     done
     for c in 0 1; do ENVV=(HVN_CHAIN_X3R=$c); bench x3r_$c $Q; done
     ;;
-  x3gpf)      # round 5: hvn_conv_x3g.hip with the prologue's vectors from global memory on the 128-row form (so it keeps two workgroups per
-              # CU) and the epilogue's first residual rows requested at kernel start; A/B of the latter against the "nopf" build on one box
-    timeout 900 python -m pytest tests/test_gpu_x3.py tests/test_gpu_chain.py -q --tb=short -x 2>&1 | tail -12 >> $O
-    for v in nopf ""; do
-      f=gpurun_out/${R}_layers_x3gpf_${v:-default}.txt
-      HVN_LIB_VARIANT=$v timeout 300 python tools/layer_ms.py > $f 2>&1; echo "== HVN_LIB_VARIANT=$v: $(tail -1 $f)" >> $O
-    done
-    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
-    for v in nopf ""; do ENVV=(HVN_LIB_VARIANT=$v); bench x3gpf_${v:-default} $Q; done
-    ;;
   wgradx3)    # round 5: weight gradients on the bf16 pipe (csrc/hvn_wgrad_x3.hip) + the LDS-DMA conv forms in the training step: kernel tests,
               # then the training step with / without them on one box
     timeout 900 python -m pytest tests/test_gpu_train.py -q --tb=line -k "wgrad" 2>&1 | tail -8 >> $O
