@@ -12,10 +12,8 @@
 //   * the weight chunks (W1: 32 output channels x all k-steps; W1': the matching k-step of the second GEMM, double-buffered) arrive by
 //     LDS-DMA (`buffer_load_dwordx4 ... lds`, source-side XOR swizzle: hvn_conv_x3g.hip), issued a whole chunk ahead;
 //   * the residual chunk is loaded a whole chunk ahead into registers (16 VGPRs at 32 channels per chunk);
-//   * a wave owns the same 32 pixels in both GEMMs, so the fp32 tile between them (accumulators -> epilogue -> GEMM 2's A operand) is a
-//     layout exchange WITHIN the wave: LDS executes a wave's operations in order, no barrier.  The two barriers per chunk that remain
-//     guard the shared weight buffers only; they are raw s_barrier with COUNTED s_waitcnt -- nothing younger than what a phase needs
-//     is waited for, so the residual stream and the y stores stay in flight across them (hvn_conv_chain_x3: seven __syncthreads).
+//   * barriers are raw s_barrier with COUNTED s_waitcnt: nothing younger than what a phase needs is waited for, so the residual stream
+//     and the y stores stay in flight across all of them.  Three barriers per chunk.
 // Chunks are 32 channels of conv3's output (hvn_conv_chain_x3: 64): the epilogue / GEMM2-A tile is [128][32] floats (16 KB, 16-byte
 // pieces XOR-swizzled like hvn_conv_x3g.hip's activation rows), LDS 52 - 76 KB, two workgroups per CU.
 // Every output element sums the partial products hvn_conv_igemm_x3 would sum, in its order (k-steps ascending, then the partial
@@ -96,8 +94,10 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
     constexpr int W1_OFF = EP_BYTES, W2_OFF = W1_OFF + W1_BYTES;
     constexpr int D1 = W1_BYTES / 4096, D2 = W2_BYTES / 4096;   // LDS-DMA instructions (1 KiB) per wave and chunk: 3 | 6
     constexpr int IPP2 = N2 / 16;                     // DMA instructions per W1' plane
-    constexpr int TN2 = N2 / 32;                      // GEMM 2: a wave owns the SAME 32 pixels as in GEMM 1, all N2 columns (2 | 4 accumulators)
-    constexpr int NIT = 4;                            // epilogue passes of a wave over its 32 rows: 8 rows x 8 pieces of 16 B per pass
+    constexpr int WAVES_M2 = N2 == 128 ? 2 : 4, WAVES_N2 = 4 / WAVES_M2;
+    constexpr int WM2 = BM / WAVES_M2, WN2 = N2 / WAVES_N2;
+    constexpr int TM2 = WM2 / 32, TN2 = WN2 / 32;     // 1 x 2 | 2 x 2
+    constexpr int NIT = BM / 32;                      // epilogue passes: 32 rows x 8 pieces of 16 B per pass
     constexpr bool RES = !HAS_X2;                     // a fused shortcut takes the residual's place (validated by the launcher)
     constexpr unsigned OOB = 0x80000000u;
     static_assert(NTERMS == 9 || NTERMS == 6, "nine exact partial products, or the six that carry > 2^-24 of the product");
@@ -191,19 +191,15 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
         }
     }
 
-    // ---- epilogue coordinates.  A wave finishes ITS OWN 32 rows (the rows it produced in GEMM 1 and consumes in GEMM 2): the tile is a
-    //      layout exchange within the wave -- LDS executes a wave's operations in order, so no barrier stands between the accumulator
-    //      store, the epilogue and GEMM 2.  lane = (16-byte column piece lane & 7, rows (lane >> 3) + 8 it); tile slot of (row, piece) =
-    //      piece ^ ((row >> 1) & 7), and (row >> 1) & 7 = (lane >> 4) + 4 (it & 1) --------------------------------------------------------
-    const int ecol = (lane & 7) * 4;
-    const int erow0 = wave * 32 + (lane >> 3);
-    int e_off[2];                                     // floats, by the parity of `it`; + 8 it rows
-#pragma unroll
-    for (int par = 0; par < 2; ++par) e_off[par] = erow0 * CB + (((lane & 7) ^ ((lane >> 4) + 4 * par)) << 2);
+    // ---- epilogue coordinates: thread = (16-byte column piece tid & 7, rows (tid >> 3) + 32 it); tile slot of (row, piece) =
+    //      piece ^ ((row >> 1) & 7) -- the key does not depend on `it` -----------------------------------------------------------
+    const int ecol = (tid & 7) * 4;
+    const int erow0 = tid >> 3;
+    const int e_off = erow0 * CB + (((tid & 7) ^ ((erow0 >> 1) & 7)) << 2);     // floats; + 32 it rows
     unsigned y_voff[NIT];      // the residual view has the output's strides (validated by the launcher): same offsets, other base
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const unsigned m = m0 + erow0 + 8 * it;
+        const unsigned m = m0 + erow0 + 32 * it;
         const bool ok = m < M;
         const unsigned mm = ok ? m : m0;
         const unsigned n = mm / HoWo;
@@ -221,12 +217,15 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
 #pragma unroll
     for (int s = 0; s < NS; ++s) cr_split(raw[s][0], raw[s][1], fa[s][0], fa[s][1], fa[s][2]);
 
-    f32x16 acc2[TN2];
+    f32x16 acc2[TM2][TN2];
 #pragma unroll
-    for (int j = 0; j < TN2; ++j)
+    for (int i = 0; i < TM2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
     const int akey = (l31 >> 1) & 7, bkey = (l31 >> 2) & 3;
+    const int wm2 = wave / WAVES_N2, wn2 = wave % WAVES_N2;
 
     // the partial products of one 16-deep slice with a-plane + b-plane = s, for one accumulator, smallest first (hvn_conv_igemm_x3's order)
     auto mac = [&](f32x16 &acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3], int s) {
@@ -270,13 +269,13 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
                 mac(acc1, fa[s], fb, t);
             }
         }
-        // accumulators -> this wave's rows of the tile (its own reads of them, in the previous chunk's GEMM 2, are older LDS operations)
+        // accumulators -> tile (free since the barrier behind the previous chunk's GEMM 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             ep[row * CB + (((l31 >> 2) ^ ((row >> 1) & 7)) << 2) + (l31 & 3)] = acc1[r];
         }
-        CR_BARRIER_LDS();              // every wave is done with this chunk's W1 planes (and, since the last barrier, with W1' stage (c + 1) & 1)
+        CR_BARRIER_LDS();              // tile visible; every wave is done with this chunk's W1 planes (and with W1' stage (c + 1) & 1)
         if constexpr (!LAST) issue_w(c + 1);
         qs = has_post ? qs : ones;
         ps = has_pre ? ps : ones;
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
             f32x4 vout[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                float *e = ep + e_off[it & 1] + 8 * it * CB;
+                float *e = ep + e_off + 32 * it * CB;
                 f32x4 v = *(const f32x4 *)e;
                 v += rres[it];
                 v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
@@ -307,49 +306,52 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
                 for (int it = 0; it < NIT; ++it) rres[it] = cr_load(rsrc_r, y_voff[it], csoff + CB * 4);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);     // (keeps GEMM 2's fragment reads out of the epilogue's register budget)
-        // ---- GEMM 2: k-step c of t1' += act(y chunk) W1'^T; A = this wave's rows of the tile (fp32, split at the fragment read: once per
-        //      16-deep slice, for all N2 columns), B = W1' stage c & 1, one 32-column block at a time (per accumulator the order is (q, term)) --
+        CR_BARRIER_LDS();              // the activated tile is visible
+        // ---- GEMM 2: k-step c of t1' += act(y chunk) W1'^T; A = the tile (fp32, split at the fragment read), B = W1' stage c & 1 -----
         {
-            const float *a = ep + (wave * 32 + l31) * CB;
-            const unsigned char *b = cs + W2_OFF + (c & 1) * W2_BYTES + l31 * 64;
+            const float *a = ep + (wm2 * WM2 + l31) * CB;
+            const unsigned char *b = cs + W2_OFF + (c & 1) * W2_BYTES + (wn2 * WN2 + l31) * 64;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                bf16x8 fa2[3];
-                const f32x4 v0 = *(const f32x4 *)(a + (((4 * q + 2 * lh) ^ akey) << 2));
-                const f32x4 v1 = *(const f32x4 *)(a + (((4 * q + 2 * lh + 1) ^ akey) << 2));
-                cr_split(v0, v1, fa2[0], fa2[1], fa2[2]);
+                bf16x8 fa2[TM2][3], fb2[TN2][3];
 #pragma unroll
-                for (int j = 0; j < TN2; ++j) {
-                    bf16x8 fb2[3];
+                for (int i = 0; i < TM2; ++i) {
+                    const f32x4 v0 = *(const f32x4 *)(a + i * 32 * CB + (((4 * q + 2 * lh) ^ akey) << 2));
+                    const f32x4 v1 = *(const f32x4 *)(a + i * 32 * CB + (((4 * q + 2 * lh + 1) ^ akey) << 2));
+                    cr_split(v0, v1, fa2[i][0], fa2[i][1], fa2[i][2]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN2; ++j)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        fb2[pl] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + pl * (N2 * 64) + j * 32 * 64 + (((2 * q + lh) ^ bkey) << 4)));
+                        fb2[j][pl] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + pl * (N2 * 64) + j * 32 * 64 + (((2 * q + lh) ^ bkey) << 4)));
 #pragma unroll
-                    for (int t = 4; t >= 0; --t) {
-                        if (NTERMS == 6 && t > 2) continue;
-                        mac(acc2[j], fa2, fb2, t);
-                    }
+                for (int t = 4; t >= 0; --t) {
+                    if (NTERMS == 6 && t > 2) continue;
+#pragma unroll
+                    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN2; ++j) mac(acc2[i][j], fa2[i], fb2[j], t);
                 }
             }
         }
-        // every wave is done with W1' stage c & 1; the next chunk's weights (issued behind the barrier after GEMM 1) have landed: younger
-        // than them are this chunk's 4 y stores and, if any, the 4 residual loads of the next chunk
-        if constexpr (!LAST) {
-            if constexpr (RES)
-                CR_BARRIER(8);
-            else
-                CR_BARRIER(4);
-        }
+        // every wave is done with the tile and with W1' stage c & 1; the next chunk's weights (issued behind the barrier after GEMM 1)
+        // have landed: younger than them are this chunk's 4 y stores and, if any, the 4 residual loads of the next chunk
+        if constexpr (LAST)
+            CR_BARRIER_LDS();
+        else if constexpr (RES)
+            CR_BARRIER(8);
+        else
+            CR_BARRIER(4);
     };
     for (int c = 0; c + 1 < NC; ++c) chunk(c, std::false_type{});
     chunk(NC - 1, std::true_type{});
 
-    // ---- epilogue 2: t1' = relu(acc2 + b2), 32 output channels at a time through this wave's rows of the tile (no barrier: see above) -----
+    // ---- epilogue 2: t1' = relu(acc2 + b2), 32 output channels at a time through the tile ----------------------------------------
     unsigned y2_voff[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const unsigned m = m0 + erow0 + 8 * it;
+        const unsigned m = m0 + erow0 + 32 * it;
         const bool ok = m < M;
         const unsigned mm = ok ? m : m0;
         const unsigned n = mm / HoWo;
@@ -360,18 +362,26 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
     const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y2 + (long)n_blk * p.y2sn), 0, 0x7fffffff, 0x00020000);
     const float relu_lo = p.relu2 ? 0.f : -__builtin_inff();
 #pragma unroll
-    for (int j = 0; j < TN2; ++j) {
+    for (int h = 0; h < N2 / 32; ++h) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            ep[row * CB + (((l31 >> 2) ^ ((row >> 1) & 7)) << 2) + (l31 & 3)] = acc2[j][r];
+        for (int j = 0; j < TN2; ++j) {
+            if ((wn2 * WN2 + j * 32) / 32 == h) {       // this wave's 32-column tile j is the group being written out
+#pragma unroll
+                for (int i = 0; i < TM2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm2 * WM2 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        ep[row * CB + (((l31 >> 2) ^ ((row >> 1) & 7)) << 2) + (l31 & 3)] = acc2[i][j][r];
+                    }
+            }
         }
+        CR_BARRIER_LDS();
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias2) bias = *(const f32x4 *)(p.bias2 + j * 32 + ecol);
+        if (p.bias2) bias = *(const f32x4 *)(p.bias2 + h * 32 + ecol);
         f32x4 vout[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            f32x4 v = *(const f32x4 *)(ep + e_off[it & 1] + 8 * it * CB);
+            f32x4 v = *(const f32x4 *)(ep + e_off + 32 * it * CB);
             v.x = fmaxf(v.x + bias.x, relu_lo);
             v.y = fmaxf(v.y + bias.y, relu_lo);
             v.z = fmaxf(v.z + bias.z, relu_lo);
@@ -379,7 +389,8 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_x3r(const ChainArgs p)
             vout[it] = v;
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) cr_store(vout[it], rsrc_y2, y2_voff[it], j * 128);
+        for (int it = 0; it < NIT; ++it) cr_store(vout[it], rsrc_y2, y2_voff[it], h * 128);
+        if (h + 1 < N2 / 32) CR_BARRIER_LDS();
     }
 }
 
