@@ -215,7 +215,6 @@ struct BnArgs {
     float *dgamma, *dbeta, *running_mean, *running_var;
     int N, H, W, C, lq, nparts;
     float eps, momentum;
-    int slot;             // set by the launcher: which row of the library's ticket table this launch counts its workgroups in
 };
 int hvn_launch_bn_forward(BnArgs a, hipStream_t stream);
 int hvn_launch_bn_backward(BnArgs a, hipStream_t stream);

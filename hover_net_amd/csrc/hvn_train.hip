@@ -510,20 +510,10 @@ int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, 
 // g = da * (a > 0), xhat = (z - mean) * rstd.  A thread owns one channel quad (LQ lanes per row, 256/LQ rows per
 // block pass), accumulates in double (8 rows in flight), the block combines through LDS and writes one partial per
 // (row block, channel) to ws[block][2*c + {0,1}]; the finalize kernels sum the partials in a fixed order.
-// The finalize step (sum of the row-block partials per channel -> scale / shift / running statistics, or the backward coefficients)
-// runs in the LAST workgroup of each column of the reduce grid to finish (a ticket per column, counted with a device-scope atomic behind
-// a fence; the table lives in the library, is all zero between launches and is left all zero).  It used to be a launch of its own
-// between the reduce and the apply launch: ~12 us of dispatch latency for ~2 us of work, 213 times per training step.
-#define HVN_BN_SLOTS 64
-#define HVN_BN_COLS 64
-__device__ unsigned g_bn_ticket[HVN_BN_SLOTS * HVN_BN_COLS];
-__device__ void bn_finalize_column(const BnArgs &p, int mode, int c0, int c1);
-
 template <int MODE>
 __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
 {
     __shared__ double red[256][8];
-    __shared__ int s_last;
     const int LQ = p.lq;
     const int q = blockIdx.x * LQ + (threadIdx.x % LQ);
     const int rsub = threadIdx.x / LQ, rper = 256 / LQ;
@@ -590,42 +580,26 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
             part[2 * (q * 4 + e)] = s[e];
             part[2 * (q * 4 + e) + 1] = s[4 + e];
         }
-        __threadfence();                       // this thread's partials are visible device-wide before its workgroup takes a ticket
     }
-    if (p.slot < 0) return;                    // (a grid too wide for the ticket table: the finalize kernels run as launches of their own)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(&g_bn_ticket[p.slot * HVN_BN_COLS + blockIdx.x], 1u);
-        s_last = t == gridDim.y - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    bn_finalize_column(p, MODE, blockIdx.x * LQ * 4, min(p.C, (int)(blockIdx.x + 1) * LQ * 4));
-    if (threadIdx.x == 0) g_bn_ticket[p.slot * HVN_BN_COLS + blockIdx.x] = 0;
 }
 
 // Sum of the row-block partials of channel c: 8 lanes per channel read interleaved partials, LDS combine.
 // Block = 32 channels x 8 part-lanes; returns the totals to part-lane 0.
-__device__ inline bool bn_part_sums(const BnArgs &p, int cbase, int cend, double &s1, double &s2, int &c)
+__device__ inline bool bn_part_sums(const BnArgs &p, double &s1, double &s2, int &c)
 {
     __shared__ double red[256][2];
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    c = cbase + cl;
+    c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    if (c < cend)
-        // (plain loads: when this runs in the reduce launch's last workgroup the partials were written by other workgroups of the SAME
-        //  launch -- behind their fences and this workgroup's, and never read on this CU before, so not in its L1; eight in flight)
-#pragma unroll 4
+    if (c < p.C)
         for (int k = pl; k < p.nparts; k += 8) {
             a += p.ws[(long)k * 2 * p.C + 2 * c];
             b += p.ws[(long)k * 2 * p.C + 2 * c + 1];
         }
-    __syncthreads();                             // (the previous group's readers are done with `red`)
     red[threadIdx.x][0] = a;
     red[threadIdx.x][1] = b;
     __syncthreads();
-    if (pl != 0 || c >= cend) return false;
+    if (pl != 0 || c >= p.C) return false;
     for (int k = 1; k < 8; ++k) {
         a += red[cl + 32 * k][0];
         b += red[cl + 32 * k][1];
@@ -636,11 +610,11 @@ __device__ inline bool bn_part_sums(const BnArgs &p, int cbase, int cend, double
 }
 
 // forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; running stats (momentum, unbiased var)
-__device__ inline void bn_final_channels(const BnArgs &p, int cbase, int cend)
+__global__ __launch_bounds__(256) void hvn_bn_final(const BnArgs p)
 {
     double s1, s2;
     int c;
-    if (!bn_part_sums(p, cbase, cend, s1, s2, c)) return;
+    if (!bn_part_sums(p, s1, s2, c)) return;
     const double n = (double)p.N * p.H * p.W;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
@@ -656,32 +630,18 @@ __device__ inline void bn_final_channels(const BnArgs &p, int cbase, int cend)
     p.running_var[c] = (1.f - mom) * p.running_var[c] + mom * (float)(var * n / (n - 1.0));
 }
 
-__global__ __launch_bounds__(256) void hvn_bn_final(const BnArgs p) { bn_final_channels(p, blockIdx.x * 32, min(p.C, (int)blockIdx.x * 32 + 32)); }
-
 // backward finalize: dgamma += sum g*xhat, dbeta += sum g; coefficients of the dz formula
-__device__ inline void bn_bwd_final_channels(const BnArgs &p, int cbase, int cend)
+__global__ __launch_bounds__(256) void hvn_bn_bwd_final(const BnArgs p)
 {
     double s1, s2;
     int c;
-    if (!bn_part_sums(p, cbase, cend, s1, s2, c)) return;
+    if (!bn_part_sums(p, s1, s2, c)) return;
     const double n = (double)p.N * p.H * p.W;
     p.dgamma[c] += (float)s2;
     p.dbeta[c] += (float)s1;
     p.coef[c] = p.gamma[c] * p.save[3 * p.C + c];
     p.coef[p.C + c] = (float)(s1 / n);
     p.coef[2 * p.C + c] = (float)(s2 / n);
-}
-__global__ __launch_bounds__(256) void hvn_bn_bwd_final(const BnArgs p) { bn_bwd_final_channels(p, blockIdx.x * 32, min(p.C, (int)blockIdx.x * 32 + 32)); }
-
-// the channels [c0, c1) of one reduce-grid column, 32 at a time, by one whole workgroup (every thread takes every barrier)
-__device__ void bn_finalize_column(const BnArgs &p, int mode, int c0, int c1)
-{
-    for (int cb = c0; cb < c1; cb += 32) {
-        if (mode == 0)
-            bn_final_channels(p, cb, min(c1, cb + 32));
-        else
-            bn_bwd_final_channels(p, cb, min(c1, cb + 32));
-    }
 }
 
 // MODE 0: a = relu(z*scale + shift).  MODE 1: dz += c1 * (g - c2 - xhat*c3).
@@ -740,10 +700,6 @@ static void bn_grid(BnArgs &a, dim3 &grid)
     a.lq = lq;
     a.nparts = (int)gy;
     grid = dim3((unsigned)gx, (unsigned)gy);
-    // a row of the ticket table per launch, round robin: launches on different streams that overlap in time count in different rows
-    static std::atomic<unsigned> next_slot{0};
-    static const bool fused = !(getenv("HVN_BN_FUSED_FINAL") && atoi(getenv("HVN_BN_FUSED_FINAL")) == 0);    // A/B knob: 0 = finalize launches of their own
-    a.slot = (fused && gx <= HVN_BN_COLS) ? (int)(next_slot.fetch_add(1) % HVN_BN_SLOTS) : -1;
 }
 
 int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
@@ -752,7 +708,7 @@ int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
     dim3 grid;
     bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<0>, grid, dim3(256), 0, stream, a);
-    if (a.slot < 0) hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
     const long total = (long)a.N * a.H * a.W * (a.C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -766,7 +722,7 @@ int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
     dim3 grid;
     bn_grid(a, grid);
     hipLaunchKernelGGL(hvn_bn_reduce<1>, grid, dim3(256), 0, stream, a);
-    if (a.slot < 0) hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(hvn_bn_bwd_final, dim3((a.C + 31) / 32), dim3(256), 0, stream, a);
     if (a.dz) {
         const long total = (long)a.N * a.H * a.W * (a.C / 4);
         long blocks = (total + 255) / 256;

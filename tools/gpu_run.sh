@@ -115,19 +115,6 @@ PY
     done
     for c in 0 1; do ENVV=(HVN_CHAIN_X3R=$c); bench x3r_$c $Q; done
     ;;
-  bnfinal)    # round 5: BatchNorm(train) finalize inside the reduce launch's last workgroups (csrc/hvn_train.hip): the training tests that
-              # touch BatchNorm, then the training step with the finalize as launches of its own | fused, both phases, one box
-    timeout 900 python -m pytest tests/test_gpu_train.py -q --tb=short -x -k "bn or batchnorm or training_step or optimizer or two_phase" 2>&1 | tail -8 >> $O
-    for cfg in "HVN_BN_FUSED_FINAL=0" "HVN_BN_FUSED_FINAL=1"; do
-      env $cfg timeout 400 python tools/train_bench.py --steps 10 --warmup 3 2>/dev/null | grep "^{" | sed "s/^/$cfg /" >> gpurun_out/${R}_train_bn_ab.jsonl
-    done
-    python - >> $O <<PY
-import json
-for l in open("gpurun_out/${R}_train_bn_ab.jsonl"):
-    i = l.index("{"); tag, d = l[:i], json.loads(l[i:])
-    print(tag, "phase", d.get("phase"), "batch", d.get("batch"), "ms/step %.2f" % d.get("ms_per_step", 0), {k: round(v, 2) for k, v in d.items() if k.endswith("_ms")})
-PY
-    ;;
   wgradx3)    # round 5: weight gradients on the bf16 pipe (csrc/hvn_wgrad_x3.hip) + the LDS-DMA conv forms in the training step: kernel tests,
               # then the training step with / without them on one box
     timeout 900 python -m pytest tests/test_gpu_train.py -q --tb=line -k "wgrad" 2>&1 | tail -8 >> $O
