@@ -324,6 +324,9 @@ int hvn_launch_predmap(const PredMapArgs &a, hipStream_t stream)
 // n^2 multiplications per m^2 outputs instead of 25 m^2 (hover_net_amd/winograd.py derives the matrices).
 // Both kernels are HBM-bound byte movers: one thread = one tile x VW channels, consecutive threads on
 // consecutive channels.  VW = 4 (16-byte accesses) where the n^2 x VW register tile fits, 2 for the 8x8 input tile.
+#ifndef HVN_WINO_XCD
+#define HVN_WINO_XCD 1             // (lib.py VARIANTS "noxcd": 0, the A/B build)
+#endif
 template <int VW> struct WVec;
 template <> struct WVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 template <> struct WVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
@@ -334,7 +337,17 @@ __global__ __launch_bounds__(256) void hvn_wino_in(const WinoArgs p, long total)
 {
     constexpr int NW = MO + R - 1;
     typedef typename WVec<VW>::T VT;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // Neighbouring tiles share (NW - MO) / NW of their input rows and columns, and workgroups are dealt to the 8 XCDs round robin
+    // (blockIdx % 8), each with an L2 of its own: in launch order every XCD would fetch every halo from HBM for itself.  XCD k takes
+    // the k-th CONTIGUOUS eighth of the (tile, channel slice) list instead, so a halo is re-read from the L2 that already holds it.
+    unsigned bid = blockIdx.x;
+#if HVN_WINO_XCD
+    {
+        const unsigned per = gridDim.x >> 3;
+        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+    }
+#endif
+    const long i = (long)bid * 256 + threadIdx.x;
     if (i >= total) return;
     const int cvn = p.C / VW;
     const int cv = (int)(i % cvn);

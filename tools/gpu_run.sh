@@ -115,6 +115,16 @@ PY
     done
     for c in 0 1; do ENVV=(HVN_CHAIN_X3R=$c); bench x3r_$c $Q; done
     ;;
+  winoxcd)    # round 5: XCD-contiguous tile ranges in the Winograd input transform (csrc/hvn_net_ops.hip); A/B against the "noxcd" build
+    timeout 600 python -m pytest tests/test_gpu_net.py tests/test_gpu_conv.py -q --tb=short -x -k "wino or network or golden" 2>&1 | tail -5 >> $O
+    for v in noxcd ""; do
+      f=gpurun_out/${R}_layers_winoxcd_${v:-default}.txt
+      HVN_LIB_VARIANT=$v timeout 300 python tools/layer_ms.py > $f 2>&1; echo "== HVN_LIB_VARIANT=$v: $(tail -1 $f)" >> $O
+      grep "wino_in" $f | awk '{s+=$(NF)} END {print "   wino_in total us:", s}' >> $O
+    done
+    Q="--steps 10 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
+    for v in noxcd ""; do ENVV=(HVN_LIB_VARIANT=$v); bench winoxcd_${v:-default} $Q; done
+    ;;
   wgradx3)    # round 5: weight gradients on the bf16 pipe (csrc/hvn_wgrad_x3.hip) + the LDS-DMA conv forms in the training step: kernel tests,
               # then the training step with / without them on one box
     timeout 900 python -m pytest tests/test_gpu_train.py -q --tb=line -k "wgrad" 2>&1 | tail -8 >> $O
