@@ -52,6 +52,15 @@ int hvn_launch_conv(const ConvArgs &a, int tile_n, hipStream_t stream);
 // Two chained 1x1 convs of a residual block in one launch (hvn_conv_chain.hip):
 //   y  = [relu(. * post_s + post_b)]( W1 . x (+ W1b . x2) + res )        C channels        (a unit's conv3 + shortcut)
 //   y2 = [relu]( W2 . a + bias2 ),  a = relu(y * pre_s + pre_b) or y     N2 channels       (the next unit's conv1)
+#ifndef HVN_CONV_XCD_CONTIG
+#define HVN_CONV_XCD_CONTIG 1      // (lib.py VARIANTS "noxcd": 0, the A/B build)
+#endif
+// pixel tile of workgroup (xcd = blockIdx % 8, seq_m) of a convolution launch with `groups` = ceil(m_tiles / 8) tiles per XCD
+static __device__ __forceinline__ int hvn_m_tile(int xcd, int seq_m, int groups, bool contiguous)
+{
+    return (HVN_CONV_XCD_CONTIG && contiguous) ? xcd * groups + seq_m : seq_m * 8 + xcd;
+}
+
 struct ChainArgs {
     const float *x;       // conv3 input view [N][Ho][Wo][K1]
     long xsn, xsy, xsx;

@@ -13,7 +13,7 @@ VARIANTS = {
     "lin": ("-DHVN_EPI_LINEAR=1",),                 # prepared, NOT yet measured: branch-free epilogue addressing for row-contiguous views
     "nt": ("-DHVN_NT=1",),                          # prepared, NOT yet measured: non-temporal hints on the epilogue's residual loads / stores
     "lin_nt": ("-DHVN_EPI_LINEAR=1", "-DHVN_NT=1"),
-    "noxcd": ("-DHVN_WINO_XCD=0",),                 # A/B: the Winograd input transform's workgroups in launch order (no XCD-contiguous tile ranges)
+    "noxcd": ("-DHVN_WINO_XCD=0", "-DHVN_CONV_XCD_CONTIG=0"),   # A/B: round-robin tile order in the Winograd input transform and the multi-tap convolutions
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")
