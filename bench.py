@@ -162,7 +162,7 @@ def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
     note = ("achieved = MFMA FLOPs executed by the launches (Winograd-domain GEMMs counted as issued; SURVEY 8d's direct-convolution figure is "
             "`algorithmic_gflop_per_step` / batch) / summed HIP-event time of those launches, per-launch median of %d passes, single stream" % n_prof)
     x3_ms = x3_eq = x3_bf16 = 0.0
-    ch_ms = ch_eq = ch_bf16 = 0.0          # round 5: the chained seams on the bf16 pipe (hvn_conv_chain_x3), their own kernel
+    ch_ms = ch_eq = ch_bf16 = 0.0          # round 5: the chained seams on the bf16 pipe (hvn_conv_chain_x3 | _x3r), their own kernels
     rest_ms = rest_flops = 0.0
     n_x3 = n_ch = 0
     if dtype == "fp32" and launches == len(timed):
@@ -187,7 +187,9 @@ def roofline_account(timed, per_ms, batch, dtype, n_prof=5):
     ideal_ms = 1e3 * ((x3_bf16 + ch_bf16) / (PEAK_BF16_MATRIX_TFLOPS * 1e12) + rest_flops / (PEAK_FP32_MATRIX_TFLOPS * 1e12))
     chained = None
     if n_ch:
-        chained = {"what": "hvn_conv_chain_x3: d0's residual seams (conv3 + residual -> next conv1 in one launch), both GEMMs on the bf16 pipe",
+        chained = {"what": "hvn_conv_chain_x3 / hvn_conv_chain_x3r (same bits, picked per seam by time): d0's residual seams (conv3 + residual -> next conv1 "
+                           "in one launch), both GEMMs on the bf16 pipe",
+                   "launches_on_register_resident_form": sum(1 for o in timed if o.kind == 8 and o.extra.get("x3") and o.extra.get("tile_form") == 1152),
                    "launches": n_ch, "ms_per_step": ch_ms, "bf16_mfma_gflop_per_step": ch_bf16 / 1e9, "achieved": ch_bf16 / (ch_ms * 1e-3) / 1e12,
                    "peak": PEAK_BF16_MATRIX_TFLOPS, "frac": ch_bf16 / (ch_ms * 1e-3) / 1e12 / PEAK_BF16_MATRIX_TFLOPS,
                    "fp32_equivalent_tflops": ch_eq / (ch_ms * 1e-3) / 1e12,

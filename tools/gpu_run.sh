@@ -116,7 +116,7 @@ PY
     for c in 0 1; do ENVV=(HVN_CHAIN_X3R=$c); bench x3r_$c $Q; done
     ;;
   winoxcd)    # round 5: XCD-contiguous tile ranges in the Winograd input transform (csrc/hvn_net_ops.hip); A/B against the "noxcd" build
-    timeout 600 python -m pytest tests/test_gpu_net.py tests/test_gpu_conv.py -q --tb=short -x -k "wino or network or golden" 2>&1 | tail -5 >> $O
+    timeout 600 python -m pytest tests/test_gpu_net.py tests/test_gpu_conv.py -q --tb=short -x -k "not slow" 2>&1 | tail -5 >> $O
     for v in noxcd ""; do
       f=gpurun_out/${R}_layers_winoxcd_${v:-default}.txt
       HVN_LIB_VARIANT=$v timeout 300 python tools/layer_ms.py > $f 2>&1; echo "== HVN_LIB_VARIANT=$v: $(tail -1 $f)" >> $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end refresh on the GPU box (one gpurun call):  gpurun -- 'bash tools/refresh_profiles.sh r05'
-# full -m gpu suite (TESTS=0 skips it), smoke(), the default bench line (fitted checkpoint; measures roofline.traffic itself through two
+# full -m gpu suite (TESTS=0 skips it), run-to-run / form-to-form bit equality of the whole network under load, smoke(), the default bench line (fitted checkpoint; measures roofline.traffic itself through two
 # rocprofv3 --pmc child passes, writes the per-launch-class traffic table of those passes, carries the cfg-3 / train_step / wsi_8k legs),
 # rocprofv3 kernel stats + per-layer table of a random-checkpoint run on ONE launch stream (every kernel's duration is its own: under the
 # two-stream schedule overlapped kernels' durations inflate), the SQ PMC pass, per-launch tables (fp32 pipe | default), cfg 3 as its own
@@ -12,6 +12,7 @@ R=${1:-r}
 if [ "${TESTS:-1}" != "0" ]; then
   timeout 1500 python -m pytest tests -q -m gpu --durations=15 2>&1 | tail -30 > gpurun_out/${R}_gpu_tests.log
 fi
+timeout 400 python tools/determinism_check.py 16 3 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_determinism.txt      # every kernel form, whole network, batch 16: same bits
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/${R}_smoke.log
 HVN_KEEP_PMC_TABLE=gpurun_out/${R}_traffic_by_kernel.txt timeout 900 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 PCMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-traffic --checkpoint random"
