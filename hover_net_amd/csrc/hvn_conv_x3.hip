@@ -87,14 +87,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_x3(ConvArgs p)
 
     // ---- A staging coordinates: wave-uniform base moving with the k-step (SGPR) + loop-invariant per-thread byte offset; a
     //      voffset beyond num_records returns zeros (padding taps, rows past the batch) --------------------------------------------
-    // a wave stages rows w, w + 4, ..., w + 28 of each 32-row pass (not 8 consecutive ones): at the padded pitch of 208 B the eight 64-byte
-    // plane pieces of rows 4 apart start at banks 0, 16, 32, 48, 0, ... -- each ds_write_b64 of the wave covers the 64 banks exactly twice,
-    // where consecutive rows (bank offsets 0, 52, 40, 28, ...) overlapped (SQ_LDS_BANK_CONFLICT: 0.28 per active LDS cycle, round 5)
-#if defined(HVN_X3_SROW_LINEAR)
     const int srow = tid >> 3;
-#else
-    const int srow = ((tid >> 3) & 7) * 4 + (tid >> 6);
-#endif
     const int scol = (tid & 7) * 4;
     const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
     const unsigned n_blk = m0 / HoWo;

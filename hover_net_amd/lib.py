@@ -14,7 +14,6 @@ VARIANTS = {
     "nt": ("-DHVN_NT=1",),                          # prepared, NOT yet measured: non-temporal hints on the epilogue's residual loads / stores
     "lin_nt": ("-DHVN_EPI_LINEAR=1", "-DHVN_NT=1"),
     "noxcd": ("-DHVN_WINO_XCD=0", "-DHVN_CONV_XCD_CONTIG=0"),   # A/B: round-robin tile order in the Winograd input transform and the multi-tap convolutions
-    "srowlin": ("-DHVN_X3_SROW_LINEAR=1",),         # A/B: hvn_conv_x3.hip staging 8 consecutive rows per wave (bank conflicts on the plane writes)
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")
