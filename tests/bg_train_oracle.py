@@ -45,8 +45,24 @@ def start():
         threads = max(4, (os.cpu_count() or 8) // 2)
         _PROC = subprocess.Popen([sys.executable, os.path.abspath(__file__), _DIR, str(threads)] + ["%s:%s" % j for j in JOBS], env=env,
                                  stdout=subprocess.DEVNULL, stderr=open(os.path.join(_DIR, "worker.err"), "w"))
+        import atexit
+
+        atexit.register(_stop)                         # a run that ends early (-x) must not leave the worker computing behind whatever runs next
     except Exception:                                  # noqa: BLE001 -- the in-process path covers every failure
         _PROC = None
+
+
+def _stop():
+    import shutil
+
+    if _PROC is not None and _PROC.poll() is None:
+        _PROC.terminate()
+        try:
+            _PROC.wait(timeout=10)
+        except Exception:                              # noqa: BLE001
+            _PROC.kill()
+    if _DIR:
+        shutil.rmtree(_DIR, ignore_errors=True)        # (the float64 result alone is ~300 MB)
 
 
 def get(case, dtype, timeout=600):
