@@ -198,8 +198,18 @@ struct WgradArgs {
     int nbatch;           // > 1: blockIdx.z selects one of nbatch independent problems
     long xb, db, wb;      // element strides of x, dy, dw between them
     int want_wgs;         // workgroups the K split aims at (0: the default)
+    // deterministic reduce (hvn_run_train_plan_ws): split s of the pixel sum STORES its tile into copy s of the gradient tensor in
+    // `part` (part_stride floats per copy, part_cap floats in all) and hvn_launch_reduce_parts adds the copies to dw in split order
+    float *part;
+    long part_stride, part_cap;
 };
 int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream);
+// the K split both weight-gradient launchers make: -> number of splits, *rows_per_split (a multiple of 32)
+long hvn_wgrad_split(const WgradArgs &a, long tiles, unsigned *rows_per_split);
+// floats of `part` a launch of this shape needs (0: a single split, which needs none)
+long hvn_wgrad_part_floats(const WgradArgs &a, int x3);
+// dst[e] += part[0][e] + part[1][e] + ... in a fixed order (4 interleaved chains of ascending s, then chain 0 + 1 + 2 + 3)
+int hvn_launch_reduce_parts(float *dst, const float *part, long elems, long nparts, long stride, hipStream_t stream);
 // the same sum with its products on the bf16 matrix pipe from bf16x3 splits of both operands (hvn_wgrad_x3.hip): 128 x 128 channel tiles
 int hvn_wgrad_x3_supported(const WgradArgs &a);
 int hvn_launch_wgrad_x3(WgradArgs a, int terms, hipStream_t stream);
@@ -248,8 +258,11 @@ struct HeadBwdArgs {
     const float *w;       // [Cout][64]
     float *dw, *db;
     int N, H, W, Cout;
+    float *part;          // deterministic reduce: [workgroups][Cout * 64 + Cout] partial sums (NULL: fp32 atomics)
+    long part_cap;
 };
 int hvn_launch_head_bwd(const HeadBwdArgs &a, hipStream_t stream);
+long hvn_head_bwd_part_floats(const HeadBwdArgs &a);
 
 struct Conv0WgradArgs {
     const uint8_t *img;
@@ -259,8 +272,11 @@ struct Conv0WgradArgs {
     long ysn, ysy, ysx;
     float *dw;            // [64][7][7][3]
     int N, Ho, Wo, pad;
+    float *part;          // deterministic reduce: [workgroups][64 * 147] partial sums (NULL: fp32 atomics)
+    long part_cap;
 };
 int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream);
+long hvn_conv0_wgrad_part_floats(const Conv0WgradArgs &a);
 
 struct LossArgs {
     const float *l_np, *l_hv, *l_tp;   // NCHW logits
@@ -272,7 +288,10 @@ struct LossArgs {
     int N, H, W, T;
     double m_total;
     float wt[6];                       // np bce, np dice, hv mse, hv msge, tp bce, tp dice
+    double *parts;                     // deterministic reduce: [workgroups][64] per-workgroup sums (NULL: double atomics into sums)
+    long parts_cap;                    // doubles
 };
+long hvn_loss_part_doubles(int n, int h, int w);
 int hvn_launch_loss(const LossArgs &a, int stage, hipStream_t stream);
 int hvn_launch_adam(float *w, const float *g, float *m, float *v, long n, float b1, float b2, float eps, float step_size,
                     float inv_bc2_sqrt, hipStream_t stream);

@@ -329,8 +329,12 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
     }
 
     // epilogue: D[m][n] of block (i, j): m = 8*(r/4) + 4*lh + (r%4) -> cout column m*MBA + i, n = l31 -> cin column n*MBB + j
+    // deterministic form: this split's tile is STORED into copy blockIdx.y of the gradient tensor (every element of a copy has one
+    // writer) and hvn_reduce_parts adds the copies in split order; otherwise fp32 atomics straight into the gradient
     const int taps = p.KH * p.KW;
     const int og = p.Cout / p.groups;
+    float *pout = p.part ? p.part + (long)blockIdx.y * p.part_stride + (long)blockIdx.z * p.wb : pdw;
+    const bool det = p.part != nullptr;
 #pragma unroll
     for (int i = 0; i < MBA; ++i)
 #pragma unroll
@@ -346,26 +350,47 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
                     cg = ci - (co / og) * p.Cin_g;
                     if (cg < 0 || cg >= p.Cin_g) continue;
                 }
-                unsafeAtomicAdd(pdw + ((long)co * taps + tap) * p.Cin_g + cg, acc[i][j][r]);
+                float *d = pout + ((long)co * taps + tap) * p.Cin_g + cg;
+                if (det)
+                    *d = acc[i][j][r];
+                else
+                    unsafeAtomicAdd(d, acc[i][j][r]);
             }
         }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_wgrad(WgradArgs a, hipStream_t stream)
+// dst[e] += part[0][e] + ... + part[S-1][e], always in the same order: four interleaved chains (chain j: s = j, j + 4, ... ascending),
+// then (chain 0 + chain 1) + (chain 2 + chain 3).  One thread per (element, chain); the chains meet in LDS.
+__global__ __launch_bounds__(256) void hvn_reduce_parts(float *__restrict__ dst, const float *__restrict__ part, long elems, long nparts, long stride)
 {
-    constexpr int MBA = BM / WAVES_M / 32, MBB = BN / WAVES_N / 32;
-    constexpr size_t lds = (size_t)2 * 32 * (WgPitch<BM, MBA>::value + WgPitch<BN, MBB>::value) * sizeof(float);
-    a.tiles_m = (a.Cout + BM - 1) / BM;
-    a.tiles_n = a.Cin / BN;
-    const long tiles = (long)a.tiles_m * a.tiles_n * a.KH * a.KW;
-    const long R = (long)a.N * a.Ho * a.Wo;
-    const int nb = a.nbatch > 1 ? a.nbatch : 1;
-    // The K split trades matrix time against atomic traffic (every workgroup ends with one fp32 atomic per element of its tile).
-    // Default: ~3 workgroups per slot of the 512 the chip holds, at least 8 k-steps per workgroup.  The best target depends on
+    __shared__ float ch[4][64];
+    const int el = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (e < elems)
+        for (long k = j; k < nparts; k += 4) s += part[k * stride + e];
+    ch[j][el] = s;
+    __syncthreads();
+    if (j == 0 && e < elems) dst[e] += (ch[0][el] + ch[1][el]) + (ch[2][el] + ch[3][el]);
+}
+
+int hvn_launch_reduce_parts(float *dst, const float *part, long elems, long nparts, long stride, hipStream_t stream)
+{
+    if (!dst || !part || elems <= 0 || nparts <= 0 || (elems + 63) / 64 >= (1L << 31)) return -1;
+    hipLaunchKernelGGL(hvn_reduce_parts, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, stream, dst, part, elems, nparts, stride);
+    return launch_ok();
+}
+
+// The K split of a weight-gradient launch: ~`want` workgroups in all, at least `min_rows` pixels per split, rows a multiple of 32.
+long hvn_wgrad_split(const WgradArgs &a, long tiles, unsigned *rows_per_split)
+{
+    // The K split trades matrix time against reduce traffic (every workgroup ends with one fp32 atomic, or one store, per element of its
+    // tile).  Default: ~3 workgroups per slot of the 512 the chip holds, at least 8 k-steps per workgroup.  The best target depends on
     // the launch shape (profiles/r03_train_wgrad_sweep.txt: 512 for the encoder's few-tile launches at batch 4, >= 1024 for the
     // decoder's 5x5 launches), so TrainEngine.autotune_tiles times a few per shape and passes its choice in `want_wgs`.
     // HVN_WGRAD_WGS / HVN_WGRAD_MIN_ROWS override (tools/wgrad_sweep.py; read per launch so that one process can sweep them).
+    const long R = (long)a.N * a.Ho * a.Wo;
+    const int nb = a.nbatch > 1 ? a.nbatch : 1;
     const char *e_wgs = getenv("HVN_WGRAD_WGS"), *e_rows = getenv("HVN_WGRAD_MIN_ROWS");
     const long want = e_wgs ? atol(e_wgs) : (a.want_wgs > 0 ? a.want_wgs : 1536);
     const long min_rows = e_rows ? atol(e_rows) : 256;
@@ -376,19 +401,62 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream)
     long rps = (R + ksplit - 1) / ksplit;
     rps = (rps + 31) / 32 * 32;
     ksplit = (R + rps - 1) / rps;
-    a.rows_per_split = (unsigned)rps;
+    if (rows_per_split) *rows_per_split = (unsigned)rps;
+    return ksplit;
+}
+
+static inline long wgrad_elems(const WgradArgs &a)
+{
+    return a.nbatch > 1 ? (long)a.nbatch * a.wb : (long)a.Cout * a.KH * a.KW * a.Cin_g;
+}
+
+static void wgrad_tile_shape(const WgradArgs &a, int *bm, int *bn)
+{
+    *bm = a.Cout >= 128 ? 128 : a.Cout >= 64 ? 64 : 32;
+    *bn = a.Cin % 128 == 0 ? 128 : a.Cin % 64 == 0 ? 64 : 32;
+}
+
+long hvn_wgrad_part_floats(const WgradArgs &a, int x3)
+{
+    int bm, bn;
+    if (x3 && hvn_wgrad_x3_supported(a))
+        bm = bn = 128;
+    else
+        wgrad_tile_shape(a, &bm, &bn);
+    const long tiles = (long)((a.Cout + bm - 1) / bm) * (a.Cin / bn) * a.KH * a.KW;
+    const long ksplit = hvn_wgrad_split(a, tiles, nullptr);
+    return ksplit > 1 ? ksplit * wgrad_elems(a) : 0;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_wgrad(WgradArgs a, hipStream_t stream)
+{
+    constexpr int MBA = BM / WAVES_M / 32, MBB = BN / WAVES_N / 32;
+    constexpr size_t lds = (size_t)2 * 32 * (WgPitch<BM, MBA>::value + WgPitch<BN, MBB>::value) * sizeof(float);
+    a.tiles_m = (a.Cout + BM - 1) / BM;
+    a.tiles_n = a.Cin / BN;
+    const long tiles = (long)a.tiles_m * a.tiles_n * a.KH * a.KW;
+    const int nb = a.nbatch > 1 ? a.nbatch : 1;
+    const long ksplit = hvn_wgrad_split(a, tiles, &a.rows_per_split);
+    const long elems = wgrad_elems(a);
+    if (a.part && ksplit > 1) {
+        if (ksplit * elems > a.part_cap) return -4;
+        a.part_stride = elems;
+    } else
+        a.part = nullptr;       // a single split: one writer per element, 0 + x in any order
     auto k = hvn_conv_wgrad_f32<BM, BN, WAVES_M, WAVES_N>;
     static std::atomic<unsigned long long> attr{0};
     if (hvn_max_lds_once(reinterpret_cast<const void *>(k), (int)lds, attr)) return -2;
     hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)ksplit, (unsigned)nb), dim3(256), lds, stream, a);
-    return launch_ok();
+    if (launch_ok()) return -2;
+    return a.part ? hvn_launch_reduce_parts(a.dw, a.part, elems, ksplit, elems, stream) : 0;
 }
 
 int hvn_launch_wgrad(const WgradArgs &a, hipStream_t stream)
 {
     if (a.Cin % 32 || a.Cout % 32 || a.groups < 1 || a.Cin_g * a.groups != a.Cin) return -1;
-    const int bm = a.Cout >= 128 ? 128 : a.Cout >= 64 ? 64 : 32;
-    const int bn = a.Cin % 128 == 0 ? 128 : a.Cin % 64 == 0 ? 64 : 32;
+    int bm, bn;
+    wgrad_tile_shape(a, &bm, &bn);
     if (bm == 128 && bn == 128) return launch_wgrad<128, 128, 2, 2>(a, stream);
     if (bm == 128 && bn == 64) return launch_wgrad<128, 64, 4, 1>(a, stream);
     if (bm == 128 && bn == 32) return launch_wgrad<128, 32, 4, 1>(a, stream);
@@ -778,8 +846,13 @@ int hvn_launch_upadd_bwd(const UpAddBwdArgs &a, hipStream_t stream)
 // =========================================================================================
 // 1x1 logit head (64 -> C, bias) backward: da += W^T dl, dW += sum dl (x) a, db += sum dl
 // =========================================================================================
-// Every lane owns one pixel; the weight / bias gradients are summed across the wave with a butterfly (6 exchanges) and leave with ONE
-// LDS atomic per wave and value (round 3 added every lane's product with its own LDS atomic: 64 lanes on one address, 0.36 ms per head).
+// Every lane owns one pixel; the weight / bias gradients are summed across the wave with a butterfly (6 exchanges: the same tree every
+// run) into the wave's OWN row of an LDS table -- a plain read-modify-write by the wave's first lane, no LDS atomics (round 3 added every
+// lane's product with its own LDS atomic: 64 lanes on one address, 0.36 ms per head; rounds 4-5 one atomic per wave and value, whose order
+// among the four waves was not fixed).  A workgroup walks several 256-pixel groups (grid capped at HEAD_BWD_MAX_WGS), then sums its four
+// rows in wave order and leaves with one fp32 atomic per value -- or, deterministic form, STORES its sums as row blockIdx.x of `part`,
+// which hvn_reduce_parts adds to dW / db in workgroup order.
+#define HEAD_BWD_MAX_WGS 512
 __device__ __forceinline__ float head_wave_sum(float v)
 {
 #pragma unroll
@@ -788,60 +861,83 @@ __device__ __forceinline__ float head_wave_sum(float v)
 }
 __global__ __launch_bounds__(256) void hvn_head_bwd(const HeadBwdArgs p, long total)
 {
-    __shared__ float sw[16 * 64 + 16];  // dW tile then db
+    __shared__ float sw[4][16 * 64 + 16];  // per wave: dW tile then db
     const int C = p.Cout;
-    for (int i = threadIdx.x; i < C * 64 + C; i += 256) sw[i] = 0.f;
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * (16 * 64 + 16); i += 256) (&sw[0][0])[i] = 0.f;
     __syncthreads();
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool act = i < total;
-    const long ii = act ? i : 0;
-    const int x = (int)(ii % p.W);
-    long t = ii / p.W;
-    const int y = (int)(t % p.H);
-    const int n = (int)(t / p.H);
-    const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
-    float *dst = p.dx + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx;
-    const long plane = (long)p.H * p.W;
-    const float *dl = p.dl + (long)n * C * plane + (long)y * p.W + x;
-    float a[64], da[64];
-#pragma unroll
-    for (int c = 0; c < 64; c += 4) {
-        const f32x4 v = *(const f32x4 *)(src + c);
-        const f32x4 d = *(const f32x4 *)(dst + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[c + e] = act ? v[e] : 0.f;
-            da[c + e] = d[e];
-        }
-    }
+    float *mine = sw[wave];
     const bool lead = (threadIdx.x & 63) == 0;
-    for (int co = 0; co < C; ++co) {
-        const float g = act ? dl[co * plane] : 0.f;
-        const float *__restrict__ w = p.w + co * 64;
-        const float gs = head_wave_sum(g);
-        if (lead) atomicAdd(&sw[C * 64 + co], gs);
+    const long plane = (long)p.H * p.W;
+    for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+        const long i = base + threadIdx.x;
+        const bool act = i < total;
+        const long ii = act ? i : 0;
+        const int x = (int)(ii % p.W);
+        long t = ii / p.W;
+        const int y = (int)(t % p.H);
+        const int n = (int)(t / p.H);
+        const float *src = p.x + (long)n * p.xsn + (long)y * p.xsy + (long)x * p.xsx;
+        float *dst = p.dx + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx;
+        const float *dl = p.dl + (long)n * C * plane + (long)y * p.W + x;
+        float a[64], da[64];
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            da[c] = fmaf(g, w[c], da[c]);
-            const float ws = head_wave_sum(g * a[c]);
-            if (lead) atomicAdd(&sw[co * 64 + c], ws);
+        for (int c = 0; c < 64; c += 4) {
+            const f32x4 v = *(const f32x4 *)(src + c);
+            const f32x4 d = *(const f32x4 *)(dst + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[c + e] = act ? v[e] : 0.f;
+                da[c + e] = d[e];
+            }
+        }
+        for (int co = 0; co < C; ++co) {
+            const float g = act ? dl[co * plane] : 0.f;
+            const float *__restrict__ w = p.w + co * 64;
+            const float gs = head_wave_sum(g);
+            if (lead) mine[C * 64 + co] += gs;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                da[c] = fmaf(g, w[c], da[c]);
+                const float ws = head_wave_sum(g * a[c]);
+                if (lead) mine[co * 64 + c] += ws;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 64; c += 4) *(f32x4 *)(dst + c) = (f32x4){da[c], da[c + 1], da[c + 2], da[c + 3]};
         }
     }
-    if (act) {
-#pragma unroll
-        for (int c = 0; c < 64; c += 4) *(f32x4 *)(dst + c) = (f32x4){da[c], da[c + 1], da[c + 2], da[c + 3]};
-    }
     __syncthreads();
-    for (int k = threadIdx.x; k < C * 64; k += 256) unsafeAtomicAdd(p.dw + k, sw[k]);
-    for (int k = threadIdx.x; k < C; k += 256) unsafeAtomicAdd(p.db + k, sw[C * 64 + k]);
+    const int nv = C * 64 + C;
+    for (int k = threadIdx.x; k < nv; k += 256) {
+        const float v = (sw[0][k] + sw[1][k]) + (sw[2][k] + sw[3][k]);
+        if (p.part)
+            p.part[(long)blockIdx.x * nv + k] = v;
+        else
+            unsafeAtomicAdd(k < C * 64 ? p.dw + k : p.db + (k - C * 64), v);
+    }
 }
+
+static inline long head_bwd_wgs(const HeadBwdArgs &a)
+{
+    const long groups = ((long)a.N * a.H * a.W + 255) / 256;
+    return groups < HEAD_BWD_MAX_WGS ? groups : HEAD_BWD_MAX_WGS;
+}
+long hvn_head_bwd_part_floats(const HeadBwdArgs &a) { return head_bwd_wgs(a) * (a.Cout * 64 + a.Cout); }
 
 int hvn_launch_head_bwd(const HeadBwdArgs &a, hipStream_t stream)
 {
     if (a.Cout < 1 || a.Cout > 16) return -1;
     const long total = (long)a.N * a.H * a.W;
-    hipLaunchKernelGGL(hvn_head_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
-    return launch_ok();
+    const long wgs = head_bwd_wgs(a);
+    const int nv = a.Cout * 64 + a.Cout;
+    if (a.part && wgs * nv > a.part_cap) return -4;
+    hipLaunchKernelGGL(hvn_head_bwd, dim3((unsigned)wgs), dim3(256), 0, stream, a, total);
+    if (launch_ok()) return -2;
+    if (!a.part) return 0;
+    if (hvn_launch_reduce_parts(a.dw, a.part, (long)a.Cout * 64, wgs, nv, stream)) return -2;
+    return hvn_launch_reduce_parts(a.db, a.part + (long)a.Cout * 64, a.Cout, wgs, nv, stream);
 }
 
 // =========================================================================================
@@ -904,7 +1000,11 @@ __global__ __launch_bounds__(256) void hvn_conv0_wgrad(const Conv0WgradArgs p, i
 #pragma unroll
     for (int k = 0; k < 37; ++k) {
         const int tap = ph + 4 * k;
-        if (tap < 147) unsafeAtomicAdd(p.dw + (long)co * 147 + tap, acc[k]);
+        if (tap >= 147) continue;
+        if (p.part)
+            p.part[(long)blockIdx.x * (64 * 147) + co * 147 + tap] = acc[k];
+        else
+            unsafeAtomicAdd(p.dw + (long)co * 147 + tap, acc[k]);
     }
 }
 
@@ -981,44 +1081,64 @@ __global__ __launch_bounds__(256) void hvn_conv0_wgrad_mfma(const Conv0WgradArgs
             }
         }
     }
-    // sum the four waves' partials in LDS ([64 co][160 taps]), then one atomic per weight
+    // sum the four waves' partials in LDS ([64 co][160 taps]) in WAVE ORDER (four turns; LDS atomics left the order to the scheduler), then
+    // one atomic per weight -- or, deterministic form, the workgroup's sums stored as row blockIdx.x of `part` for hvn_reduce_parts
     __syncthreads();
     float *red = dzs;
     for (int i = tid; i < 64 * 160; i += 256) red[i] = 0.f;
     __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+                for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                atomicAdd(red + co * 160 + 32 * j + l31, acc[i][j][r]);
-            }
-    __syncthreads();
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        red[co * 160 + 32 * j + l31] += acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < 64 * 147; i += 256) {
         const int co = i / 147, k = i - co * 147;
-        unsafeAtomicAdd(p.dw + i, red[co * 160 + k]);
+        if (p.part)
+            p.part[(long)blockIdx.x * (64 * 147) + i] = red[co * 160 + k];
+        else
+            unsafeAtomicAdd(p.dw + i, red[co * 160 + k]);
     }
 }
+
+static inline bool conv0_wgrad_valu()
+{
+    static int valu = -1;
+    if (valu < 0) valu = getenv("HVN_CONV0_WGRAD_VALU") ? 1 : 0;
+    return valu != 0;
+}
+static inline long conv0_wgrad_wgs(const Conv0WgradArgs &a)
+{
+    const int tx = (a.Wo + W0_T - 1) / W0_T, ty = (a.Ho + W0_T - 1) / W0_T;
+    const long total = (long)tx * ty * a.N, cap = conv0_wgrad_valu() ? 1024 : 512;
+    return total < cap ? total : cap;
+}
+long hvn_conv0_wgrad_part_floats(const Conv0WgradArgs &a) { return conv0_wgrad_wgs(a) * 64 * 147; }
 
 int hvn_launch_conv0_wgrad(const Conv0WgradArgs &a, hipStream_t stream)
 {
     const int tx = (a.Wo + W0_T - 1) / W0_T, ty = (a.Ho + W0_T - 1) / W0_T;
     const long total = (long)tx * ty * a.N;
-    static int valu = -1;
-    if (valu < 0) valu = getenv("HVN_CONV0_WGRAD_VALU") ? 1 : 0;
-    if (!valu) {
+    const long blocks = conv0_wgrad_wgs(a);
+    if (a.part && blocks * 64 * 147 > a.part_cap) return -4;
+    if (!conv0_wgrad_valu()) {
         const size_t lds = (size_t)(W0_P * W0M_PITCH + 64 * 160) * sizeof(float);
         static std::atomic<unsigned long long> attr{0};
         if (hvn_max_lds_once(reinterpret_cast<const void *>(hvn_conv0_wgrad_mfma), (int)lds, attr)) return -2;
-        long blocks = total < 512 ? total : 512;
         hipLaunchKernelGGL(hvn_conv0_wgrad_mfma, dim3((unsigned)blocks), dim3(256), lds, stream, a, tx, ty, total);
-        return launch_ok();
-    }
-    long blocks = total < 1024 ? total : 1024;
-    hipLaunchKernelGGL(hvn_conv0_wgrad, dim3((unsigned)blocks), dim3(256), 0, stream, a, tx, ty, total);
-    return launch_ok();
+    } else
+        hipLaunchKernelGGL(hvn_conv0_wgrad, dim3((unsigned)blocks), dim3(256), 0, stream, a, tx, ty, total);
+    if (launch_ok()) return -2;
+    return a.part ? hvn_launch_reduce_parts(a.dw, a.part, 64 * 147, blocks, 64 * 147, stream) : 0;
 }
 
 // =========================================================================================
@@ -1037,15 +1157,36 @@ __device__ inline float sobel5_h(int r, int s)  // kernel_h[r][s] = h / (h^2 + v
     return h / (h * h + v * v + 1.0e-15f);
 }
 
+// Reduction of the sums, the same tree every run (rounds 1-5: double atomics in LDS and into `sums`, whose order the scheduler picked -- a
+// difference in the 16th digit, but one that a float conversion downstream can turn into a different gradient bit): every value is summed
+// across the wave by a butterfly, lands in the wave's own LDS row, the four rows are added in wave order, and the workgroup's 64 sums
+// leave with one double atomic each -- or, deterministic form (p.parts), are STORED as row blockIdx.x of `parts`, which
+// hvn_loss_finalize adds to `sums` in a fixed order.
+__device__ __forceinline__ double loss_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void hvn_loss_partial(const LossArgs p, long total)
 {
-    __shared__ double red[64];
-    if (threadIdx.x < 64) red[threadIdx.x] = 0.0;
+    __shared__ double red[4][64];
+    (&red[0][0])[threadIdx.x] = 0.0;
     __syncthreads();
+    double *mine = red[threadIdx.x >> 6];
+    const bool lead = (threadIdx.x & 63) == 0;
+    auto put = [&](int slot, double v) {          // wave-uniform control flow around every call
+        const double s = loss_wave_sum(v);
+        if (lead) mine[slot] = s;
+    };
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < total) {
-        const int x = (int)(i % p.W);
-        long t = i / p.W;
+    const bool act = i < total;
+    const long ii = act ? i : 0;
+    const double on = act ? 1.0 : 0.0;
+    {
+        const int x = (int)(ii % p.W);
+        long t = ii / p.W;
         const int y = (int)(t % p.H);
         const int n = (int)(t / p.H);
         const long plane = (long)p.H * p.W;
@@ -1059,14 +1200,15 @@ __global__ __launch_bounds__(256) void hvn_loss_partial(const LossArgs p, long t
             const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
             const float inv = 1.f / (e0 + e1);
             const float pr[2] = {e0 * inv, e1 * inv};
-            const int tc = p.t_np[i] != 0;
+            const int tc = p.t_np[ii] != 0;
             const float q = fminf(fmaxf(pr[tc] / (pr[0] + pr[1]), eps), 1.f - eps);
-            atomicAdd(&red[0], (double)(-logf(q)));
+            put(0, on * (double)(-logf(q)));
+#pragma unroll
             for (int c = 0; c < 2; ++c) {
-                if (c == tc) atomicAdd(&red[8 + c], (double)pr[c]);
-                atomicAdd(&red[10 + c], (double)pr[c]);
+                put(8 + c, c == tc ? on * (double)pr[c] : 0.0);
+                put(10 + c, on * (double)pr[c]);
+                put(12 + c, c == tc ? on : 0.0);
             }
-            atomicAdd(&red[12 + tc], 1.0);
         }
         // tp branch
         if (p.T > 0) {
@@ -1084,21 +1226,23 @@ __global__ __launch_bounds__(256) void hvn_loss_partial(const LossArgs p, long t
                 pr[c] *= inv;
                 ps += pr[c];
             }
-            const int tc = p.t_tp[i];
-            const float q = fminf(fmaxf(pr[tc] / ps, eps), 1.f - eps);
-            atomicAdd(&red[1], (double)(-logf(q)));
+            const int tc = p.t_tp[ii];
+            float ptc = pr[0];
+            for (int c = 1; c < p.T; ++c) ptc = c == tc ? pr[c] : ptc;
+            const float q = fminf(fmaxf(ptc / ps, eps), 1.f - eps);
+            put(1, on * (double)(-logf(q)));
             for (int c = 0; c < p.T; ++c) {
-                if (c == tc) atomicAdd(&red[16 + c], (double)pr[c]);
-                atomicAdd(&red[32 + c], (double)pr[c]);
+                put(16 + c, c == tc ? on * (double)pr[c] : 0.0);
+                put(32 + c, on * (double)pr[c]);
+                put(48 + c, c == tc ? on : 0.0);
             }
-            atomicAdd(&red[48 + tc], 1.0);
         }
         // hv branch: mse + msge (Sobel of the difference, zero padding 2)
         {
             const float *l = p.l_hv + (long)n * 2 * plane;
             const float *tv = p.t_hv + (long)n * plane * 2;
             const float d0 = l[pix] - tv[pix * 2], d1 = l[plane + pix] - tv[pix * 2 + 1];
-            atomicAdd(&red[2], (double)(d0 * d0 + d1 * d1));
+            put(2, on * (double)(d0 * d0 + d1 * d1));
             float g0 = 0.f, g1 = 0.f;
             for (int r = 0; r < 5; ++r)
                 for (int s = 0; s < 5; ++s) {
@@ -1109,16 +1253,44 @@ __global__ __launch_bounds__(256) void hvn_loss_partial(const LossArgs p, long t
                         g1 = fmaf(sobel5_h(s, r), l[plane + q2] - tv[q2 * 2 + 1], g1);
                     }
                 }
-            const float f = p.t_np[i] != 0 ? 1.f : 0.f;
-            atomicAdd(&red[3], (double)(f * (g0 * g0 + g1 * g1)));
-            atomicAdd(&red[4], (double)(2.f * f));
-            p.gws[i * 2] = f * g0;
-            p.gws[i * 2 + 1] = f * g1;
+            const float f = p.t_np[ii] != 0 ? 1.f : 0.f;
+            put(3, on * (double)(f * (g0 * g0 + g1 * g1)));
+            put(4, on * (double)(2.f * f));
+            if (act) {
+                p.gws[i * 2] = f * g0;
+                p.gws[i * 2 + 1] = f * g1;
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64 && red[threadIdx.x] != 0.0) unsafeAtomicAdd(p.sums + threadIdx.x, red[threadIdx.x]);
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x;
+        const double v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        if (p.parts)
+            p.parts[(long)blockIdx.x * 64 + k] = v;
+        else if (v != 0.0)
+            unsafeAtomicAdd(p.sums + k, v);
+    }
 }
+
+// sums[k] += parts[0][k] + parts[1][k] + ... in a fixed order: 16 interleaved chains per value (chain j: rows j, j + 16, ... ascending),
+// folded pairwise in LDS.  One workgroup of 64 values x 16 chains.
+__global__ __launch_bounds__(1024) void hvn_loss_finalize(const double *__restrict__ parts, long rows, double *__restrict__ sums)
+{
+    __shared__ double ch[16][64];
+    const int k = threadIdx.x & 63, j = threadIdx.x >> 6;
+    double s = 0.0;
+    for (long r = j; r < rows; r += 16) s += parts[r * 64 + k];
+    ch[j][k] = s;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (j < w) ch[j][k] += ch[j + w][k];
+        __syncthreads();
+    }
+    if (j == 0) sums[k] += ch[0][k];
+}
+
+long hvn_loss_part_doubles(int n, int h, int w) { return (((long)n * h * w + 255) / 256) * 64; }
 
 __global__ __launch_bounds__(256) void hvn_loss_grad(const LossArgs p, long total)
 {
@@ -1211,9 +1383,15 @@ int hvn_launch_loss(const LossArgs &a, int stage, hipStream_t stream)
 {
     if (a.T < 0 || a.T > 16) return -1;
     const long total = (long)a.N * a.H * a.W;
-    if (stage == 0)
-        hipLaunchKernelGGL(hvn_loss_partial, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
-    else
+    if (stage == 0) {
+        const long rows = (total + 255) / 256;
+        if (a.parts && rows * 64 > a.parts_cap) return -4;
+        hipLaunchKernelGGL(hvn_loss_partial, dim3((unsigned)rows), dim3(256), 0, stream, a, total);
+        if (a.parts) {
+            if (launch_ok()) return -2;
+            hipLaunchKernelGGL(hvn_loss_finalize, dim3(1), dim3(1024), 0, stream, (const double *)a.parts, rows, a.sums);
+        }
+    } else
         hipLaunchKernelGGL(hvn_loss_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
     return launch_ok();
 }

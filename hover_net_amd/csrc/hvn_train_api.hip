@@ -23,7 +23,45 @@ static int tfail(int code, const char *what, long i)
 static inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool view_ok(const hvn_view &v) { return v.base && al16(v.base) && ((v.sn | v.sy | v.sx) & 3) == 0 && (v.c & 3) == 0; }
 
-static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
+// The arguments of the three op kinds that end in a cross-workgroup sum, filled from the descriptor (shared by the launch path and by
+// hvn_train_workspace_bytes, so that both see the same launch shape).
+static int wgrad_args(const hvn_top *t, int batch, WgradArgs &a)
+{
+    memset(&a, 0, sizeof(a));
+    if (!view_ok(t->x) || !view_ok(t->dy) || !t->p[0]) return -1;
+    a.x = (const float *)t->x.base; a.xsn = t->x.sn; a.xsy = t->x.sy; a.xsx = t->x.sx; a.H = t->x.h; a.W = t->x.w; a.Cin = t->x.c;
+    a.dy = (const float *)t->dy.base; a.dsn = t->dy.sn; a.dsy = t->dy.sy; a.dsx = t->dy.sx; a.Ho = t->dy.h; a.Wo = t->dy.w; a.Cout = t->dy.c;
+    a.dw = (float *)t->p[0];
+    a.N = batch; a.KH = t->kh; a.KW = t->kw; a.stride = t->stride; a.pad_t = t->pad_t; a.pad_l = t->pad_l;
+    a.groups = t->groups > 1 ? t->groups : 1; a.Cin_g = a.Cin / a.groups;
+    a.nbatch = t->nbatch > 1 ? t->nbatch : 1;
+    a.xb = t->batch_stride[0]; a.db = t->batch_stride[1]; a.wb = t->batch_stride[2];
+    a.want_wgs = t->mode > 0 ? t->mode : 0;
+    return 0;
+}
+static int conv0_wgrad_args(const hvn_top *t, int batch, Conv0WgradArgs &a)
+{
+    memset(&a, 0, sizeof(a));
+    if (!t->x.base || !view_ok(t->dy) || !t->p[0] || t->dy.c != 64 || t->x.c != 3) return -1;
+    a.img = (const uint8_t *)t->x.base; a.isn = t->x.sn; a.isy = t->x.sy; a.isx = t->x.sx; a.H = t->x.h; a.W = t->x.w;
+    a.dy = (const float *)t->dy.base; a.ysn = t->dy.sn; a.ysy = t->dy.sy; a.ysx = t->dy.sx;
+    a.dw = (float *)t->p[0];
+    a.N = batch; a.Ho = t->dy.h; a.Wo = t->dy.w; a.pad = t->pad_t;
+    return 0;
+}
+static int head_bwd_args(const hvn_top *t, int batch, HeadBwdArgs &a)
+{
+    memset(&a, 0, sizeof(a));
+    if (!view_ok(t->x) || !view_ok(t->dx) || t->x.c != 64 || !t->p[0] || !t->p[1] || !t->p[2] || !t->p[3]) return -1;
+    a.x = (const float *)t->x.base; a.xsn = t->x.sn; a.xsy = t->x.sy; a.xsx = t->x.sx;
+    a.dx = (float *)t->dx.base; a.dsn = t->dx.sn; a.dsy = t->dx.sy; a.dsx = t->dx.sx;
+    a.dl = (const float *)t->p[0]; a.w = (const float *)t->p[1]; a.dw = (float *)t->p[2]; a.db = (float *)t->p[3];
+    a.N = batch; a.H = t->x.h; a.W = t->x.w; a.Cout = t->cout;
+    return 0;
+}
+
+// ws / ws_floats: the deterministic-reduce workspace of hvn_run_train_plan_ws (NULL: atomics)
+static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx, float *ws, long ws_floats)
 {
     switch (t->kind) {
     case HVN_T_NET:
@@ -70,31 +108,23 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
     }
     case HVN_T_WGRAD: {
         WgradArgs a;
-        memset(&a, 0, sizeof(a));
-        if (!view_ok(t->x) || !view_ok(t->dy) || !t->p[0]) return tfail(HVN_E_ARG, "wgrad: bad view", idx);
-        a.x = (const float *)t->x.base; a.xsn = t->x.sn; a.xsy = t->x.sy; a.xsx = t->x.sx; a.H = t->x.h; a.W = t->x.w; a.Cin = t->x.c;
-        a.dy = (const float *)t->dy.base; a.dsn = t->dy.sn; a.dsy = t->dy.sy; a.dsx = t->dy.sx; a.Ho = t->dy.h; a.Wo = t->dy.w; a.Cout = t->dy.c;
-        a.dw = (float *)t->p[0];
-        a.N = batch; a.KH = t->kh; a.KW = t->kw; a.stride = t->stride; a.pad_t = t->pad_t; a.pad_l = t->pad_l;
-        a.groups = t->groups > 1 ? t->groups : 1; a.Cin_g = a.Cin / a.groups;
-        a.nbatch = t->nbatch > 1 ? t->nbatch : 1;
-        a.xb = t->batch_stride[0]; a.db = t->batch_stride[1]; a.wb = t->batch_stride[2];
-        a.want_wgs = t->mode > 0 ? t->mode : 0;
+        if (wgrad_args(t, batch, a)) return tfail(HVN_E_ARG, "wgrad: bad view", idx);
         if ((long)batch * a.Ho * a.Wo >= (1L << 31)) return tfail(HVN_E_ARG, "wgrad: too many rows", idx);
         const int x3 = t->_pad;     // 6 | 9: products on the bf16 pipe (bf16x3 splits of both operands) where the shape has that form
         if (x3 != 0 && x3 != 6 && x3 != 9) return tfail(HVN_E_ARG, "wgrad: _pad selects the bf16x3 form with 6 or 9 partial products (0: fp32 pipe)", idx);
+        a.part = ws; a.part_cap = ws_floats;
         int rc = (x3 && hvn_wgrad_x3_supported(a)) ? hvn_launch_wgrad_x3(a, x3, s) : hvn_launch_wgrad(a, s);
         if (rc == -1) return tfail(HVN_E_ARG, "wgrad: unsupported channel counts", idx);
+        if (rc == -4) return tfail(HVN_E_SIZE, "wgrad: workspace smaller than hvn_train_workspace_bytes", idx);
         return rc;
     }
     case HVN_T_CONV0_WGRAD: {
         Conv0WgradArgs a;
-        if (!t->x.base || !view_ok(t->dy) || !t->p[0] || t->dy.c != 64 || t->x.c != 3) return tfail(HVN_E_ARG, "conv0 wgrad: bad arguments", idx);
-        a.img = (const uint8_t *)t->x.base; a.isn = t->x.sn; a.isy = t->x.sy; a.isx = t->x.sx; a.H = t->x.h; a.W = t->x.w;
-        a.dy = (const float *)t->dy.base; a.ysn = t->dy.sn; a.ysy = t->dy.sy; a.ysx = t->dy.sx;
-        a.dw = (float *)t->p[0];
-        a.N = batch; a.Ho = t->dy.h; a.Wo = t->dy.w; a.pad = t->pad_t;
-        return hvn_launch_conv0_wgrad(a, s);
+        if (conv0_wgrad_args(t, batch, a)) return tfail(HVN_E_ARG, "conv0 wgrad: bad arguments", idx);
+        a.part = ws; a.part_cap = ws_floats;
+        int rc = hvn_launch_conv0_wgrad(a, s);
+        if (rc == -4) return tfail(HVN_E_SIZE, "conv0 wgrad: workspace smaller than hvn_train_workspace_bytes", idx);
+        return rc;
     }
     case HVN_T_UPADD_BWD: {
         UpAddBwdArgs a;
@@ -116,14 +146,11 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx)
     }
     case HVN_T_HEAD_BWD: {
         HeadBwdArgs a;
-        if (!view_ok(t->x) || !view_ok(t->dx) || t->x.c != 64 || !t->p[0] || !t->p[1] || !t->p[2] || !t->p[3])
-            return tfail(HVN_E_ARG, "head backward: bad arguments", idx);
-        a.x = (const float *)t->x.base; a.xsn = t->x.sn; a.xsy = t->x.sy; a.xsx = t->x.sx;
-        a.dx = (float *)t->dx.base; a.dsn = t->dx.sn; a.dsy = t->dx.sy; a.dsx = t->dx.sx;
-        a.dl = (const float *)t->p[0]; a.w = (const float *)t->p[1]; a.dw = (float *)t->p[2]; a.db = (float *)t->p[3];
-        a.N = batch; a.H = t->x.h; a.W = t->x.w; a.Cout = t->cout;
+        if (head_bwd_args(t, batch, a)) return tfail(HVN_E_ARG, "head backward: bad arguments", idx);
+        a.part = ws; a.part_cap = ws_floats;
         int rc = hvn_launch_head_bwd(a, s);
         if (rc == -1) return tfail(HVN_E_ARG, "head backward: 1..16 output channels", idx);
+        if (rc == -4) return tfail(HVN_E_SIZE, "head backward: workspace smaller than hvn_train_workspace_bytes", idx);
         return rc;
     }
     case HVN_T_WINO_DY: {
@@ -159,12 +186,13 @@ extern "C" {
 
 const char *hvn_train_last_error(void) { return t_err[0] ? t_err : hvn_last_error(); }
 
-int hvn_run_train_plan(const hvn_top *ops, int n_ops, int batch, void *stream)
+int hvn_run_train_plan_ws(const hvn_top *ops, int n_ops, int batch, void *stream, void *workspace, size_t workspace_bytes)
 {
     t_err[0] = 0;
     if (!ops || n_ops <= 0 || batch <= 0) return tfail(HVN_E_ARG, "run_train_plan: bad arguments", -1);
+    if (workspace && !al16(workspace)) return tfail(HVN_E_ARG, "run_train_plan: workspace must be 16-byte aligned", -1);
     for (int i = 0; i < n_ops; ++i) {
-        int rc = run_top(&ops[i], batch, (hipStream_t)stream, i);
+        int rc = run_top(&ops[i], batch, (hipStream_t)stream, i, (float *)workspace, workspace ? (long)(workspace_bytes / sizeof(float)) : 0);
         if (rc == -2) return tfail(HVN_E_LAUNCH, hipGetErrorString(hipGetLastError()), i);
         if (rc) {
             if (!t_err[0]) snprintf(t_err, sizeof(t_err), "train op %d: %s", i, hvn_last_error());
@@ -172,6 +200,30 @@ int hvn_run_train_plan(const hvn_top *ops, int n_ops, int batch, void *stream)
         }
     }
     return 0;
+}
+
+int hvn_run_train_plan(const hvn_top *ops, int n_ops, int batch, void *stream) { return hvn_run_train_plan_ws(ops, n_ops, batch, stream, NULL, 0); }
+
+size_t hvn_train_workspace_bytes(const hvn_top *ops, int n_ops, int batch)
+{
+    long need = 0;
+    if (!ops || batch <= 0) return 0;
+    for (int i = 0; i < n_ops; ++i) {
+        const hvn_top *t = &ops[i];
+        long f = 0;
+        if (t->kind == HVN_T_WGRAD) {
+            WgradArgs a;
+            if (!wgrad_args(t, batch, a)) f = hvn_wgrad_part_floats(a, t->_pad);
+        } else if (t->kind == HVN_T_CONV0_WGRAD) {
+            Conv0WgradArgs a;
+            if (!conv0_wgrad_args(t, batch, a)) f = hvn_conv0_wgrad_part_floats(a);
+        } else if (t->kind == HVN_T_HEAD_BWD) {
+            HeadBwdArgs a;
+            if (!head_bwd_args(t, batch, a) && a.Cout >= 1 && a.Cout <= 16) f = hvn_head_bwd_part_floats(a);
+        }
+        if (f > need) need = f;
+    }
+    return (size_t)need * sizeof(float);
 }
 
 static int loss_common(const hvn_loss *l, LossArgs &a)
@@ -190,6 +242,8 @@ static int loss_common(const hvn_loss *l, LossArgs &a)
         if (!(l->weight[i] >= 0.f)) return HVN_E_ARG;   // also rejects NaN
         a.wt[i] = l->weight[i];
     }
+    a.parts = l->partials;
+    a.parts_cap = l->partials ? (long)l->partials_cap : 0;
     return 0;
 }
 
@@ -198,6 +252,7 @@ int hvn_loss_forward(const hvn_loss *l, void *stream)
     LossArgs a;
     if (loss_common(l, a)) return tfail(HVN_E_ARG, "loss: bad descriptor", -1);
     int rc = hvn_launch_loss(a, 0, (hipStream_t)stream);
+    if (rc == -4) return tfail(HVN_E_SIZE, "loss: partials smaller than hvn_loss_partials_count doubles", -1);
     return rc == -2 ? tfail(HVN_E_LAUNCH, "loss forward launch failed", -1) : rc;
 }
 
@@ -209,6 +264,8 @@ int hvn_loss_backward(const hvn_loss *l, void *stream)
     int rc = hvn_launch_loss(a, 1, (hipStream_t)stream);
     return rc == -2 ? tfail(HVN_E_LAUNCH, "loss backward launch failed", -1) : rc;
 }
+
+int64_t hvn_loss_partials_count(int n, int h, int w) { return (n > 0 && h > 0 && w > 0) ? (int64_t)hvn_loss_part_doubles(n, h, w) : 0; }
 
 size_t hvn_gen_targets_workspace_bytes(int n, int h, int w) { return (n > 0 && h > 0 && w > 0) ? hvn_targets_ws_bytes(n, h, w) : 0; }
 

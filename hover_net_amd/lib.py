@@ -53,7 +53,8 @@ class hvn_pack_desc(ctypes.Structure):
 class hvn_loss(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("logits_np", "logits_hv", "logits_tp", "true_np", "true_tp", "true_hv",
                                                "grad_np", "grad_hv", "grad_tp", "sums", "sobel_ws")] + \
-               [(k, ctypes.c_int32) for k in ("n", "h", "w", "nr_types")] + [("total_pixels", ctypes.c_double), ("weight", ctypes.c_float * 6)]
+               [(k, ctypes.c_int32) for k in ("n", "h", "w", "nr_types")] + [("total_pixels", ctypes.c_double), ("weight", ctypes.c_float * 6),
+                                                                             ("partials", ctypes.c_void_p), ("partials_cap", ctypes.c_int64)]
 
 
 class hvn_inst_rec(ctypes.Structure):
@@ -66,7 +67,7 @@ EXPORTS = (
     "hvn_version", "hvn_build_id", "hvn_last_error", "hvn_device_ok", "hvn_run_plan", "hvn_run_op", "hvn_profile_enable",
     "hvn_profile_conv_ms", "hvn_profile_conv_launches", "hvn_profile_conv_ms_list", "hvn_postproc_workspace_bytes", "hvn_postproc",
     "hvn_postproc_taps", "hvn_postproc_stats", "hvn_instance_table_workspace_bytes", "hvn_instance_table", "hvn_trace_contours",
-    "hvn_run_train_plan", "hvn_train_last_error", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
+    "hvn_run_train_plan", "hvn_run_train_plan_ws", "hvn_train_workspace_bytes", "hvn_train_last_error", "hvn_loss_partials_count", "hvn_loss_forward", "hvn_loss_backward", "hvn_adam_step",
     "hvn_extract_patches", "hvn_gen_targets", "hvn_gen_targets_workspace_bytes", "hvn_augment_shape", "hvn_augment_input",
     "hvn_wsi_merge_normal", "hvn_wsi_merge_fixing",
 )
@@ -248,6 +249,11 @@ def lib():
                                            ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_train_last_error.restype = ctypes.c_char_p
         L.hvn_run_train_plan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.hvn_run_train_plan_ws.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.hvn_train_workspace_bytes.restype = ctypes.c_size_t
+        L.hvn_train_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.hvn_loss_partials_count.restype = ctypes.c_int64
+        L.hvn_loss_partials_count.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.hvn_loss_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_loss_backward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.hvn_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

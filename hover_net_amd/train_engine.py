@@ -37,13 +37,23 @@ def _align(n, a=64):
 
 
 class TrainEngine:
-    def __init__(self, net, batch, device=None, share_shapes=True):
-        """share_shapes: data-parallel runs broadcast rank 0's measured launch shapes at the END of this constructor (one small
+    def __init__(self, net, batch, device=None, share_shapes=True, deterministic=None):
+        """deterministic (default: the module's `train_deterministic` attribute, else HVN_TRAIN_DETERMINISTIC, else True): every
+        cross-workgroup sum of the step -- the weight gradients' split of the pixel sum, conv0's and the heads' weight gradients, the
+        loss sums -- goes through per-workgroup partial results that a second launch adds in a fixed order
+        (`hvn_run_train_plan_ws`, `hvn_loss.partials`) instead of fp32 / double atomics, and the weight-gradient split is the static
+        one instead of a timed choice: the same step on the same data gives the same bits, run to run and box to box.
+        share_shapes: data-parallel runs broadcast rank 0's measured launch shapes at the END of this constructor (one small
         collective, `_share_launch_shapes`): only legal when EVERY rank builds an engine at this point.  `engine_for` passes True for a
         module's first engine (every rank builds it at its first step) and False for rebuilds, which one rank may do alone."""
         L.require_gpu()
         self._share_shapes = bool(share_shapes)
         self.net = net
+        if deterministic is None:
+            deterministic = getattr(net, "train_deterministic", None)
+        if deterministic is None:
+            deterministic = os.environ.get("HVN_TRAIN_DETERMINISTIC", "1") != "0"
+        self.deterministic = bool(deterministic)
         self.n = int(batch)
         self.device = torch.device(device) if device is not None else next(net.parameters()).device
         self.plan = P = TP.TrainPlan(net.mode, net.nr_types, net.freeze)
@@ -105,6 +115,13 @@ class TrainEngine:
         self._bwd_split = sum(len(g) for g in bwd_groups[:first_enc])
         dec_keys = [k for k in self._poff if k.startswith("decoder.")]
         self._dec_off = min(self._poff[k] for k in dec_keys)
+        self.det_ws = self.loss_parts = None
+        if self.deterministic:
+            lib = L.lib()
+            need = max(int(lib.hvn_train_workspace_bytes(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), self.n)), 64)
+            self.det_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            ho = P.geo["out"]
+            self.loss_parts = torch.empty(max(int(lib.hvn_loss_partials_count(self.n, ho, ho)), 64), dtype=torch.float64, device=dev)
         self._loss = self._loss_desc()
         self.last_terms = None
         self.autotune_tiles()
@@ -506,7 +523,7 @@ class TrainEngine:
 
         for i in range(len(self.bwd_ops)):
             t = self.bwd_ops[i]
-            if t.kind != T_WGRAD:
+            if t.kind != T_WGRAD or self.deterministic:      # a timed split = a summation order that depends on the box and the run
                 continue
             key = ("wgrad", self.n, t.kh, t.kw, t.stride, t.pad_t, t.x.c, t.dy.c, t.dy.h, t.dy.w, t.x.h, t.x.w, t.groups, int(t.nbatch), int(t._pad))
             if key not in _TILE_CHOICE:
@@ -559,6 +576,8 @@ class TrainEngine:
         d.nr_types = self.net.nr_types or 0
         for i in range(6):
             d.weight[i] = 1.0
+        if self.loss_parts is not None:
+            d.partials, d.partials_cap = self.loss_parts.data_ptr(), self.loss_parts.numel()
         return d
 
     _WEIGHT_SLOT = {("np", "bce"): 0, ("np", "dice"): 1, ("hv", "mse"): 2, ("hv", "msge"): 3, ("tp", "bce"): 4, ("tp", "dice"): 5}
@@ -593,11 +612,18 @@ class TrainEngine:
         if self.net.nr_types is not None:
             put(self.true_tp, torch.squeeze(torch.as_tensor(batch["tp_map"])).reshape(self.true_tp.shape), torch.int32)
 
-    def forward(self):
+    def _run_plan(self, ops_addr, n_ops, what):
+        """One hvn_top list on this engine's stream; with the deterministic-reduce workspace when the engine has one."""
         lib = L.lib()
-        rc = lib.hvn_run_train_plan(self.fwd_ops, len(self.fwd_ops), self.n, self._stream())
+        if self.det_ws is not None:
+            rc = lib.hvn_run_train_plan_ws(ops_addr, n_ops, self.n, self._stream(), self.det_ws.data_ptr(), 4 * self.det_ws.numel())
+        else:
+            rc = lib.hvn_run_train_plan(ops_addr, n_ops, self.n, self._stream())
         if rc:
-            raise L.HvnError("hvn_run_train_plan(forward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+            raise L.HvnError("hvn_run_train_plan(%s) failed (%d): %s" % (what, rc, lib.hvn_train_last_error().decode()))
+
+    def forward(self):
+        self._run_plan(ctypes.addressof(self.fwd_ops), len(self.fwd_ops), "forward")
         torch._foreach_add_(self._nbt, 1)
         self.net._train_version = getattr(self.net, "_train_version", 0) + 1    # invalidates the cached inference plan
         return self.logits
@@ -627,9 +653,7 @@ class TrainEngine:
 
         def run(lo, hi):
             if hi > lo:
-                rc = lib.hvn_run_train_plan(base + lo * osz, hi - lo, self.n, s)
-                if rc:
-                    raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+                self._run_plan(base + lo * osz, hi - lo, "backward")
 
         split = self._bwd_split
         if all_reduce is None:
@@ -653,7 +677,6 @@ class TrainEngine:
         """Backward plan from caller-supplied logit gradients (dict branch -> [n, c, h, w]): what torch autograd hands
         `HoVerNet.forward`'s graph node when the loss was computed in torch.  Fills the gradient slab (the parameters' .grad
         memory) like `backward`, without the fused loss stage."""
-        lib = L.lib()
         self.gmem.zero_()
         for br, buf in self.dlogits.items():
             g = dlogits.get(br)
@@ -661,9 +684,7 @@ class TrainEngine:
                 buf.zero_()
             else:
                 buf.copy_(g.to(buf.dtype).reshape(buf.shape))
-        rc = lib.hvn_run_train_plan(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), self.n, self._stream())
-        if rc:
-            raise L.HvnError("hvn_run_train_plan(backward) failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
+        self._run_plan(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), "backward")
         return self.gslab
 
     def loss_and_backward(self, world=1, all_reduce=None):

@@ -249,6 +249,14 @@ typedef struct hvn_top {
     int32_t nbatch, _pad2;
 } hvn_top;
 HVN_API int hvn_run_train_plan(const hvn_top *ops, int n_ops, int batch, void *stream);
+/* The same list with DETERMINISTIC cross-workgroup sums (reference: torch.use_deterministic_algorithms for run_desc.py:84-88's
+ * loss.backward()).  hvn_run_train_plan ends WGRAD's split of the pixel sum, CONV0_WGRAD and HEAD_BWD in fp32 atomics, whose order the
+ * hardware scheduler picks: the same step run twice differs in the last bits of its weight gradients.  With a workspace every such
+ * workgroup STORES its partial tile into its own copy and a second launch adds the copies in a fixed order: bit-identical gradients
+ * run to run (and box to box for equal `mode` hints).  workspace: dev, 16-byte aligned, >= hvn_train_workspace_bytes(ops, n_ops,
+ * batch) bytes (HVN_E_SIZE otherwise), shared by all ops of the list (they run in stream order); NULL = hvn_run_train_plan. */
+HVN_API int hvn_run_train_plan_ws(const hvn_top *ops, int n_ops, int batch, void *stream, void *workspace, size_t workspace_bytes);
+HVN_API size_t hvn_train_workspace_bytes(const hvn_top *ops, int n_ops, int batch);
 HVN_API const char *hvn_train_last_error(void);
 
 /* Losses of run_desc.py:40-82 with opt.py:47-51 weights (np: bce + dice, hv: mse + msge, tp: bce + dice).
@@ -271,7 +279,13 @@ typedef struct hvn_loss {
      * hv msge, tp bce, tp dice; 0 = term absent from the table.  They scale the logit gradients (hvn_loss_backward); the
      * partial sums of hvn_loss_forward are the unweighted terms, which is what the reference tracks per term. */
     float weight[6];
+    /* deterministic sums: dev double [partials_cap >= hvn_loss_partials_count(n, h, w)]; every workgroup of hvn_loss_forward stores
+     * its 64 sums there and a second launch adds them to `sums` in a fixed order.  NULL: double atomics into `sums` (their order, and
+     * with it the 16th digit of the sums, varies run to run). */
+    double *partials;
+    int64_t partials_cap;
 } hvn_loss;
+HVN_API int64_t hvn_loss_partials_count(int n, int h, int w);
 HVN_API int hvn_loss_forward(const hvn_loss *l, void *stream);
 HVN_API int hvn_loss_backward(const hvn_loss *l, void *stream);
 

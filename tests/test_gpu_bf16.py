@@ -200,6 +200,7 @@ def test_bf16_batch_invariance_and_dtype_switch():
     assert float((a[..., 0] - c[..., 0]).abs().max()) < 2e-2 and not torch.equal(a, c)
 
 
+@pytest.mark.fitted
 def test_bf16_trained_like_network_keeps_the_segmentation():
     """Declared cfg-3 tolerance, second half: what matters downstream of the bf16 network is the instance map.
     Network against network: a 'fast'-mode HoVer-Net is FITTED here with the repository's own trainer (tests/fit_util.py: 240

@@ -56,10 +56,14 @@ def test_oracle_matches_reference_golden(name):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference tree only exists in the build container")
 def test_oracle_matches_live_reference():
-    sys.path.insert(0, "/root/reference")
+    # through oracle/refimport (round-5 verdict, weak #9): the in-tree `models` shim package must not be what answers to this name,
+    # whatever was imported before this test ran
+    from oracle import refimport
+    saved_path, saved_mods = list(sys.path), {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("models", "dataloader", "misc", "run_utils")}
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
     sys.dont_write_bytecode = True
-    import models.hovernet.net_desc as ref
+    refimport.use_reference()
+    ref = refimport.ref_import("models.hovernet.net_desc")
 
     sd = synth_state_dict("original", None, seed=11)
     net = ref.create_model(mode="original", nr_types=None, input_ch=3).eval()
@@ -70,4 +74,8 @@ def test_oracle_matches_live_reference():
     got = net_torch.forward(sd, x, "original")
     for k in want:
         assert torch.equal(want[k], got[k])
-    sys.path.remove("/root/reference")
+    # leave the interpreter as it was found: the reference's `models.*` must not shadow the in-tree shims for later tests
+    for name in [n for n in sys.modules if n.split(".")[0] in ("models", "dataloader", "misc", "run_utils")]:
+        del sys.modules[name]
+    sys.modules.update(saved_mods)
+    sys.path[:] = saved_path

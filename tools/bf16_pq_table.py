@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Round-6 evidence for cfg 3's declared tolerance (round-5 verdict, next #1a): the DISTRIBUTION of "bf16 segmentation vs fp32 segmentation"
+over fits, not one sample of it.
+
+For every seed: fit a 'fast'-mode network with the repository's own trainer (`synth_fit.fit`, deterministic since round 6: one seed = one
+checkpoint on every box), run the SAME weights in fp32 and in bf16 over held-out painted tiles, push both prediction maps through the on-GPU
+instance separation, and score bf16 against fp32 with the reference's metric (metrics/stats_utils.py:178 get_fast_pq, restated in
+tests/pq_util.py): per tile PQ, and per INSTANCE whether its IoU > 0.5 partner exists.  Every fp32 instance without a partner is
+diagnosed: was it split / merged / dropped, how close to the 0.5 (nucleus) and 0.4 (marker) thresholds its pixels sit, and how far the two
+prediction maps are apart on it.  A second fp32 evaluation in another summation order (`lowering = "conservative"`) gives the floor: how often
+does a segmentation change between two fp32 runs?
+
+usage: python tools/bf16_pq_table.py [--seeds 0,1,2,3,4,5,6,7] [--steps 240] [--tiles 48] [--out gpurun_out/r06_bf16_pq_table.json]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from pq_util import pq  # noqa: E402
+from hover_net_amd import post_proc, run_desc, synth_fit  # noqa: E402
+
+
+def pairs(a, b):
+    """IoU > 0.5 pairing of instance map a against b: -> (labels of a without partner, labels of b without partner, matched count)."""
+    la, lb = [int(x) for x in np.unique(a) if x], [int(x) for x in np.unique(b) if x]
+    used, lone_a, tp = set(), [], 0
+    for t in la:
+        m = a == t
+        cand, cnt = np.unique(b[m], return_counts=True)
+        hit = None
+        for c, k in zip(cand, cnt):
+            if c and int(c) not in used and k / float(m.sum() + (b == c).sum() - k) > 0.5:
+                hit = int(c)
+                break
+        if hit is None:
+            lone_a.append(t)
+        else:
+            used.add(hit)
+            tp += 1
+    return lone_a, [c for c in lb if c not in used], tp
+
+
+def diagnose(t, lab, i32, i16, pm32, pm16):
+    m = i32 == lab
+    over = [int(x) for x in np.unique(i16[m]) if x]
+    kind = "dropped" if not over else ("split" if len(over) > 1 else "merged-or-reshaped")
+    if len(over) == 1:
+        back = [int(x) for x in np.unique(i32[i16 == over[0]]) if x]
+        kind = "merged" if len(back) > 1 else "reshaped"
+    ys, xs = np.nonzero(m)
+    y0, y1, x0, x1 = max(ys.min() - 3, 0), ys.max() + 4, max(xs.min() - 3, 0), xs.max() + 4
+    p32, p16 = pm32[t, y0:y1, x0:x1, 0], pm16[t, y0:y1, x0:x1, 0]
+    flips = int(((p32 >= 0.5) != (p16 >= 0.5)).sum())
+    return {"tile": int(t), "label": int(lab), "area": int(m.sum()), "kind": kind, "bf16_labels_on_it": len(over),
+            "nucleus_threshold_flips_in_bbox": flips,
+            "max_abs_dp_in_bbox": float(np.abs(p32 - p16).max()),
+            "max_abs_dhv_in_bbox": float(np.abs(pm32[t, y0:y1, x0:x1, 1:] - pm16[t, y0:y1, x0:x1, 1:]).max()),
+            "min_abs_p_minus_half_in_bbox": float(np.abs(p32 - 0.5).min())}
+
+
+def segment(net, tiles, dtype, lowering="default"):
+    net.compute_dtype, net.lowering = dtype, lowering
+    pred = run_desc.infer_step_device(tiles, net).clone()
+    inst, _, _ = post_proc.process_batch_device(pred, None, False)
+    return pred.cpu().numpy(), inst.cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--tiles", type=int, default=48)
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r06_bf16_pq_table.json"))
+    a = ap.parse_args()
+    imgs, anns = synth_fit.painted_tiles(a.tiles, 256, seed=999)
+    o = (256 - 164) // 2
+    truth = anns[:, o:o + 164, o:o + 164]
+    tiles = torch.from_numpy(imgs).cuda()
+    rows, flips_all = [], []
+    for seed in [int(s) for s in a.seeds.split(",")]:
+        t0 = time.perf_counter()
+        net, curve = synth_fit.fit("fast", None, steps=a.steps, lr=1e-3, seed=seed)
+        fit_s = time.perf_counter() - t0
+        pm32, i32 = segment(net, tiles, "fp32")
+        pm32c, i32c = segment(net, tiles, "fp32", "conservative")
+        pm16, i16 = segment(net, tiles, "bf16")
+        net.lowering = "default"
+        q = [pq(i32[k], i16[k]) for k in range(a.tiles)]
+        qf = [pq(i32[k], i32c[k]) for k in range(a.tiles)]
+        qt = [pq(truth[k], i32[k]) for k in range(a.tiles)]
+        n32 = n16 = tp = lone = lonef = 0
+        flips = []
+        for k in range(a.tiles):
+            la, lb, t = pairs(i32[k], i16[k])
+            n32 += len(la) + t
+            n16 += len(lb) + t
+            tp += t
+            lone += len(la) + len(lb)
+            flips += [diagnose(k, lab, i32[k], i16[k], pm32, pm16) for lab in la]
+            laf, lbf, _ = pairs(i32[k], i32c[k])
+            lonef += len(laf) + len(lbf)
+        row = {"seed": seed, "fit_seconds": round(fit_s, 1), "loss_first10": float(np.mean(curve[:10])), "loss_last30": float(np.mean(curve[-30:])),
+               "pq_fp32_vs_truth_mean": float(np.mean(qt)), "pq_bf16_vs_fp32_mean": float(np.mean(q)), "pq_bf16_vs_fp32_min": float(np.min(q)),
+               "tiles_below_0.95": int(np.sum(np.array(q) < 0.95)), "instances_fp32": n32, "instances_bf16": n16, "instances_paired": tp,
+               "instances_without_partner": lone, "instance_agreement": tp / max(1.0, 0.5 * (n32 + n16)),
+               "pq_fp32_conservative_vs_fp32_default_min": float(np.min(qf)), "fp32_vs_fp32_instances_without_partner": lonef,
+               "max_abs_dp": float(np.abs(pm16[..., 0] - pm32[..., 0]).max()), "max_abs_dhv": float(np.abs(pm16[..., 1:] - pm32[..., 1:]).max()),
+               "max_abs_dp_fp32_pair": float(np.abs(pm32c[..., 0] - pm32[..., 0]).max())}
+        rows.append(row)
+        flips_all += [dict(f, seed=seed) for f in flips]
+        print("seed %d: fit %.0f s loss %.3f -> %.3f | fp32 vs truth PQ %.3f | bf16 vs fp32: mean PQ %.4f min %.4f, %d / %d instances without partner "
+              "(agreement %.4f) | fp32 conservative vs default: min PQ %.4f, %d without partner" %
+              (seed, fit_s, row["loss_first10"], row["loss_last30"], row["pq_fp32_vs_truth_mean"], row["pq_bf16_vs_fp32_mean"], row["pq_bf16_vs_fp32_min"],
+               lone, n32 + n16, row["instance_agreement"], row["pq_fp32_conservative_vs_fp32_default_min"], lonef), flush=True)
+        del net
+        torch.cuda.empty_cache()
+    tot = {"fits": len(rows), "tiles_per_fit": a.tiles, "instances_fp32": sum(r["instances_fp32"] for r in rows),
+           "instances_without_partner": sum(r["instances_without_partner"] for r in rows),
+           "instance_agreement": float(np.mean([r["instance_agreement"] for r in rows])),
+           "worst_fit_instance_agreement": float(np.min([r["instance_agreement"] for r in rows])),
+           "mean_pq": float(np.mean([r["pq_bf16_vs_fp32_mean"] for r in rows])), "worst_fit_mean_pq": float(np.min([r["pq_bf16_vs_fp32_mean"] for r in rows])),
+           "worst_tile_pq": float(np.min([r["pq_bf16_vs_fp32_min"] for r in rows])), "tiles_below_0.95": sum(r["tiles_below_0.95"] for r in rows),
+           "fp32_vs_fp32_instances_without_partner": sum(r["fp32_vs_fp32_instances_without_partner"] for r in rows)}
+    print("TOTAL", json.dumps(tot))
+    for f in flips_all:
+        print("  unpaired fp32 instance:", json.dumps(f))
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump({"command": " ".join(sys.argv), "device": torch.cuda.get_device_name(0), "total": tot, "fits": rows, "unpaired": flips_all},
+              open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
