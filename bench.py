@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip variants.train_step (BASELINE cfg 5: both phases of the training schedule)")
     ap.add_argument("--no-wsi-leg", action="store_true", help="skip variants.wsi_8k (BASELINE cfg 4 scaled to one GPU)")
     ap.add_argument("--wsi-size", type=int, default=8192)
+    ap.add_argument("--wsi-leg", action="store_true", help="run the whole-slide leg even with --no-variants (tests)")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct resident tile batches per rank the timed loop cycles through (round-5 verdict, next #7: rounds 1-5 timed the SAME 32 "
                          "tiles every step; the instance load then never changes and every cache sees the same addresses)")
@@ -800,6 +801,9 @@ def main():
         legs = {}
         for ph in (0, 1):
             r_ = train_bench.measure(ph, steps=5, warmup=2, mode=args.mode, nt=nt, device=dev)
+            if world == 1:          # the same step with rounds 1-5's reduce (fp32 atomics, timed weight-gradient splits): what determinism costs
+                a_ = train_bench.measure(ph, steps=3, warmup=2, mode=args.mode, nt=nt, device=dev, deterministic=False)
+                r_["atomic_reduce_ms_per_step"] = a_["ms_per_step"]
             if world > 1:
                 allr = [None] * world
                 dist.all_gather_object(allr, {k: r_[k] for k in ("ms_per_step", "forward_ms", "loss_backward_ms", "optimizer_ms", "allreduce_slab_alone_ms")})
@@ -811,9 +815,30 @@ def main():
             result.setdefault("variants", {})["train_step"] = dict(
                 legs, what="BASELINE cfg 5 on %d GPU(s): one training step (forward in train mode, the reference's loss table, backward, FusedAdam) of "
                            "phase 0 (frozen encoder, batch 16 per GPU) and phase 1 (all layers, batch 4 per GPU), CoNSeP '%s' mode, %s types, "
-                           "synthetic batch; 5 steps after 2 warm-up steps each; N > 1: SUM all-reduce of the loss partial sums and of the "
+                           "synthetic batch; 5 steps after 2 warm-up steps each; deterministic cross-workgroup sums (round 6 default; "
+                           "atomic_reduce_ms_per_step = the same step with fp32 atomics and timed weight-gradient splits); N > 1: SUM all-reduce of the loss partial sums and of the "
                            "gradient slab in two buckets inside the step (ms_per_step = slowest rank)" % (world, args.mode, nt))
-    if rank == 0 and world == 1 and not args.no_variants and not args.no_wsi_leg:
+    if world > 1 and (args.wsi_leg or not args.no_variants) and not args.no_wsi_leg:
+        # BASELINE cfg 4 on all ranks (round-5 verdict, next #4: the row-slab + halo all_to_all path of infer_wsi.py never ran in a bench):
+        # per rank stage 1 (own patch rows), the halo exchange, stage 2 (owner-post-processed tiles -> rank 0's sequential merge)
+        import wsi_bench
+
+        torch.cuda.empty_cache()
+        mine = wsi_bench.measure_dist(args.wsi_size, args.mode, nt, args.batch, device=dev)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            s1, s2 = max(a_["stage1_s"] for a_ in allr), max(a_["stage2_s"] for a_ in allr)
+            n_p = sum(a_["patches"] for a_ in allr)
+            result.setdefault("variants", {})["wsi_%dk" % (args.wsi_size // 1024)] = {
+                "slide": [args.wsi_size, args.wsi_size], "world_size": world, "patches": n_p, "stage1_s": s1, "patches_per_s": n_p / s1, "stage2_s": s2,
+                "instances": allr[0]["instances"], "per_rank": allr,
+                "what": "BASELINE cfg 4 on %d ranks: a synthetic %d^2 slide; the prediction map is OWNED by row slabs -- every rank predicts the patch rows of its "
+                        "slab (stage1_own_rows_s), receives the halo rows its stage-2 tiles reach into in ONE all_to_all_single (halo_exchange_s), "
+                        "post-processes the tiles whose rows it owns and sends the results to rank 0, which applies the sequential three-phase merge "
+                        "(stage2_s; infer/wsi.py:449-709).  stage1_s / stage2_s = slowest rank; stage 2 runs on a structured map written into each rank's "
+                        "rows (the random-init network emits no nuclei)" % (world, args.wsi_size)}
+    if rank == 0 and world == 1 and (args.wsi_leg or not args.no_variants) and not args.no_wsi_leg:
         import wsi_bench
 
         w_ = wsi_bench.measure(args.wsi_size, args.mode, nt, args.batch, "fp32", device=dev)

@@ -307,6 +307,7 @@ class Engine:
         import os
 
         lib = L.lib()
+        reps = max(1, int(os.environ.get("HVN_TUNE_REPS", reps)))       # (tests/conftest.py: 1 -- every candidate gives the same bits)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         osz = ctypes.sizeof(L.hvn_op)
@@ -415,6 +416,7 @@ class Engine:
         import os
 
         lib = L.lib()
+        reps = max(1, int(os.environ.get("HVN_TUNE_REPS", reps)))
         stream = torch.cuda.current_stream(self.device).cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         osz = ctypes.sizeof(L.hvn_op)

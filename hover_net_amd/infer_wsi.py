@@ -464,6 +464,7 @@ class WsiInference:
         it needs, predicts those patches and scatters them into its LOCAL tensor (slab + halo rows, 1 / world of the map).  The
         halo rows -- what its stage-2 tiles reach into the neighbours' slabs -- then arrive in one `all_to_all_single`.
         Returns the whole map as a tensor (one rank), or a `SlabMap` (as_slab=True; always on several ranks)."""
+        t_start = time.perf_counter()
         shape = np.array(slide.shape[:2])
         H, W = int(shape[0]), int(shape[1])
         dist, rank, world = infer_tile._dist()
@@ -516,8 +517,18 @@ class WsiInference:
             rows = (otl[:, 0, None] + ar - lo)[:, :, None].expand(-1, h, h)
             cols = (otl[:, 1, None] + ar)[:, None, :].expand(-1, h, h)
             local.t[rows, cols] = out.to(local.t.device)          # one scatter per chunk
+        tm = getattr(self, "timing", None)
+        if tm is not None and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+            tm["stage1_own_rows_s"] = time.perf_counter() - t_start
         if world > 1:
+            t_h = time.perf_counter()
             exchange_halo(local, need, bounds)
+            if tm is not None:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                tm["halo_exchange_s"] = time.perf_counter() - t_h
+                tm["halo_rows"] = int((hi - lo) - (bounds[rank + 1] - bounds[rank]))
         return local if (as_slab or world > 1) else local.t
 
     def _step(self, batch):

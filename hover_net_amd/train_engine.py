@@ -32,6 +32,22 @@ _TILE_CHOICE = {}       # (batch, launch shape) -> (choice, ms of the static cho
 WGRAD_TARGETS = (1536, 1024, 768, 512, 384)     # workgroups a weight-gradient launch may aim at; the first is the untuned default
 
 
+def static_wgrad_target(kh, kw):
+    """Workgroups a DETERMINISTIC weight-gradient launch aims at (hvn_top.mode): a function of the launch SHAPE only, because a timed
+    choice is a summation order that depends on the box and the run.  Read off `profiles/r06_wgrad_static_rule.txt` (tools/
+    wgrad_static_rule.py: every weight-gradient launch of phase 0 / phase 1 / the fit's 'fast' batch 8 timed at 7 targets through the
+    deterministic path): the 1x1 launches -- most of them, bf16x3 tiles of 128 x 128 -- are fastest at 768 on all three plans, the
+    multi-tap ones (3x3, grouped 5x5) at 1024 - 1536; the launcher's own default of 1536 was tuned for the atomic form.  Sum over the
+    launches of a step: 15.2 / 14.3 / 26.3 ms with this rule against 15.3 / 15.4 / 26.6 at 1536 everywhere and 14.5 / 13.7 / 24.6 with
+    every launch at its own best."""
+    return 1024 if kh * kw > 1 else 768
+
+
+def _tune_reps(default):
+    """Timings per candidate of the engines' timing passes (HVN_TUNE_REPS; tests/conftest.py sets 1: every candidate is bit-identical)."""
+    return max(1, int(os.environ.get("HVN_TUNE_REPS", default)))
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 
@@ -410,6 +426,7 @@ class TrainEngine:
             t.p[0] = self._at_ptr
             g = L.hvn_top()
             g.kind, g.kh, g.kw, g.stride, g.groups, g.nbatch = T_WGRAD, 1, 1, 1, 1, 64
+            g.mode = static_wgrad_target(1, 1) if self.deterministic else 0
             g._pad = self.wgrad_x3
             g.x = self._tview(self.wino_vs[op.wkey].data_ptr(), t1, 1, cin)
             g.dy = self._tview(self.wino_m.data_ptr(), t1, 1, cout)
@@ -421,6 +438,7 @@ class TrainEngine:
             return [t, g, w]
         if op.kind == "wgrad":
             t.kind = T_WGRAD
+            t.mode = static_wgrad_target(op.kh, op.kw) if self.deterministic else 0
             t._pad = self.wgrad_x3 if op.groups <= 1 else 0
             t.kh, t.kw, t.stride, t.pad_t, t.pad_l, t.groups = op.kh, op.kw, op.stride, op.pad[0], op.pad[0], op.groups
             t.x, t.dy = self._view(op.x), self._view(op.dy)
@@ -468,6 +486,7 @@ class TrainEngine:
             return
         lib = L.lib()
         stream = self._stream()
+        reps = _tune_reps(reps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
         def time_op(o):
@@ -491,6 +510,7 @@ class TrainEngine:
             cands = (128, 64) if o.tile_n == 128 else (64, 320)
             if (o.tile_n == 128 and o.act_dtype in (2, 3) and o.cout >= 128 and not o.pre_scale and os.environ.get("HVN_X3G", "1") != "0"):
                 cands = cands + (896, 640)                 # + the LDS-DMA forms of the bf16x3 convolution (csrc/hvn_conv_x3g.hip): same packing, same bits
+            key = key + (cands, str(self.device))          # (round-5 advisor: another candidate set / device is another question)
             if key not in _TILE_CHOICE:
                 t = {}
                 for tn in cands:

@@ -7,6 +7,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# The engines time bit-identical kernel forms per launch shape at build (Engine.autotune_tiles, TrainEngine.autotune_tiles); which form
+# wins is invisible in every result the tests look at, so one timing per candidate is enough here (the product default is 3).
+os.environ.setdefault("HVN_TUNE_REPS", "1")
 
 
 def pytest_configure(config):

@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.fitted]
 
 TOL = 1e-3
 # (HVN_WINOGRAD, HVN_WINOGRAD3_M, HVN_WINOGRAD3): decoder F(m,5) tile | encoder F(m,3) tile | 0 = no Winograd at all

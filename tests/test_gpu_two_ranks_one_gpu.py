@@ -98,7 +98,7 @@ def test_bench_step_on_two_ranks_sharing_the_gpu(launch):
     # launch = "torchrun": under the launcher, as the driver starts N > 1; "self": `python bench.py --gpus 2` alone -- the script becomes
     # its own launcher (the shape of the driver's N = 1 command).  The default (fitted) checkpoint path: rank 0 fits, the others receive it.
     args = [os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-variants",
-            "--no-roofline", "--fit-steps", "12"]
+            "--no-roofline", "--fit-steps", "12", "--wsi-leg", "--wsi-size", "4096"]
     cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                "--master-port", str(port)] if launch == "torchrun" else []) + args
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
@@ -110,3 +110,8 @@ def test_bench_step_on_two_ranks_sharing_the_gpu(launch):
     assert len(pr["step_ms"]) == 2 and len(pr["gather_ms"]) == 2 and all(t > 0 for t in pr["step_ms"]) and all(t >= 0 for t in pr["gather_ms"])
     assert d["config"]["instances_last_step"] > 0          # rank 0 holds the gathered results of both ranks
     assert d["config"]["checkpoint"]["kind"].startswith("fitted") and "rank 0 and broadcast" in d["config"]["checkpoint"]["kind"]
+    # round 6: BASELINE cfg 4 as a multi-rank leg -- row-slab ownership, ONE halo all_to_all, owner-post-processed tiles, rank 0's merge
+    w = d["variants"]["wsi_4k"]
+    assert w["world_size"] == 2 and len(w["per_rank"]) == 2 and w["patches"] == 49 * 49 and w["instances"] > 100
+    assert all(p["patches"] > 0 and p["stage1_s"] > 0 and p["stage2_s"] > 0 and p["halo_rows"] > 0 and p["halo_exchange_s"] > 0 for p in w["per_rank"])
+    assert all(p["map_rows_resident"] < 4096 for p in w["per_rank"])          # each rank held its slab + halo, not the map

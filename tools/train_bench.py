@@ -53,7 +53,7 @@ def conv_flops(eng, n):
     return af, ab, ef, eb
 
 
-def measure(phase, steps=10, warmup=3, mode="original", nt=5, device="cuda", seed_sd=None):
+def measure(phase, steps=10, warmup=3, mode="original", nt=5, device="cuda", seed_sd=None, deterministic=None):
     """One phase of the two-stage schedule (opt.py:23-142: phase 0 = frozen encoder, batch 16; phase 1 = all layers, batch 4) on `device`:
     a dict with ms per step split into forward / loss+backward / optimizer and the step's MFMA work.  With torch.distributed
     initialised (world > 1) the step is the data-parallel one of run_desc.train_step -- SUM all-reduce of the loss partial sums and of
@@ -66,7 +66,7 @@ def measure(phase, steps=10, warmup=3, mode="original", nt=5, device="cuda", see
     net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
     net.load_state_dict(synth_state_dict(mode, nt, seed=0) if seed_sd is None else seed_sd, strict=True)
     net = net.to(device)
-    eng = TrainEngine(net, bs)
+    eng = TrainEngine(net, bs, deterministic=deterministic)
     opt = FusedAdam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
     rank = dist.get_rank() if world > 1 else 0
     eng.load_batch(synth_train_batch(bs, mode, nt, seed=1 + rank))
@@ -108,7 +108,7 @@ def measure(phase, steps=10, warmup=3, mode="original", nt=5, device="cuda", see
            "algorithmic_gflop_forward": af / 1e9, "algorithmic_gflop_backward": ab / 1e9,
            "algorithmic_speedup": (af + ab) / (ef + eb),
            "timed_conv_launches": int(n_conv), "timed_conv_launch_ms": conv_ms, "timed_conv_launch_share_of_step": conv_ms / ms,
-           "plan_ops_per_step": len(eng.fwd_ops) + len(eng.bwd_ops),
+           "plan_ops_per_step": len(eng.fwd_ops) + len(eng.bwd_ops), "deterministic_reduce": bool(eng.deterministic),
            "gradient_slab_mb": slab_mb, "world_size": world,
            "loss": eng.loss_terms()["overall_loss"], "arena_gb": eng.arena.numel() * 4 / 1e9, "grad_gb": eng.gmem.numel() * 4 / 1e9}
     if world > 1:

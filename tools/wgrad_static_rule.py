@@ -20,7 +20,6 @@ TARGETS = (3072, 1536, 1024, 768, 512, 384, 256)
 
 
 def main():
-    os.environ["HVN_WGRAD_STATIC"] = "0"          # the rule under study off: mode 0 = the launcher's default
     lib = L.lib()
     seen = {}
     for tag, mode, nt, freeze, bs in (("phase0_b16", "original", 5, True, 16), ("phase1_b4", "original", 5, False, 4), ("fit_fast_b8", "fast", None, False, 8)):

@@ -78,6 +78,66 @@ def measure(size=8192, mode="original", nt=5, batch=32, dtype="fp32", skip_stage
     return out
 
 
+def _structured_rows(blk, lo, hi, W, device):
+    """Rows [lo, hi) of the structured S x W prediction map `measure` assembles (512^2 painted blocks, block (r + c) % 4 at block row r,
+    block column c): a function of ABSOLUTE coordinates, so every rank builds its own slab + halo rows without communication."""
+    out = torch.empty((hi - lo, W, blk.shape[-1]), dtype=torch.float32, device=device)
+    for r in range(lo // 512, (hi - 1) // 512 + 1):
+        y0, y1 = max(lo, r * 512), min(hi, (r + 1) * 512)
+        for c in range(-(-W // 512)):
+            x0, x1 = c * 512, min(W, (c + 1) * 512)
+            out[y0 - lo:y1 - lo, x0:x1] = blk[(r + c) % 4][y0 - r * 512:y1 - r * 512, :x1 - x0]
+    return out
+
+
+def measure_dist(size=8192, mode="original", nt=5, batch=32, device="cuda"):
+    """BASELINE cfg 4 on N ranks (torch.distributed initialised, one rank per GPU): `WsiInference.raw_prediction` -- every rank predicts the
+    patch rows of ITS row slab of the map and receives its halo rows in ONE all_to_all -- then `stitch_instances` on the slab-resident map
+    (tiles post-processed by the owner of their rows, results to rank 0, which applies the sequential three-phase merge).  Stage 2 runs on
+    a structured map (`measure`'s: the random-init network emits no nuclei), written into each rank's slab + halo rows locally.
+    Returns this rank's dict; the caller gathers them (bench.py: variants.wsi_Nk.per_rank).  Reference: infer/wsi.py:449-709."""
+    import torch.distributed as dist
+
+    S = size
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+    sd = synth_state_dict(mode, nt, seed=0)
+    sd["decoder.np.u0.conv.bias"] = torch.tensor([8.0, -8.0])
+    net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
+    net.load_state_dict(sd, strict=True)
+    net.max_batch = batch
+    net = net.to(device).eval()
+    tile = np.random.default_rng(0).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    slide = infer_wsi.TiledSlide(tile, (S, S))
+    wsi = infer_wsi.WsiInference(net, nr_types=nt, batch_size=batch)
+    mask = np.ones((S // 32, S // 32), np.uint8)
+    wsi.raw_prediction(infer_wsi.TiledSlide(tile, (1024 * max(1, world), 1024)), np.ones((32 * max(1, world), 32), np.uint8))   # warm-up (plan, arena, the collective)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wsi.timing = {}
+    t0 = time.perf_counter()
+    pm = wsi.raw_prediction(slide, mask, as_slab=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter() - t0
+    own_patches = int(wsi.stage1_patches)
+    lo, hi = pm.rows
+    blk = torch.from_numpy(synth_pred_maps(4, 512, 512, nt, seed=3, k_lo=2, k_hi=6)[0]).to(device)
+    pm.t.copy_(_structured_rows(blk, lo, hi, S, device))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    inst_map, info = wsi.stitch_instances(pm, mask, shape=(S, S))
+    torch.cuda.synchronize()
+    t2 = time.perf_counter() - t0
+    out = {"rank": rank, "stage1_s": t1, "stage1_own_rows_s": wsi.timing.get("stage1_own_rows_s"), "halo_exchange_s": wsi.timing.get("halo_exchange_s", 0.0),
+           "halo_rows": wsi.timing.get("halo_rows", 0), "map_rows_resident": int(wsi.map_rows_resident), "patches": own_patches,
+           "stage2_s": t2, "merge_s": wsi.timing.get("merge_s"), "instances": len(info) if info is not None else None}
+    del pm, inst_map, info, wsi, net
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=8192)
