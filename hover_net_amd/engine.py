@@ -124,6 +124,19 @@ def pack_conv_x3(w32):
     return np.stack(planes, axis=-2)
 
 
+def pack_conv_x3_device(w32, device):
+    """`pack_conv_x3` computed on the GPU (round 6: the numpy split of the ~150 M packed weights of a cfg-2 plan -- Winograd-domain tensors
+    included -- took 3 - 9 s of every engine build): the fp32 packing goes up as it is and the three planes are formed there with the same
+    round-to-nearest-even conversions (torch's float32 -> bfloat16 is the bit trick of `to_bf16_bits`; both differences are exact in
+    fp32).  -> flat int16 tensor [rows][3][32] on `device`, bit-equal to `pack_conv_x3(w32).ravel()` (tests/test_gpu_x3.py)."""
+    w = torch.from_numpy(np.ascontiguousarray(w32, np.float32).reshape(-1, 32)).to(device)
+    h = w.to(torch.bfloat16)
+    r = w - h.float()
+    m = r.to(torch.bfloat16)
+    l = (r - m.float()).to(torch.bfloat16)
+    return torch.stack((h, m, l), dim=1).view(torch.int16).reshape(-1)
+
+
 class Engine:
     def __init__(self, plan, max_batch=32, device="cuda", n_split=None, dtype="fp32", n_lanes=None):
         L.require_gpu()
@@ -201,15 +214,14 @@ class Engine:
                 w16.append((tot16, wb))
                 tot16 += (wb.size + 127) // 128 * 128
             elif self.dtype == "fp32" and op.kind in (PL.OP_CONV, PL.OP_CHAIN) and op.extra.get("x3"):
-                wb = pack_conv_x3(op.w).ravel()          # fp32 weights as three bf16 planes (csrc/hvn_conv_x3.hip)
+                # fp32 weights as three bf16 planes (csrc/hvn_conv_x3.hip), split on the device: (offset, fp32 packing) now, planes below
                 off16[i] = tot16
-                w16.append((tot16, wb))
-                tot16 += (wb.size + 127) // 128 * 128
+                w16.append((tot16, op.w, True))
+                tot16 += (3 * op.w.size + 127) // 128 * 128
                 if op.kind == PL.OP_CHAIN:               # + the second conv's (csrc/hvn_conv_chain_x3.hip)
-                    wb2 = pack_conv_x3(op.extra["w2"]).ravel()
                     off16[(i, "w2")] = tot16
-                    w16.append((tot16, wb2))
-                    tot16 += (wb2.size + 127) // 128 * 128
+                    w16.append((tot16, op.extra["w2"], True))
+                    tot16 += (3 * op.extra["w2"].size + 127) // 128 * 128
             else:
                 put((i, "w"), op.w)
             put((i, "bias"), op.bias)
@@ -230,10 +242,16 @@ class Engine:
         self._poff16 = off16
         self.params16 = None
         if tot16:
-            h16 = np.zeros(tot16, np.uint16)
-            for off, a in w16:
-                h16[off:off + a.size] = a
-            self.params16 = torch.from_numpy(h16.view(np.int16)).to(self.device)
+            if any(len(e) == 3 for e in w16):            # bf16x3: planes made on the device, one conv at a time
+                self.params16 = torch.zeros(tot16, dtype=torch.int16, device=self.device)
+                for off, w32, _ in w16:
+                    pl = pack_conv_x3_device(w32, self.device)
+                    self.params16[off:off + pl.numel()] = pl
+            else:
+                h16 = np.zeros(tot16, np.uint16)
+                for off, a in w16:
+                    h16[off:off + a.size] = a
+                self.params16 = torch.from_numpy(h16.view(np.int16)).to(self.device)
 
     def _pptr(self, i, name):
         off = self._poff.get((i, name))

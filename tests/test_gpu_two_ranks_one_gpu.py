@@ -112,6 +112,7 @@ def test_bench_step_on_two_ranks_sharing_the_gpu(launch):
     assert d["config"]["checkpoint"]["kind"].startswith("fitted") and "rank 0 and broadcast" in d["config"]["checkpoint"]["kind"]
     # round 6: BASELINE cfg 4 as a multi-rank leg -- row-slab ownership, ONE halo all_to_all, owner-post-processed tiles, rank 0's merge
     w = d["variants"]["wsi_4k"]
-    assert w["world_size"] == 2 and len(w["per_rank"]) == 2 and w["patches"] == 49 * 49 and w["instances"] > 100
-    assert all(p["patches"] > 0 and p["stage1_s"] > 0 and p["stage2_s"] > 0 and p["halo_rows"] > 0 and p["halo_exchange_s"] > 0 for p in w["per_rank"])
+    assert w["world_size"] == 2 and len(w["per_rank"]) == 2 and w["patches"] == sum(p["patches"] for p in w["per_rank"]) > 2000 and w["instances"] > 100
+    assert all(p["patches"] > 0 and p["stage1_s"] > 0 and p["stage2_s"] > 0 and p["halo_exchange_s"] > 0 for p in w["per_rank"])
+    assert sum(p["halo_rows"] for p in w["per_rank"]) > 0                      # (the last slab's tiles reach into nobody's rows)
     assert all(p["map_rows_resident"] < 4096 for p in w["per_rank"])          # each rank held its slab + halo, not the map

@@ -172,6 +172,17 @@ X3G_CASES = {
 }
 
 
+def test_device_split_of_the_weight_planes_equals_the_host_split():
+    """Engine._upload_params forms the bf16 planes of the fp32 weight packings on the GPU (round 6): bit-equal to engine.pack_conv_x3 (numpy),
+    whose arithmetic tests/test_x3_arithmetic.py pins on the CPU -- incl. values across the whole exponent range and exact ties."""
+    from hover_net_amd.engine import pack_conv_x3, pack_conv_x3_device
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((3, 64, 5, 9, 32)) * np.exp(rng.uniform(-60, 60, (3, 64, 5, 9, 32)))).astype(np.float32)
+    w[0, 0, 0, 0, :8] = np.float32([1.00390625, 1.01171875, -1.00390625, 0.0, -0.0, 2.0 ** -120, 3.0e38, -3.0e38])   # ties to even, zeros, the edges
+    got = pack_conv_x3_device(w, "cuda").cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, pack_conv_x3(w).ravel())
+
+
 @pytest.mark.parametrize("form", X3G_FORMS)
 @pytest.mark.parametrize("case", sorted(X3G_CASES))
 def test_lds_dma_form_gives_the_bits_of_the_staged_form(case, form):
