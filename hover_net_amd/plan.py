@@ -140,6 +140,40 @@ def _tile_n(cout):
     return 128 if cout >= 128 else (64 if cout >= 64 else 32)
 
 
+# Transform-domain weight packings of the last plans built in this process, keyed by a hash of the (BN-folded, float64) weights: the float64
+# GEMM with kron(G, G) and the packing are ~85 % of `build_plan`'s time (3.4 of 4.0 s for a cfg-2 plan), and a process that rebuilds an
+# engine for the same checkpoint -- another batch size, dtype, lowering or launch schedule; every second test of the GPU suite -- gets the
+# same arrays again.  Entries are read-only; least recently used ones go once the cache holds more than HVN_WINO_CACHE_MB (default 2048).
+_WINO_PACKED = {}
+_WINO_PACKED_BYTES = [0]
+
+
+def _wino_packed(wt, m, n2, cout, cin, cout_pad):
+    """U = G g G^T of every (cout, cin) filter, packed [n2, cout_pad, cin / 32, 1, 32] fp32 (see `conv_winograd`)."""
+    import os
+
+    from . import winograd as WG
+    try:
+        import xxhash
+        digest = xxhash.xxh3_128_hexdigest(np.ascontiguousarray(wt, np.float64))
+    except ImportError:                                    # pragma: no cover
+        import hashlib
+        digest = hashlib.blake2b(np.ascontiguousarray(wt, np.float64), digest_size=16).hexdigest()
+    key = (digest, tuple(wt.shape), m, cout_pad)
+    hit = _WINO_PACKED.pop(key, None)
+    if hit is None:
+        u = WG.transform_weights(wt, m)                                       # [n2, cout, cin] float64
+        hit = np.zeros((n2, cout_pad, cin // 32, 1, 32), np.float32)
+        hit[:, :cout] = u.reshape(n2, cout, cin // 32, 1, 32)
+        _WINO_PACKED_BYTES[0] += hit.nbytes
+    _WINO_PACKED[key] = hit                                                   # (re)inserted last = most recently used
+    limit = int(os.environ.get("HVN_WINO_CACHE_MB", "2048")) << 20
+    while _WINO_PACKED_BYTES[0] > limit and len(_WINO_PACKED) > 1:
+        old_key = next(iter(_WINO_PACKED))
+        _WINO_PACKED_BYTES[0] -= _WINO_PACKED.pop(old_key).nbytes
+    return hit
+
+
 def _pack_conv(wt, out_scale=None, groups=1):
     """[cout, cin/groups, kh, kw] (torch) -> [cout_pad, cin/32, kh*kw, 32] fp32: BN scale folded in
     float64, grouped convs expanded to block-diagonal dense, and the reduction index ordered
@@ -261,11 +295,9 @@ class Plan:
             cache[key] = vbuf
         vbuf = cache[key]
         mbuf = self.buf(name + ".M", n2, t1, cout)
-        u = WG.transform_weights(wt, m)                                       # [n2, cout, cin] float64
         tn = _tile_n(cout)
         cout_pad = (cout + tn - 1) // tn * tn
-        packed = np.zeros((n2, cout_pad, cin // 32, 1, 32), np.float32)
-        packed[:, :cout] = u.reshape(n2, cout, cin // 32, 1, 32)
+        packed = _wino_packed(wt, m, n2, cout, cin, cout_pad)
         g = Op(OP_CONV, name + ".wino_gemm", x=View(vbuf, 0, 0, 1, t1), y=View(mbuf, 0, 0, 1, t1), w=packed, cout=cout, tile_n=tn)
         g.extra.update(nbatch=n2, batch_strides=(t1 * cin, cout_pad * cin, t1 * cout), cin_real=cin, groups=1,
                        algo_flops=2.0 * y.h * y.w * cout * cin * r * r, exec_flops=2.0 * n2 * t1 * cout * cin)

@@ -82,6 +82,9 @@ def _conv_gain(key):
     return 1.0
 
 
+_SD_CACHE = {}
+
+
 def synth_state_dict(mode="original", nr_types=None, seed=0, as_torch=True):
     """Seeded, platform-independent (numpy PCG64) checkpoint in the reference's key
     format: Kaiming fan_out convs like `Net.weights_init`
@@ -89,6 +92,14 @@ def synth_state_dict(mode="original", nr_types=None, seed=0, as_torch=True):
     affine + running statistics so that BN folding / prologues are really exercised."""
     from .arch import param_table
 
+    key_ = (mode, nr_types, int(seed))
+    if key_ in _SD_CACHE:                       # (the last few checkpoints drawn in this process: 37 - 55 M normals take ~2 s; fresh copies are handed out)
+        sd = {k: v.copy() for k, v in _SD_CACHE[key_].items()}
+        if as_torch:
+            import torch
+
+            sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+        return sd
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = {}
     for key, (kind, shape) in param_table(mode, nr_types).items():
@@ -115,6 +126,9 @@ def synth_state_dict(mode="original", nr_types=None, seed=0, as_torch=True):
         else:
             raise KeyError(kind)
         sd[key] = a.astype(np.int64 if kind == "bn_nbt" else np.float32)
+    _SD_CACHE[key_] = {k: v.copy() for k, v in sd.items()}
+    while len(_SD_CACHE) > 6:
+        _SD_CACHE.pop(next(iter(_SD_CACHE)))
     if as_torch:
         import torch
 

@@ -45,7 +45,8 @@ def start():
     try:
         _DIR = tempfile.mkdtemp(prefix="hvn_oracle_")
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", PYTHONPATH=os.pathsep.join([os.path.dirname(_HERE), _HERE, os.environ.get("PYTHONPATH", "")]))
-        threads = max(4, (os.cpu_count() or 8) // 2)
+        # (at most 16: torch's CPU convolutions do not scale further, and the GPU tests in the foreground run CPU oracles of their own)
+        threads = min(16, max(4, (os.cpu_count() or 8) // 2))
         _PROC = subprocess.Popen([sys.executable, os.path.abspath(__file__), _DIR, str(threads)] + ["%s:%s" % j for j in JOBS], env=env,
                                  stdout=subprocess.DEVNULL, stderr=open(os.path.join(_DIR, "worker.err"), "w"))
         import atexit
