@@ -642,33 +642,7 @@ class TrainEngine:
         if rc:
             raise L.HvnError("hvn_run_train_plan(%s) failed (%d): %s" % (what, rc, lib.hvn_train_last_error().decode()))
 
-    def _zero_grads_async(self):
-        """The step's gradient memory (slab + arena + Winograd-domain weight gradients, ~8 GB at batch 16: every backward op accumulates) is
-        cleared UNDER the forward pass: on a side stream that starts where the launch stream stands now -- behind the previous step's
-        optimizer, which read the gradients -- and that the launch stream joins again before the first backward op (`_zero_grads_join`).
-        Rounds 1-5 cleared it between forward and backward: 1.8 ms of a 50 ms step with nothing to overlap it (HVN_TRAIN_ZERO_ASYNC=0)."""
-        if os.environ.get("HVN_TRAIN_ZERO_ASYNC", "1") == "0":
-            return
-        if getattr(self, "_zero_stream", None) is None:
-            self._zero_stream = torch.cuda.Stream(self.device)
-            self._zero_done = torch.cuda.Event()
-        main = torch.cuda.current_stream(self.device)
-        self._zero_stream.wait_stream(main)
-        with torch.cuda.stream(self._zero_stream):
-            self.gmem.zero_()
-            self._zero_done.record(self._zero_stream)
-        self._zero_pending = True
-
-    def _zero_grads_join(self):
-        """Gradient memory is zero from here on in launch-stream order: join the side-stream clear `forward` started, or clear now."""
-        if getattr(self, "_zero_pending", False):
-            torch.cuda.current_stream(self.device).wait_event(self._zero_done)
-            self._zero_pending = False
-        else:
-            self.gmem.zero_()
-
     def forward(self):
-        self._zero_grads_async()
         self._run_plan(ctypes.addressof(self.fwd_ops), len(self.fwd_ops), "forward")
         torch._foreach_add_(self._nbt, 1)
         self.net._train_version = getattr(self.net, "_train_version", 0) + 1    # invalidates the cached inference plan
@@ -677,7 +651,7 @@ class TrainEngine:
     def loss_forward(self):
         """Zero the gradient memory, run loss stage 1 -> this rank's partial sums (device float64 [64])."""
         lib = L.lib()
-        self._zero_grads_join()
+        self.gmem.zero_()
         self.sums.zero_()
         rc = lib.hvn_loss_forward(ctypes.byref(self._loss), self._stream())
         if rc:
@@ -723,7 +697,7 @@ class TrainEngine:
         """Backward plan from caller-supplied logit gradients (dict branch -> [n, c, h, w]): what torch autograd hands
         `HoVerNet.forward`'s graph node when the loss was computed in torch.  Fills the gradient slab (the parameters' .grad
         memory) like `backward`, without the fused loss stage."""
-        self._zero_grads_join()
+        self.gmem.zero_()
         for br, buf in self.dlogits.items():
             g = dlogits.get(br)
             if g is None:
