@@ -212,7 +212,8 @@ class TrainEngine:
         # (HVN_TRAIN_X3 = 6 (default) | 9 partial products per product, 0 = every conv on the fp32 pipe)
         self.x3_terms = int(os.environ.get("HVN_TRAIN_X3", "6"))
         # round 5: the weight gradients too (csrc/hvn_wgrad_x3.hip: both operands split on the fly; HVN_TRAIN_WGRAD_X3=0 keeps the fp32 pipe)
-        self.wgrad_x3 = self.x3_terms if os.environ.get("HVN_TRAIN_WGRAD_X3", "1") != "0" else 0
+        wg = os.environ.get("HVN_TRAIN_WGRAD_X3", "1")            # 1: as the forward convs | 6 | 9 | 0: fp32 pipe
+        self.wgrad_x3 = 0 if (wg == "0" or not self.x3_terms) else (int(wg) if wg in ("6", "9") else self.x3_terms)
         self.packs_x3 = torch.zeros(3 * total, dtype=torch.int16, device=self.device) if self.x3_terms else None
 
     def pack_ptr(self, key, mode):
