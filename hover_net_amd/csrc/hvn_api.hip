@@ -213,7 +213,31 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
         a.M = (long)batch * a.Ho * a.Wo;
         a.bm = op->tile_n == 64 ? 64 : 128;      // CHAIN: tile_n = pixels per workgroup (0 / 128: 128)
         const bool cx3 = op->act_dtype == 2 || op->act_dtype == 3;       // products on the bf16 pipe from bf16x3 splits: w / w2 = plane packings
-        if (op->act_dtype != 0 && !cx3) return fail(HVN_E_ARG, "chain: fp32 activations only (act_dtype 0, or 2 | 3 for bf16x3 products)%s", "");
+        const bool cbf = op->act_dtype == 1;                             // bf16 activations and weights (hvn_conv_chain_bf16.hip)
+        if (op->act_dtype != 0 && !cx3 && !cbf) return fail(HVN_E_ARG, "chain: act_dtype 0 (fp32), 1 (bf16) or 2 | 3 (fp32 with bf16x3 products)%s", "");
+        if (cbf) {
+            if (!a.x || !a.w1 || !a.y || !a.w2 || !a.y2) return fail(HVN_E_ARG, "chain: null pointer%s", "");
+            if (op->kh != 1 || op->kw != 1 || op->stride != 1 || op->pad_t || op->pad_l || op->relu || op->bias)
+                return fail(HVN_E_ARG, "chain: the first conv is a plain 1x1 (no bias / relu of its own)%s", "");
+            if (!hvn_chain_bf16_supported(a.K1, a.K1b, a.C, a.N2) || op->y.c != a.C || op->y2.c != a.N2)
+                return fail(HVN_E_ARG, "chain (bf16): needs input channels in slabs of 64 (64 or 128 in all), cout %% 64 == 0, cout2 in {64, 128} (cout2 = %s%ld)", "", a.N2);
+            if (op->x.h != a.Ho || op->x.w != a.Wo || op->y2.h != a.Ho || op->y2.w != a.Wo ||
+                (a.x2 && ((long)(a.Ho - 1) * a.stride2 >= op->x2.h || (long)(a.Wo - 1) * a.stride2 >= op->x2.w)))
+                return fail(HVN_E_ARG, "chain: views do not cover the output grid%s", "");
+            if (a.res && (a.rsn != a.ysn || a.rsy != a.ysy || a.rsx != a.ysx || op->res.c != a.C))
+                return fail(HVN_E_ARG, "chain: the residual view must have the output's strides%s", "");
+            if (!aligned16(a.x) || !aligned16(a.w1) || !aligned16(a.w2) || !aligned16(a.y) || !aligned16(a.y2) || (a.res && !aligned16(a.res)) ||
+                (a.x2 && !aligned16(a.x2)) || ((a.xsn | a.xsy | a.xsx | a.ysn | a.ysy | a.ysx | a.y2sn | a.y2sy | a.y2sx | a.x2sn | a.x2sy | a.x2sx) & 7))
+                return fail(HVN_E_ARG, "chain (bf16): views / weights not 16-byte aligned%s", "");
+            if ((!a.pre_s != !a.pre_b) || (!a.post_s != !a.post_b) || (a.pre_s && (!aligned16(a.pre_s) || !aligned16(a.pre_b))) ||
+                (a.post_s && (!aligned16(a.post_s) || !aligned16(a.post_b))) || (a.bias2 && !aligned16(a.bias2)))
+                return fail(HVN_E_ARG, "chain: per-channel vectors must be 16-byte aligned and come in pairs%s", "");
+            if (g_prof) prof_mark(s);
+            const int rcb = hvn_launch_conv_chain_bf16(a, s);
+            if (g_prof) prof_mark(s);
+            if (rcb) return fail(rcb == -1 ? HVN_E_ARG : HVN_E_LAUNCH, "chain (bf16): launch failed (cout2=%s%ld)", "", a.N2);
+            return 0;
+        }
         if (!a.x || !a.w1 || !a.y || !a.w2 || !a.y2) return fail(HVN_E_ARG, "chain: null pointer%s", "");
         if (op->kh != 1 || op->kw != 1 || op->stride != 1 || op->pad_t || op->pad_l || op->relu || op->bias)
             return fail(HVN_E_ARG, "chain: the first conv is a plain 1x1 (no bias / relu of its own)%s", "");

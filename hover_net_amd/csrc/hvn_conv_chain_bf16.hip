@@ -1,0 +1,384 @@
+// hvn_conv_chain_bf16.hip -- the chained pair of 1x1 convolutions of a pre-activation residual block (hvn_conv_chain.hip: a unit's conv3 +
+// residual | fused shortcut (+ block-closing BN-ReLU), then the NEXT unit's pre-activation + conv1, in one launch; reference
+// /root/reference/models/hovernet/net_utils.py:250-266) for the bf16 path of BASELINE cfg 3 (hvn_conv_bf16.hip: bf16 activations and weights,
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16).
+//
+// Why (round-5 verdict, next #2): d0 / d1's 1x1 layers of a cfg-3 step are HBM-bound (12 of 34 ms at ~4.3 TB/s).  Unchained, a seam moves
+// conv3's input + the residual + y (written) and then y again (read by conv1) + conv1's output; chained, y is consumed while it is on chip:
+// a third (d0) to a quarter (d1) of the seam's bytes go away.
+//
+// Structure: 64 pixels x all C output channels of conv3 per 256-thread workgroup (four waves as 2 x 2), in chunks of 64 channels.
+//   * conv3's INPUT tile ([64][K1 (+ K1b of the fused shortcut's input)] bf16, K1 + K1b = 64 | 128) is loaded ONCE and stays in LDS;
+//   * per chunk: W1 (64 rows x all k), W1' (N2 rows x the chunk's 64 k) and the residual chunk arrive in registers a whole chunk ahead;
+//     GEMM1 -> fp32 tile [64][68] -> epilogue 1 (+ residual, block-closing BN-ReLU, y rounded to bf16 and stored, the next unit's
+//     pre-activation applied to the ROUNDED y, rounded again: exactly what the unchained conv1 reads and stages) -> bf16 tile [64][72]
+//     -> GEMM2 accumulates the chunk's 64 k into the N2-wide accumulators;
+//   * epilogue 2: bias, ReLU, bf16, 64 output channels at a time through the fp32 tile.
+// LDS: 3 x 17 KB (input tile, W1 chunk, fp32 tile) + 9 KB (bf16 tile) + 9 | 18 KB (W1' chunk) <= 78 KB: two workgroups per CU.
+// Per accumulator the MFMAs run over k in ascending blocks of 16 with hvn_conv_igemm_bf16's lane -> k assignment, and both epilogues apply
+// its operations in its order: y and t1' are BIT-IDENTICAL to the two bf16 CONV launches the op replaces (tests/test_gpu_bf16.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvn_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define CB_BM 64
+#define CB_CN 64                      // conv3 output channels per chunk
+#define CB_EP 68                      // fp32 tile row pitch (floats)
+#define CB_T 72                       // bf16 tile / W1' chunk row pitch (elements: 144 B)
+
+static __device__ __forceinline__ float cb_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+static __device__ __forceinline__ float cb_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+static __device__ __forceinline__ uint32_t cb_pack(float a, float b)
+{
+    bf16x2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+template <int N2, int KA, bool HAS_X2>
+__global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
+{
+    constexpr int BM = CB_BM;
+    constexpr int LDA = KA + 8;                        // input tile / W1 chunk row pitch (elements): 144 | 272 B, conflict-free ds_read_b128
+    constexpr int PA = BM * (KA / 8) / 256;            // 16-byte pieces per thread of the input tile / a W1 chunk: 2 | 4
+    constexpr int PW2 = N2 * 8 / 256;                  // ... of a W1' chunk: 2 | 4
+    constexpr int TN2 = N2 / 64;                       // 32-column MFMA tiles per wave in GEMM2 (waves 2 x 2: 32 rows x N2 / 2 columns)
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(KA == 64 || KA == 128, "K1 + K1b");
+    static_assert(N2 == 64 || N2 == 128, "cout2");
+    extern __shared__ __attribute__((aligned(16))) unsigned char cbs[];
+    uint16_t *As = (uint16_t *)cbs;                    // [64][LDA]
+    uint16_t *W1s = As + BM * LDA;                     // [64][LDA]
+    float *ep = (float *)(W1s + CB_CN * LDA);          // [64][68]
+    uint16_t *Ts = (uint16_t *)(ep + BM * CB_EP);      // [64][72]
+    uint16_t *W2s = Ts + BM * CB_T;                    // [N2][72]
+
+    const uint16_t *px = (const uint16_t *)p.x, *px2 = (const uint16_t *)p.x2, *pw1 = (const uint16_t *)p.w1, *pw2 = (const uint16_t *)p.w2;
+    const uint16_t *pres = (const uint16_t *)p.res;
+    uint16_t *py = (uint16_t *)p.y, *py2 = (uint16_t *)p.y2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned M = (unsigned)p.M;
+    const unsigned m0 = blockIdx.x * (unsigned)BM;
+    const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
+    const unsigned n_blk = m0 / HoWo;
+    const int NC = p.C / CB_CN;
+    const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr, has_pre = p.pre_s != nullptr;
+
+    // ---- the input tile: piece t = tid + 256 j of [64 rows][KA / 8 pieces]; the first K1 / 8 pieces of a row come from x, the rest from x2 ----
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)(px + (long)n_blk * p.xsn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2 =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(HAS_X2 ? px2 + (long)n_blk * p.x2sn : px), 0, 0x7fffffff, 0x00020000);
+    {
+        u32x4 ra[PA];
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int t = tid + 256 * j;
+            const int row = t / (KA / 8), pc = t - row * (KA / 8);
+            const unsigned m = m0 + row;
+            const bool ok = m < M;
+            const unsigned mm = ok ? m : m0;
+            const unsigned n = mm / HoWo;
+            const unsigned rem = mm - n * HoWo;
+            const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+            const bool second = HAS_X2 && pc * 8 >= p.K1;
+            unsigned vo;
+            if (second)
+                vo = (unsigned)(((long)(n - n_blk) * p.x2sn + (long)(oy * p.stride2) * p.x2sy + (long)(ox * p.stride2) * p.x2sx + (pc * 8 - p.K1)) * 2);
+            else
+                vo = (unsigned)(((long)(n - n_blk) * p.xsn + (long)oy * p.xsy + (long)ox * p.xsx + pc * 8) * 2);
+            vo = ok ? vo : OOB;
+            if constexpr (HAS_X2)
+                ra[j] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2, vo, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, 0, 0);
+            else
+                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int t = tid + 256 * j;
+            const int row = t / (KA / 8), pc = t - row * (KA / 8);
+            *(u32x4 *)(As + row * LDA + pc * 8) = ra[j];
+        }
+    }
+
+    // ---- per-chunk operands, a chunk ahead in registers --------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)pw1, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)pw2, 0, 0x7fffffff, 0x00020000);
+    unsigned w1_voff[PA], w2_voff[PW2];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int t = tid + 256 * j;
+        const int row = t / (KA / 8), pc = t - row * (KA / 8);
+        w1_voff[j] = (unsigned)(((long)row * KA + pc * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < PW2; ++j) {
+        const int t = tid + 256 * j;
+        const int row = t >> 3, pc = t & 7;
+        w2_voff[j] = (unsigned)(((long)row * p.C + pc * 8) * 2);
+    }
+    u32x4 rw1[PA], rw2[PW2];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) rw1[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w1, w1_voff[j], c * (CB_CN * KA * 2), 0);
+#pragma unroll
+        for (int j = 0; j < PW2; ++j) rw2[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w2, w2_voff[j], c * (CB_CN * 2), 0);
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int t = tid + 256 * j;
+            const int row = t / (KA / 8), pc = t - row * (KA / 8);
+            *(u32x4 *)(W1s + row * LDA + pc * 8) = rw1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PW2; ++j) {
+            const int t = tid + 256 * j;
+            *(u32x4 *)(W2s + (t >> 3) * CB_T + (t & 7) * 8) = rw2[j];
+        }
+    };
+
+    // ---- epilogue coordinates: thread = one 16-byte piece (8 channels) of rows erow0 + 32 it -----------------------------------------------
+    const int ecol = (tid & 7) * 8;
+    const int erow0 = tid >> 3;
+    unsigned y_voff[2], y2_voff[2];   // the residual view has the output's strides (validated by the launcher)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const unsigned m = m0 + erow0 + 32 * it;
+        const bool ok = m < M;
+        const unsigned mm = ok ? m : m0;
+        const unsigned n = mm / HoWo;
+        const unsigned rem = mm - n * HoWo;
+        const unsigned oy = rem / (unsigned)p.Wo, ox = rem - oy * (unsigned)p.Wo;
+        y_voff[it] = ok ? (unsigned)(((long)(n - n_blk) * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + ecol) * 2) : OOB;
+        y2_voff[it] = ok ? (unsigned)(((long)(n - n_blk) * p.y2sn + (long)oy * p.y2sy + (long)ox * p.y2sx + ecol) * 2) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void *)(py + (long)n_blk * p.ysn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? pres + (long)n_blk * p.rsn : px), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc((void *)(py2 + (long)n_blk * p.y2sn), 0, 0x7fffffff, 0x00020000);
+    const float post_lo = has_post ? 0.f : -__builtin_inff();
+    const float relu1_lo = -__builtin_inff();          // the first conv of a chain has no ReLU / bias of its own (validated by the caller)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x16 acc2[TN2];
+#pragma unroll
+    for (int j = 0; j < TN2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+
+    u32x4 rres[2];
+    auto load_res = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            rres[it] = has_res ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff[it], c * (CB_CN * 2), 0) : (u32x4){0u, 0u, 0u, 0u};
+    };
+
+    load_w(0);
+    load_res(0);
+    store_w();
+    __syncthreads();
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) load_w(c + 1);                 // flies under this whole chunk
+        // ---- GEMM1: 32 pixels x 32 channels per wave over all KA ---------------------------------------------------------------------------
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        {
+            const uint16_t *a = As + (wm * 32 + l31) * LDA + 8 * lh;
+            const uint16_t *b = W1s + (wn * 32 + l31) * LDA + 8 * lh;
+#pragma unroll
+            for (int q = 0; q < KA / 16; ++q) {
+                const bf16x8 fa = __builtin_bit_cast(bf16x8, *(const u32x4 *)(a + q * 16));
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + q * 16));
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ep[row * CB_EP + wn * 32 + l31] = acc1[r];
+        }
+        __syncthreads();
+        // ---- epilogue 1: + residual, block-closing BN-ReLU, y (bf16) stored; the next unit's pre-activation of the ROUNDED y into the bf16 tile
+        {
+            const int co = c * CB_CN + ecol;
+            f32x4 qs[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, qb[2] = {zero4, zero4}, ps[2] = {qs[0], qs[0]}, pb[2] = {zero4, zero4};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (has_post) {
+                    qs[h] = *(const f32x4 *)(p.post_s + co + 4 * h);
+                    qb[h] = *(const f32x4 *)(p.post_b + co + 4 * h);
+                }
+                if (has_pre) {
+                    ps[h] = *(const f32x4 *)(p.pre_s + co + 4 * h);
+                    pb[h] = *(const f32x4 *)(p.pre_b + co + 4 * h);
+                }
+            }
+            u32x4 yout[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int rr = erow0 + 32 * it;
+                const u32x4 r4 = rres[it];
+                u32x4 o, a4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 v = *(const f32x4 *)(ep + rr * CB_EP + ecol + 4 * h);
+                    // hvn_conv_igemm_bf16's epilogue, operation by operation (bias = 0, no ReLU of its own)
+                    v.x = fmaxf(v.x + zero4.x, relu1_lo);
+                    v.y = fmaxf(v.y + zero4.y, relu1_lo);
+                    v.z = fmaxf(v.z + zero4.z, relu1_lo);
+                    v.w = fmaxf(v.w + zero4.w, relu1_lo);
+                    if (has_res) {
+                        v.x += cb_lo(r4[2 * h]);
+                        v.y += cb_hi(r4[2 * h]);
+                        v.z += cb_lo(r4[2 * h + 1]);
+                        v.w += cb_hi(r4[2 * h + 1]);
+                    }
+                    v.x = fmaxf(fmaf(v.x, qs[h].x, qb[h].x), post_lo);
+                    v.y = fmaxf(fmaf(v.y, qs[h].y, qb[h].y), post_lo);
+                    v.z = fmaxf(fmaf(v.z, qs[h].z, qb[h].z), post_lo);
+                    v.w = fmaxf(fmaf(v.w, qs[h].w, qb[h].w), post_lo);
+                    o[2 * h] = cb_pack(v.x, v.y);
+                    o[2 * h + 1] = cb_pack(v.z, v.w);
+                    if (has_pre) {      // the unchained conv1 stages relu(bf16(y) * s + b), rounded to bf16 (hvn_conv_igemm_bf16: store_lds)
+                        const float s_[4] = {ps[h].x, ps[h].y, ps[h].z, ps[h].w}, b_[4] = {pb[h].x, pb[h].y, pb[h].z, pb[h].w};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float lo = fmaxf(fmaf(cb_lo(o[2 * h + e]), s_[2 * e], b_[2 * e]), 0.f);
+                            const float hi = fmaxf(fmaf(cb_hi(o[2 * h + e]), s_[2 * e + 1], b_[2 * e + 1]), 0.f);
+                            a4[2 * h + e] = cb_pack(lo, hi);
+                        }
+                    } else {
+                        a4[2 * h] = o[2 * h];
+                        a4[2 * h + 1] = o[2 * h + 1];
+                    }
+                }
+                yout[it] = o;
+                *(u32x4 *)(Ts + rr * CB_T + ecol) = a4;
+            }
+            if (c + 1 < NC) load_res(c + 1);           // ahead of the y stores (one in-order counter for loads and stores)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_buffer_store_b128(yout[it], rsrc_y, y_voff[it], c * (CB_CN * 2), 0);
+        }
+        __syncthreads();
+        // ---- GEMM2: the chunk's 64 k into the N2-wide accumulators: 32 pixels x N2 / 2 channels per wave -------------------------------------
+        {
+            const uint16_t *a = Ts + (wm * 32 + l31) * CB_T + 8 * lh;
+            const uint16_t *b = W2s + (wn * (N2 / 2) + l31) * CB_T + 8 * lh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 fa = __builtin_bit_cast(bf16x8, *(const u32x4 *)(a + q * 16));
+#pragma unroll
+                for (int j = 0; j < TN2; ++j) {
+                    const bf16x8 fb = __builtin_bit_cast(bf16x8, *(const u32x4 *)(b + j * 32 * CB_T + q * 16));
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                               // W1 / W1' chunk and both tiles are free
+        if (c + 1 < NC) {
+            store_w();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue 2: t1' = relu(acc2 + bias2) as bf16, 64 output channels at a time through the fp32 tile ------------------------------------
+    const float relu_lo = p.relu2 ? 0.f : -__builtin_inff();
+    const float no_post = -__builtin_inff();
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int h2 = 0; h2 < N2 / 64; ++h2) {
+#pragma unroll
+        for (int j = 0; j < TN2; ++j) {
+            const int col0 = wn * (N2 / 2) + j * 32;
+            if (col0 / 64 == h2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    ep[row * CB_EP + (col0 & 63) + l31] = acc2[j][r];
+                }
+            }
+        }
+        __syncthreads();
+        f32x4 bias[2] = {zero4, zero4};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (p.bias2) bias[h] = *(const f32x4 *)(p.bias2 + h2 * 64 + ecol + 4 * h);
+        u32x4 out[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rr = erow0 + 32 * it;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v = *(const f32x4 *)(ep + rr * CB_EP + ecol + 4 * h);
+                v.x = fmaxf(v.x + bias[h].x, relu_lo);
+                v.y = fmaxf(v.y + bias[h].y, relu_lo);
+                v.z = fmaxf(v.z + bias[h].z, relu_lo);
+                v.w = fmaxf(v.w + bias[h].w, relu_lo);
+                v.x = fmaxf(fmaf(v.x, one4.x, zero4.x), no_post);
+                v.y = fmaxf(fmaf(v.y, one4.y, zero4.y), no_post);
+                v.z = fmaxf(fmaf(v.z, one4.z, zero4.z), no_post);
+                v.w = fmaxf(fmaf(v.w, one4.w, zero4.w), no_post);
+                out[it][2 * h] = cb_pack(v.x, v.y);
+                out[it][2 * h + 1] = cb_pack(v.z, v.w);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_buffer_store_b128(out[it], rsrc_y2, y2_voff[it], h2 * 128, 0);
+        if (h2 + 1 < N2 / 64) __syncthreads();
+    }
+}
+
+template <int N2, int KA, bool HAS_X2>
+static int launch_chain_bf16(const ChainArgs &a, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t)2 * CB_BM * (KA + 8) * 2 + (size_t)CB_BM * CB_EP * 4 + (size_t)CB_BM * CB_T * 2 + (size_t)N2 * CB_T * 2;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static std::atomic<unsigned long long> attr_done{0};
+    auto kern = hvn_conv_chain_bf16<N2, KA, HAS_X2>;
+    if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
+    const long grid = (a.M + CB_BM - 1) / CB_BM;
+    if (grid <= 0 || grid > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Which chains have this form: conv3's reduction (K1 + K1b) is 64 or 128 channels in whole 64-channel slabs (the bf16 packing's k-step),
+// cout a multiple of 64, cout2 64 | 128.
+int hvn_chain_bf16_supported(int k1, int k1b, int c, int n2)
+{
+    const int ka = k1 + k1b;
+    return k1 > 0 && k1 % 64 == 0 && k1b % 64 == 0 && (ka == 64 || ka == 128) && c > 0 && c % 64 == 0 && (n2 == 64 || n2 == 128);
+}
+
+// ChainArgs as hvn_launch_conv_chain with bf16 views (pointers reinterpreted, strides in ELEMENTS) and weights in hvn_conv_bf16.hip's
+// packing ([rows][ceil(k / 64)][1][64] bf16); fp32 per-channel vectors.
+int hvn_launch_conv_chain_bf16(const ChainArgs &a, hipStream_t stream)
+{
+    if (!hvn_chain_bf16_supported(a.K1, a.x2 ? a.K1b : 0, a.C, a.N2) || (a.x2 != nullptr) != (a.K1b > 0)) return -1;
+    if (a.M <= 0 || a.M >= (1L << 31) - 256) return -1;
+    const long px = (long)a.Ho * a.Wo;
+    if (px <= 0) return -1;
+    const long ns = CB_BM / px + 2;
+    const long spans[5] = {ns * a.xsn, a.x2 ? ns * a.x2sn : 0, ns * a.ysn, a.res ? ns * a.rsn : 0, ns * a.y2sn};
+    for (long s : spans)
+        if (s < 0 || s * 2 >= (1L << 31)) return -1;
+    if ((long)(a.C + 64) * (a.K1 + a.K1b) * 2 >= (1L << 31) || (long)(a.N2 + 64) * a.C * 2 >= (1L << 31)) return -1;
+    const int ka = a.K1 + a.K1b;
+    if (a.N2 == 64) {
+        if (a.x2) return ka == 128 ? launch_chain_bf16<64, 128, true>(a, stream) : -1;
+        return ka == 128 ? launch_chain_bf16<64, 128, false>(a, stream) : launch_chain_bf16<64, 64, false>(a, stream);
+    }
+    if (a.x2) return ka == 128 ? launch_chain_bf16<128, 128, true>(a, stream) : -1;
+    return ka == 128 ? launch_chain_bf16<128, 128, false>(a, stream) : launch_chain_bf16<128, 64, false>(a, stream);
+}

@@ -88,6 +88,9 @@ struct ChainArgs {
 };
 int hvn_launch_conv_chain(const ChainArgs &a, hipStream_t stream);
 int hvn_chain_supported(int c, int n2);
+// the same chain for the bf16 path (hvn_conv_chain_bf16.hip): bf16 views (strides in elements), hvn_conv_bf16.hip's weight packing, 64 pixels per workgroup
+int hvn_chain_bf16_supported(int k1, int k1b, int c, int n2);
+int hvn_launch_conv_chain_bf16(const ChainArgs &a, hipStream_t stream);
 // the same op with w1 / w2 = bf16 planes of the fp32 packings and both GEMMs' products on the bf16 matrix pipe (hvn_conv_chain_x3.hip)
 int hvn_launch_conv_chain_x3(const ChainArgs &a, int terms, hipStream_t stream);
 // the same op, same bits, conv3's input tile resident in registers and every other operand a chunk ahead in flight (hvn_conv_chain_x3r.hip);

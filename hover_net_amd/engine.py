@@ -208,11 +208,16 @@ class Engine:
 
         w16, off16, tot16 = [], {}, 0
         for i, op in enumerate(self.plan.ops):
-            if self.dtype == "bf16" and op.kind == PL.OP_CONV:
+            if self.dtype == "bf16" and op.kind in (PL.OP_CONV, PL.OP_CHAIN):
                 wb = repack_conv_bf16(op.w).ravel()
                 off16[i] = tot16
                 w16.append((tot16, wb))
                 tot16 += (wb.size + 127) // 128 * 128
+                if op.kind == PL.OP_CHAIN:               # + the second conv's (csrc/hvn_conv_chain_bf16.hip)
+                    wb2 = repack_conv_bf16(op.extra["w2"]).ravel()
+                    off16[(i, "w2")] = tot16
+                    w16.append((tot16, wb2))
+                    tot16 += (wb2.size + 127) // 128 * 128
             elif self.dtype == "fp32" and op.kind in (PL.OP_CONV, PL.OP_CHAIN) and op.extra.get("x3"):
                 # fp32 weights as three bf16 planes (csrc/hvn_conv_x3.hip), split on the device: (offset, fp32 packing) now, planes below
                 off16[i] = tot16
@@ -225,7 +230,7 @@ class Engine:
             else:
                 put((i, "w"), op.w)
             put((i, "bias"), op.bias)
-            if not (op.kind == PL.OP_CHAIN and op.extra.get("x3") and self.dtype == "fp32"):
+            if not (op.kind == PL.OP_CHAIN and (self.dtype == "bf16" or op.extra.get("x3"))):
                 put((i, "w2"), op.extra.get("w2"))
             put((i, "bias2"), op.extra.get("bias2"))
             if op.pre is not None:
@@ -285,11 +290,11 @@ class Engine:
                 o.y.h, o.y.w, o.y.c = P.pred_map.h, P.pred_map.w, P.pred_map.c
                 continue
             if op.kind == PL.OP_CHAIN:
-                if self.dtype != "fp32":
-                    raise ValueError("OP_CHAIN is fp32 only: build the bf16 plan with chain=False")
                 o.cout2 = int(op.extra["cout2"])
                 o.w2, o.bias2 = self._pptr(i, "w2"), self._pptr(i, "bias2")
-                if op.extra.get("x3"):
+                if self.dtype == "bf16":                 # csrc/hvn_conv_chain_bf16.hip: both packings in hvn_conv_bf16.hip's layout
+                    o.w2 = self.params16.data_ptr() + 2 * self._poff16[(i, "w2")]
+                elif op.extra.get("x3"):
                     o.w2 = self.params16.data_ptr() + 2 * self._poff16[(i, "w2")]
                     o.act_dtype = 2 if int(op.extra["x3"]) == 9 else 3
                     o.tile_n = 128

@@ -17,7 +17,7 @@ VARIANTS = {
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("hvn_conv.hip", "hvn_conv_chain.hip", "hvn_conv_chain_x3.hip", "hvn_conv_chain_x3r.hip", "hvn_conv_bf16.hip", "hvn_conv_bf16g.hip", "hvn_conv_x3.hip", "hvn_conv_x3g.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_wgrad_x3.hip", "hvn_targets.hip", "hvn_wsi_merge.hip",
+SOURCES = ("hvn_conv.hip", "hvn_conv_chain.hip", "hvn_conv_chain_x3.hip", "hvn_conv_chain_x3r.hip", "hvn_conv_bf16.hip", "hvn_conv_bf16g.hip", "hvn_conv_chain_bf16.hip", "hvn_conv_x3.hip", "hvn_conv_x3g.hip", "hvn_net_ops.hip", "hvn_postproc.hip", "hvn_api.hip", "hvn_train.hip", "hvn_wgrad_x3.hip", "hvn_targets.hip", "hvn_wsi_merge.hip",
            "hvn_augment.hip", "hvn_train_api.hip", "hvn_contour.cpp")
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-fvisibility=hidden", "-Wno-unused-value", "-pthread")

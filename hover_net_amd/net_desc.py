@@ -91,6 +91,9 @@ class _TrainForward(torch.autograd.Function):
         return (None, None) + out
 
 
+BF16_CHAIN_DEFAULT = "0"      # which blocks' seams the bf16 plan chains by default (set from the measurement: DESIGN section 4.8)
+
+
 class HoVerNet(nn.Module):
     """Initialise HoVer-Net (interface of net_desc.py:14-99)."""
 
@@ -142,11 +145,16 @@ class HoVerNet(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("HoVerNet runs on MI355X only: call .to('cuda') first (no CPU fallback)")
-        key = (self._weights_version(), str(dev), self.compute_dtype, self.launch_schedule, self.lowering)
+        import os
+        key = (self._weights_version(), str(dev), self.compute_dtype, self.launch_schedule, self.lowering, os.environ.get("HVN_BF16_CHAIN", BF16_CHAIN_DEFAULT))
         if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             bf16 = self.compute_dtype == "bf16"
-            plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None, chain=False if bf16 else None, x3=0 if bf16 else None,
+            # bf16: direct convolutions, no bf16x3; HVN_BF16_CHAIN = d0 | d0d1 chains those blocks' conv3 -> conv1 seams (csrc/hvn_conv_chain_bf16.hip, same bits), 0 none
+            import os
+            bchain = os.environ.get("HVN_BF16_CHAIN", BF16_CHAIN_DEFAULT)
+            plan = PL.build_plan(sd, self.mode, self.nr_types, winograd=0 if bf16 else None,
+                                 chain=(("bf16:" + bchain) if bchain not in ("0", "") else False) if bf16 else None, x3=0 if bf16 else None,
                                  lowering=self.lowering)
             self._engine = None  # free the old arena first
             ns, nl = self.launch_schedule if self.launch_schedule is not None else (None, None)

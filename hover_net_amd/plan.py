@@ -344,7 +344,7 @@ class Plan:
         for op in ops:
             self.add(op)
 
-    def fuse_chains(self, max_n2=128):
+    def fuse_chains(self, max_n2=128, accept=None):
         """Merge each residual unit's closing 1x1 conv (conv3: + residual or fused shortcut, optional block-closing BN-ReLU)
         with the 1x1 conv that directly consumes its output (the next unit's conv1, pre-activation included) into one
         OP_CHAIN launch (csrc/hvn_conv_chain.hip; net_utils.py:250-266).  Both are per-pixel, so the second runs on the
@@ -365,6 +365,8 @@ class Plan:
                   (b.x.buf is a.y.buf and (b.x.y0, b.x.x0, b.x.h, b.x.w, b.x.c0, b.x.c) == (a.y.y0, a.y.x0, a.y.h, a.y.w, a.y.c0, a.y.c)) and
                   (b.y.h, b.y.w) == (a.y.h, a.y.w) and
                   (a.res is None or (a.res.buf.w, a.res.buf.c, a.res.h, a.res.w, a.res.c) == (a.y.buf.w, a.y.buf.c, a.y.h, a.y.w, a.y.c)))
+            if ok and accept is not None and not accept(a, b):
+                ok = False
             if not ok:
                 out.append(a)
                 i += 1
@@ -575,7 +577,17 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
     if x3:
         # (which pipe a layer's products run on is a rule by LAYER, never by what the chain pass did: HVN_CHAIN=0 runs the same bits unchained)
         P.mark_x3(int(x3), d1=os.environ.get("HVN_X3_D1", "1") != "0", chain=os.environ.get("HVN_X3_CHAIN", "d0"))
-    if chain:
+    if isinstance(chain, str) and chain.startswith("bf16"):
+        # the bf16 path (csrc/hvn_conv_chain_bf16.hip): seams whose conv3 reduces over 64 or 128 channels in whole 64-channel slabs --
+        # d0's three and d1's plain-residual ones; chain = "bf16:d0" | "bf16:d0d1" names the blocks whose seams are chained
+        blocks = tuple(chain.split(":", 1)[1].replace("d0d1", "d0,d1").split(",")) if ":" in chain else ("d0", "d1")
+
+        def bf16_seam(a, b):
+            x2 = a.extra.get("x2")
+            ka = a.x.c + (x2.c if x2 is not None else 0)
+            return a.name.split(".")[0] in blocks and a.x.c % 64 == 0 and (x2 is None or x2.c % 64 == 0) and ka in (64, 128)
+        P.fuse_chains(128, accept=bf16_seam)
+    elif chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
     if os.environ.get("HVN_FUSE_UPADD", "0") != "0":
         # measured (profiles/r03_upadd_fusion_ab.txt): parity-green and bit-equal, one launch and one tensor less per decoder stage, but

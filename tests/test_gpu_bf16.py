@@ -200,6 +200,35 @@ def test_bf16_batch_invariance_and_dtype_switch():
     assert float((a[..., 0] - c[..., 0]).abs().max()) < 2e-2 and not torch.equal(a, c)
 
 
+@pytest.mark.parametrize("mode,nt,size,n", [("fast", 6, 256, 3), ("original", 5, 270, 2)])
+def test_bf16_chained_seams_give_the_bits_of_the_two_launches(mode, nt, size, n, monkeypatch):
+    """Round 6 (round-5 verdict, next #2): csrc/hvn_conv_chain_bf16.hip -- a residual unit's conv3 (+ residual | fused shortcut, block-closing
+    BN-ReLU) chained with the next unit's pre-activation + conv1 on the bf16 path, y consumed while it is on chip.  HVN_BF16_CHAIN = d0d1
+    chains d0's three seams (K = 64, 64 + 64 of the fused shortcut, cout2 = 64 | 128) and d1's plain-residual ones (K = 128): logits and
+    prediction map carry the bits of the unchained plan (HVN_BF16_CHAIN=0), in both geometries ('original': pixel counts that are not a
+    multiple of the 64-pixel workgroup, tiles that straddle samples)."""
+    from hover_net_amd import net_desc, plan as PL, run_desc
+    from hover_net_amd.synth import synth_state_dict, synth_tiles
+    tiles = torch.from_numpy(synth_tiles(n, size, seed=21))
+    outs, chains = [], []
+    for mode_env in ("0", "d0", "d0d1"):
+        monkeypatch.setenv("HVN_BF16_CHAIN", mode_env)
+        net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
+        net.load_state_dict(synth_state_dict(mode, nt, seed=5), strict=True)
+        net.compute_dtype = "bf16"
+        net = net.cuda().eval()
+        pred = run_desc.infer_step_device(tiles, net).cpu().clone()
+        eng = net.engine(n)
+        chains.append(sum(1 for o in eng.plan.ops if o.kind == PL.OP_CHAIN))
+        out = {k: eng.logits[k][:n].cpu().clone() for k in eng.logits}
+        out["pred"] = pred
+        outs.append(out)
+    assert chains == [0, 3, 5], chains          # (d1 -> d2: cout2 = 256, unchained)
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], o[k]), k
+
+
 def _pairs(a, b):
     """IoU > 0.5 pairing (the reference metric's: metrics/stats_utils.py:178-260): (instances of a, of b, paired, without a partner)."""
     la, lb = [int(x) for x in np.unique(a) if x], [int(x) for x in np.unique(b) if x]

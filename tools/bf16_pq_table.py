@@ -88,6 +88,11 @@ def main():
         t0 = time.perf_counter()
         net, curve = synth_fit.fit("fast", None, steps=a.steps, lr=1e-3, seed=seed)
         fit_s = time.perf_counter() - t0
+        import hashlib
+        hsh = hashlib.sha256()
+        for k_, v_ in net.state_dict().items():
+            hsh.update(v_.detach().cpu().contiguous().numpy().tobytes())
+        weights_sha = hsh.hexdigest()[:16]          # the fit is deterministic: this is the same on every box and every run of one build
         pm32, i32 = segment(net, tiles, "fp32")
         pm32c, i32c = segment(net, tiles, "fp32", "conservative")
         pm16, i16 = segment(net, tiles, "bf16")
@@ -106,7 +111,7 @@ def main():
             flips += [diagnose(k, lab, i32[k], i16[k], pm32, pm16) for lab in la]
             laf, lbf, _ = pairs(i32[k], i32c[k])
             lonef += len(laf) + len(lbf)
-        row = {"seed": seed, "fit_seconds": round(fit_s, 1), "loss_first10": float(np.mean(curve[:10])), "loss_last30": float(np.mean(curve[-30:])),
+        row = {"seed": seed, "weights_sha256_16": weights_sha, "fit_seconds": round(fit_s, 1), "loss_first10": float(np.mean(curve[:10])), "loss_last30": float(np.mean(curve[-30:])),
                "pq_fp32_vs_truth_mean": float(np.mean(qt)), "pq_bf16_vs_fp32_mean": float(np.mean(q)), "pq_bf16_vs_fp32_min": float(np.min(q)),
                "tiles_below_0.95": int(np.sum(np.array(q) < 0.95)), "instances_fp32": n32, "instances_bf16": n16, "instances_paired": tp,
                "instances_without_partner": lone, "instance_agreement": tp / max(1.0, 0.5 * (n32 + n16)),
@@ -115,9 +120,9 @@ def main():
                "max_abs_dp_fp32_pair": float(np.abs(pm32c[..., 0] - pm32[..., 0]).max())}
         rows.append(row)
         flips_all += [dict(f, seed=seed) for f in flips]
-        print("seed %d: fit %.0f s loss %.3f -> %.3f | fp32 vs truth PQ %.3f | bf16 vs fp32: mean PQ %.4f min %.4f, %d / %d instances without partner "
+        print("seed %d [weights %s]: fit %.0f s loss %.3f -> %.3f | fp32 vs truth PQ %.3f | bf16 vs fp32: mean PQ %.4f min %.4f, %d / %d instances without partner "
               "(agreement %.4f) | fp32 conservative vs default: min PQ %.4f, %d without partner" %
-              (seed, fit_s, row["loss_first10"], row["loss_last30"], row["pq_fp32_vs_truth_mean"], row["pq_bf16_vs_fp32_mean"], row["pq_bf16_vs_fp32_min"],
+              (seed, weights_sha, fit_s, row["loss_first10"], row["loss_last30"], row["pq_fp32_vs_truth_mean"], row["pq_bf16_vs_fp32_mean"], row["pq_bf16_vs_fp32_min"],
                lone, n32 + n16, row["instance_agreement"], row["pq_fp32_conservative_vs_fp32_default_min"], lonef), flush=True)
         del net
         torch.cuda.empty_cache()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end refresh on the GPU box (one gpurun call):  gpurun -- 'bash tools/refresh_profiles.sh r05'
+# Round-end refresh on the GPU box (one gpurun call):  gpurun -- 'bash tools/refresh_profiles.sh r06'
 # full -m gpu suite (TESTS=0 skips it), run-to-run / form-to-form bit equality of the whole network under load, smoke(), the default bench line (fitted checkpoint; measures roofline.traffic itself through two
 # rocprofv3 --pmc child passes, writes the per-launch-class traffic table of those passes, carries the cfg-3 / train_step / wsi_8k legs),
 # rocprofv3 kernel stats + per-layer table of a random-checkpoint run on ONE launch stream (every kernel's duration is its own: under the
@@ -36,6 +36,8 @@ for ph in 0 1; do
   python tools/train_roofline.py $tdb gpurun_out/${R}_train_profiled_phase$ph.json 6 > gpurun_out/${R}_train_roofline_phase$ph.json 2>/dev/null
   rm -rf gpurun_out/${R}_tprof$ph
 done
+# cfg 3's declared tolerance as a distribution: 8 deterministic fits x 48 tiles, bf16 vs fp32 segmentation (weights hash per fit: equal on every box)
+timeout 900 python tools/bf16_pq_table.py --out gpurun_out/${R}_bf16_pq_table.json 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_bf16_pq_table.txt
 if [ -n "$WSI40K" ]; then
   timeout 1200 python tools/wsi_bench.py --size 40000 2>&1 | tail -1 > gpurun_out/${R}_wsi_40k.json
 fi
