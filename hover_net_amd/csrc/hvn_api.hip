@@ -220,7 +220,7 @@ static int run_one(const hvn_op *op, int batch, hipStream_t s)
             if (op->kh != 1 || op->kw != 1 || op->stride != 1 || op->pad_t || op->pad_l || op->relu || op->bias)
                 return fail(HVN_E_ARG, "chain: the first conv is a plain 1x1 (no bias / relu of its own)%s", "");
             if (!hvn_chain_bf16_supported(a.K1, a.K1b, a.C, a.N2) || op->y.c != a.C || op->y2.c != a.N2)
-                return fail(HVN_E_ARG, "chain (bf16): needs input channels in slabs of 64 (64 or 128 in all), cout %% 64 == 0, cout2 in {64, 128} (cout2 = %s%ld)", "", a.N2);
+                return fail(HVN_E_ARG, "chain (bf16): needs input channels in slabs of 64 (64 or 128 in all), cout %% 256 == 0, cout2 in {64, 128} (cout2 = %s%ld)", "", a.N2);
             if (op->x.h != a.Ho || op->x.w != a.Wo || op->y2.h != a.Ho || op->y2.w != a.Wo ||
                 (a.x2 && ((long)(a.Ho - 1) * a.stride2 >= op->x2.h || (long)(a.Wo - 1) * a.stride2 >= op->x2.w)))
                 return fail(HVN_E_ARG, "chain: views do not cover the output grid%s", "");

@@ -176,19 +176,42 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
 
-    u32x4 rres[2];
-    auto load_res = [&](int c) {
+    // the residual chunks arrive FOUR chunks ahead (a ring of four register stages, 8 VGPRs each): one chunk is ~1.5 us of a workgroup's
+    // time, less than an HBM round trip under load -- with the request only one chunk ahead every epilogue waited for it
+    u32x4 rres[4][2];
+    auto load_res = [&](u32x4 (&slot)[2], int c) {
 #pragma unroll
         for (int it = 0; it < 2; ++it)
-            rres[it] = has_res ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff[it], c * (CB_CN * 2), 0) : (u32x4){0u, 0u, 0u, 0u};
+            slot[it] = (has_res && c < NC) ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, y_voff[it], c * (CB_CN * 2), 0) : (u32x4){0u, 0u, 0u, 0u};
     };
 
     load_w(0);
-    load_res(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_res(rres[u], u);
     store_w();
     __syncthreads();
-    for (int c = 0; c < NC; ++c) {
+    for (int c4 = 0; c4 < NC; c4 += 4) {               // NC is a multiple of 4 (C % 256 == 0: validated by the launcher)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c4 + u;
         if (c + 1 < NC) load_w(c + 1);                 // flies under this whole chunk
+        // the chunk's per-channel vectors (block-closing BN, next unit's pre-activation): requested here, under GEMM1 -- fetched where
+        // epilogue 1 uses them they were ~700 exposed cycles per chunk
+        f32x4 qs[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, qb[2] = {zero4, zero4}, ps[2] = {qs[0], qs[0]}, pb[2] = {zero4, zero4};
+        {
+            const int co = c * CB_CN + ecol;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (has_post) {
+                    qs[h] = *(const f32x4 *)(p.post_s + co + 4 * h);
+                    qb[h] = *(const f32x4 *)(p.post_b + co + 4 * h);
+                }
+                if (has_pre) {
+                    ps[h] = *(const f32x4 *)(p.pre_s + co + 4 * h);
+                    pb[h] = *(const f32x4 *)(p.pre_b + co + 4 * h);
+                }
+            }
+        }
         // ---- GEMM1: 32 pixels x 32 channels per wave over all KA ---------------------------------------------------------------------------
         f32x16 acc1;
 #pragma unroll
@@ -211,24 +234,11 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
         __syncthreads();
         // ---- epilogue 1: + residual, block-closing BN-ReLU, y (bf16) stored; the next unit's pre-activation of the ROUNDED y into the bf16 tile
         {
-            const int co = c * CB_CN + ecol;
-            f32x4 qs[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, qb[2] = {zero4, zero4}, ps[2] = {qs[0], qs[0]}, pb[2] = {zero4, zero4};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (has_post) {
-                    qs[h] = *(const f32x4 *)(p.post_s + co + 4 * h);
-                    qb[h] = *(const f32x4 *)(p.post_b + co + 4 * h);
-                }
-                if (has_pre) {
-                    ps[h] = *(const f32x4 *)(p.pre_s + co + 4 * h);
-                    pb[h] = *(const f32x4 *)(p.pre_b + co + 4 * h);
-                }
-            }
             u32x4 yout[2];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int rr = erow0 + 32 * it;
-                const u32x4 r4 = rres[it];
+                const u32x4 r4 = rres[u][it];
                 u32x4 o, a4;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
                 yout[it] = o;
                 *(u32x4 *)(Ts + rr * CB_T + ecol) = a4;
             }
-            if (c + 1 < NC) load_res(c + 1);           // ahead of the y stores (one in-order counter for loads and stores)
+            load_res(rres[u], c + 4);                  // this stage is consumed; ahead of the y stores (one in-order counter for loads and stores)
 #pragma unroll
             for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_buffer_store_b128(yout[it], rsrc_y, y_voff[it], c * (CB_CN * 2), 0);
         }
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
             store_w();
             __syncthreads();
         }
+    }
     }
 
     // ---- epilogue 2: t1' = relu(acc2 + bias2) as bf16, 64 output channels at a time through the fp32 tile ------------------------------------
@@ -354,11 +365,11 @@ static int launch_chain_bf16(const ChainArgs &a, hipStream_t stream)
 }
 
 // Which chains have this form: conv3's reduction (K1 + K1b) is 64 or 128 channels in whole 64-channel slabs (the bf16 packing's k-step),
-// cout a multiple of 64, cout2 64 | 128.
+// cout a multiple of 256 (the residual ring walks four 64-channel chunks per turn), cout2 64 | 128.
 int hvn_chain_bf16_supported(int k1, int k1b, int c, int n2)
 {
     const int ka = k1 + k1b;
-    return k1 > 0 && k1 % 64 == 0 && k1b % 64 == 0 && (ka == 64 || ka == 128) && c > 0 && c % 64 == 0 && (n2 == 64 || n2 == 128);
+    return k1 > 0 && k1 % 64 == 0 && k1b % 64 == 0 && (ka == 64 || ka == 128) && c > 0 && c % 256 == 0 && (n2 == 64 || n2 == 128);
 }
 
 // ChainArgs as hvn_launch_conv_chain with bf16 views (pointers reinterpreted, strides in ELEMENTS) and weights in hvn_conv_bf16.hip's

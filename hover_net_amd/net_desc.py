@@ -91,7 +91,7 @@ class _TrainForward(torch.autograd.Function):
         return (None, None) + out
 
 
-BF16_CHAIN_DEFAULT = "0"      # which blocks' seams the bf16 plan chains by default (set from the measurement: DESIGN section 4.8)
+BF16_CHAIN_DEFAULT = "d0d1"      # which blocks' seams the bf16 plan chains by default (set from the measurement: DESIGN section 4.8)
 
 
 class HoVerNet(nn.Module):

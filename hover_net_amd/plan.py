@@ -585,7 +585,7 @@ def build_plan(sd, mode="original", nr_types=None, with_predmap=True, winograd=N
         def bf16_seam(a, b):
             x2 = a.extra.get("x2")
             ka = a.x.c + (x2.c if x2 is not None else 0)
-            return a.name.split(".")[0] in blocks and a.x.c % 64 == 0 and (x2 is None or x2.c % 64 == 0) and ka in (64, 128)
+            return a.name.split(".")[0] in blocks and a.x.c % 64 == 0 and (x2 is None or x2.c % 64 == 0) and ka in (64, 128) and a.cout % 256 == 0
         P.fuse_chains(128, accept=bf16_seam)
     elif chain:
         P.fuse_chains(int(os.environ.get("HVN_CHAIN_MAXN2", "128")))
