@@ -41,7 +41,9 @@ static __device__ __forceinline__ uint32_t cb_pack(float a, float b)
     return __builtin_bit_cast(uint32_t, h);
 }
 
-template <int N2, int KA, bool HAS_X2>
+// FL: which optional operands exist, known at compile time for the four seam kinds HoVer-Net has (bit 0 residual, bit 1 the next unit's
+// pre-activation, bit 2 block-closing BN-ReLU) -- the epilogue is then straight-line code; -1: decided at run time (any other chain).
+template <int N2, int KA, bool HAS_X2, int FL>
 __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
 {
     constexpr int BM = CB_BM;
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
     const unsigned HoWo = (unsigned)(p.Ho * p.Wo);
     const unsigned n_blk = m0 / HoWo;
     const int NC = p.C / CB_CN;
-    const bool has_res = p.res != nullptr, has_post = p.post_s != nullptr, has_pre = p.pre_s != nullptr;
+    const bool has_res = FL < 0 ? p.res != nullptr : (FL & 1) != 0;
+    const bool has_pre = FL < 0 ? p.pre_s != nullptr : (FL & 2) != 0;
+    const bool has_post = FL < 0 ? p.post_s != nullptr : (FL & 4) != 0;
 
     // ---- the input tile: piece t = tid + 256 j of [64 rows][KA / 8 pieces]; the first K1 / 8 pieces of a row come from x, the rest from x2 ----
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)(px + (long)n_blk * p.xsn), 0, 0x7fffffff, 0x00020000);
@@ -166,8 +170,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
     const __amdgpu_buffer_rsrc_t rsrc_r =
         __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? pres + (long)n_blk * p.rsn : px), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc((void *)(py2 + (long)n_blk * p.y2sn), 0, 0x7fffffff, 0x00020000);
-    const float post_lo = has_post ? 0.f : -__builtin_inff();
-    const float relu1_lo = -__builtin_inff();          // the first conv of a chain has no ReLU / bias of its own (validated by the caller)
+    // (the first conv of a chain has no ReLU / bias of its own: validated by the caller)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     f32x16 acc2[TN2];
@@ -243,21 +246,22 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     f32x4 v = *(const f32x4 *)(ep + rr * CB_EP + ecol + 4 * h);
-                    // hvn_conv_igemm_bf16's epilogue, operation by operation (bias = 0, no ReLU of its own)
-                    v.x = fmaxf(v.x + zero4.x, relu1_lo);
-                    v.y = fmaxf(v.y + zero4.y, relu1_lo);
-                    v.z = fmaxf(v.z + zero4.z, relu1_lo);
-                    v.w = fmaxf(v.w + zero4.w, relu1_lo);
+                    // hvn_conv_igemm_bf16's epilogue with its identities left out: it computes max(acc + bias, lo) with bias = 0 and lo = -inf
+                    // here, and fma(v, 1, 0) / max(., -inf) when there is no block-closing BN -- all of them return their argument for every
+                    // finite or infinite value that is not -0, and an MFMA accumulator that started at +0 is never -0 (x + y is -0 only if
+                    // both are), nor is a sum with one operand that is not -0.  (Not preserved: a NaN, which max(., -inf) would turn into -inf.)
                     if (has_res) {
                         v.x += cb_lo(r4[2 * h]);
                         v.y += cb_hi(r4[2 * h]);
                         v.z += cb_lo(r4[2 * h + 1]);
                         v.w += cb_hi(r4[2 * h + 1]);
                     }
-                    v.x = fmaxf(fmaf(v.x, qs[h].x, qb[h].x), post_lo);
-                    v.y = fmaxf(fmaf(v.y, qs[h].y, qb[h].y), post_lo);
-                    v.z = fmaxf(fmaf(v.z, qs[h].z, qb[h].z), post_lo);
-                    v.w = fmaxf(fmaf(v.w, qs[h].w, qb[h].w), post_lo);
+                    if (has_post) {
+                        v.x = fmaxf(fmaf(v.x, qs[h].x, qb[h].x), 0.f);
+                        v.y = fmaxf(fmaf(v.y, qs[h].y, qb[h].y), 0.f);
+                        v.z = fmaxf(fmaf(v.z, qs[h].z, qb[h].z), 0.f);
+                        v.w = fmaxf(fmaf(v.w, qs[h].w, qb[h].w), 0.f);
+                    }
                     o[2 * h] = cb_pack(v.x, v.y);
                     o[2 * h + 1] = cb_pack(v.z, v.w);
                     if (has_pre) {      // the unchained conv1 stages relu(bf16(y) * s + b), rounded to bf16 (hvn_conv_igemm_bf16: store_lds)
@@ -305,8 +309,6 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
 
     // ---- epilogue 2: t1' = relu(acc2 + bias2) as bf16, 64 output channels at a time through the fp32 tile ------------------------------------
     const float relu_lo = p.relu2 ? 0.f : -__builtin_inff();
-    const float no_post = -__builtin_inff();
-    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int h2 = 0; h2 < N2 / 64; ++h2) {
 #pragma unroll
@@ -336,10 +338,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
                 v.y = fmaxf(v.y + bias[h].y, relu_lo);
                 v.z = fmaxf(v.z + bias[h].z, relu_lo);
                 v.w = fmaxf(v.w + bias[h].w, relu_lo);
-                v.x = fmaxf(fmaf(v.x, one4.x, zero4.x), no_post);
-                v.y = fmaxf(fmaf(v.y, one4.y, zero4.y), no_post);
-                v.z = fmaxf(fmaf(v.z, one4.z, zero4.z), no_post);
-                v.w = fmaxf(fmaf(v.w, one4.w, zero4.w), no_post);
+                // (hvn_conv_igemm_bf16 goes on with fma(v, 1, 0) and max(., -inf): identities here, see epilogue 1)
                 out[it][2 * h] = cb_pack(v.x, v.y);
                 out[it][2 * h + 1] = cb_pack(v.z, v.w);
             }
@@ -350,13 +349,13 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_chain_bf16(const ChainArgs p)
     }
 }
 
-template <int N2, int KA, bool HAS_X2>
+template <int N2, int KA, bool HAS_X2, int FL = -1>
 static int launch_chain_bf16(const ChainArgs &a, hipStream_t stream)
 {
     constexpr size_t lds = (size_t)2 * CB_BM * (KA + 8) * 2 + (size_t)CB_BM * CB_EP * 4 + (size_t)CB_BM * CB_T * 2 + (size_t)N2 * CB_T * 2;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     static std::atomic<unsigned long long> attr_done{0};
-    auto kern = hvn_conv_chain_bf16<N2, KA, HAS_X2>;
+    auto kern = hvn_conv_chain_bf16<N2, KA, HAS_X2, FL>;
     if (hvn_max_lds_once((const void *)kern, (int)lds, attr_done)) return -2;
     const long grid = (a.M + CB_BM - 1) / CB_BM;
     if (grid <= 0 || grid > 0x7fffffffL) return -1;
@@ -386,10 +385,16 @@ int hvn_launch_conv_chain_bf16(const ChainArgs &a, hipStream_t stream)
         if (s < 0 || s * 2 >= (1L << 31)) return -1;
     if ((long)(a.C + 64) * (a.K1 + a.K1b) * 2 >= (1L << 31) || (long)(a.N2 + 64) * a.C * 2 >= (1L << 31)) return -1;
     const int ka = a.K1 + a.K1b;
+    const int fl = (a.res ? 1 : 0) | (a.pre_s ? 2 : 0) | (a.post_s ? 4 : 0);
+    // the four seams of a HoVer-Net encoder, with their operand set compiled in
+    if (a.N2 == 64 && ka == 128 && a.x2 && fl == 2) return launch_chain_bf16<64, 128, true, 2>(a, stream);      // d0 unit 0 (fused shortcut) -> unit 1
+    if (a.N2 == 64 && ka == 64 && !a.x2 && fl == 3) return launch_chain_bf16<64, 64, false, 3>(a, stream);       // d0 unit 1 -> unit 2
+    if (a.N2 == 128 && ka == 64 && !a.x2 && fl == 5) return launch_chain_bf16<128, 64, false, 5>(a, stream);     // d0's last unit (block BN-ReLU) -> d1 unit 0
+    if (a.N2 == 128 && ka == 128 && !a.x2 && fl == 3) return launch_chain_bf16<128, 128, false, 3>(a, stream);   // d1 unit i -> unit i + 1
     if (a.N2 == 64) {
         if (a.x2) return ka == 128 ? launch_chain_bf16<64, 128, true>(a, stream) : -1;
         return ka == 128 ? launch_chain_bf16<64, 128, false>(a, stream) : launch_chain_bf16<64, 64, false>(a, stream);
     }
-    if (a.x2) return ka == 128 ? launch_chain_bf16<128, 128, true>(a, stream) : -1;
+    if (a.x2) return -1;       // (a fused shortcut in front of a 128-wide conv1 does not occur in HoVer-Net)
     return ka == 128 ? launch_chain_bf16<128, 128, false>(a, stream) : launch_chain_bf16<128, 64, false>(a, stream);
 }
