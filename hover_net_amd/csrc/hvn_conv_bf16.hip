@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "hvn_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -344,29 +346,64 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_bf16(const ConvArgs p)
             const int rr = erow0 + it * RPP;
             oks[it] = rr < BM && m0 + rr < M && cok;
             yoffs[it] = (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co;
-            const u32x4 r4 = rall[it];
-            u32x4 o;
+        }
+        // Round 6 (hvn_conv_x3g.hip has the argument): the arithmetic in the 8 forms {bias + ReLU | neither} x {residual | none} x {block
+        // BN-ReLU | none}; what a launch does not have used to be computed as an identity (max(acc + 0, -inf), max(fma(., 1, 0), -inf)): same bits.
+        auto finish = [&](auto hb_t, auto hr_t, auto hp_t) {
+            constexpr bool HB = decltype(hb_t)::value, HR = decltype(hr_t)::value, HP = decltype(hp_t)::value;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 v = *(const f32x4 *)(ep + (rr < BM ? rr : 0) * EP_LD + ecol + 4 * h);
-                v.x = fmaxf(v.x + bias[h].x, relu_lo);
-                v.y = fmaxf(v.y + bias[h].y, relu_lo);
-                v.z = fmaxf(v.z + bias[h].z, relu_lo);
-                v.w = fmaxf(v.w + bias[h].w, relu_lo);
-                if (has_res) {
-                    v.x += bf_lo(r4[2 * h]);
-                    v.y += bf_hi(r4[2 * h]);
-                    v.z += bf_lo(r4[2 * h + 1]);
-                    v.w += bf_hi(r4[2 * h + 1]);
+            for (int it = 0; it < NIT; ++it) {
+                const int rr = erow0 + it * RPP;
+                const u32x4 r4 = rall[it];
+                u32x4 o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 v = *(const f32x4 *)(ep + (rr < BM ? rr : 0) * EP_LD + ecol + 4 * h);
+                    if constexpr (HB) {
+                        v.x = fmaxf(v.x + bias[h].x, relu_lo);
+                        v.y = fmaxf(v.y + bias[h].y, relu_lo);
+                        v.z = fmaxf(v.z + bias[h].z, relu_lo);
+                        v.w = fmaxf(v.w + bias[h].w, relu_lo);
+                    }
+                    if (HR && has_res) {
+                        v.x += bf_lo(r4[2 * h]);
+                        v.y += bf_hi(r4[2 * h]);
+                        v.z += bf_lo(r4[2 * h + 1]);
+                        v.w += bf_hi(r4[2 * h + 1]);
+                    }
+                    if constexpr (HP) {
+                        v.x = fmaxf(fmaf(v.x, qs[h].x, qb[h].x), post_lo);
+                        v.y = fmaxf(fmaf(v.y, qs[h].y, qb[h].y), post_lo);
+                        v.z = fmaxf(fmaf(v.z, qs[h].z, qb[h].z), post_lo);
+                        v.w = fmaxf(fmaf(v.w, qs[h].w, qb[h].w), post_lo);
+                    }
+                    o[2 * h] = pack_bf(v.x, v.y);
+                    o[2 * h + 1] = pack_bf(v.z, v.w);
                 }
-                v.x = fmaxf(fmaf(v.x, qs[h].x, qb[h].x), post_lo);
-                v.y = fmaxf(fmaf(v.y, qs[h].y, qb[h].y), post_lo);
-                v.z = fmaxf(fmaf(v.z, qs[h].z, qb[h].z), post_lo);
-                v.w = fmaxf(fmaf(v.w, qs[h].w, qb[h].w), post_lo);
-                o[2 * h] = pack_bf(v.x, v.y);
-                o[2 * h + 1] = pack_bf(v.z, v.w);
+                vout[it] = o;
             }
-            vout[it] = o;
+        };
+        {
+            using T = std::true_type;
+            using F = std::false_type;
+            const bool hb = p.bias != nullptr || p.relu;
+#if defined(HVN_X3G_FULL_EPI) && HVN_X3G_FULL_EPI
+            finish(T{}, T{}, T{});      // A/B build (lib.VARIANTS["fullepi"]): every operation, absent operands as identities
+#else
+            if (hb) {
+                if (has_res) {
+                    if (has_post) finish(T{}, T{}, T{}); else finish(T{}, T{}, F{});
+                } else {
+                    if (has_post) finish(T{}, F{}, T{}); else finish(T{}, F{}, F{});
+                }
+            } else {
+                if (has_res) {
+                    if (has_post) finish(F{}, T{}, T{}); else finish(F{}, T{}, F{});
+                } else {
+                    if (has_post) finish(F{}, F{}, T{}); else finish(F{}, F{}, F{});
+                }
+            }
+#endif
         }
         // ... and the stores leave back to back (the empty asm keeps LLVM from sinking the arithmetic into the store blocks, which
         // would put a vmcnt(0) -- a wait for the previous STORE -- between them; hvn_conv.hip has the measurements)

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "hvn_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -329,17 +331,52 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_x3(ConvArgs p)
             e_oy -= (unsigned)p.Ho;
             ++e_n;
         }
-        f32x4 v = *(const f32x4 *)(ep + (erow0 + it * RPP) * EP_LD + ecol);
-        v.x = fmaxf(v.x + bias.x, relu_lo);
-        v.y = fmaxf(v.y + bias.y, relu_lo);
-        v.z = fmaxf(v.z + bias.z, relu_lo);
-        v.w = fmaxf(v.w + bias.w, relu_lo);
-        v += rall[it];
-        v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
-        v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
-        v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
-        v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
-        vout[it] = v;
+    }
+    // Round 6 (hvn_conv_x3g.hip has the argument): the arithmetic in the 8 forms {bias + ReLU | neither} x {residual | none} x {block BN-ReLU |
+    // none}; what a launch does not have was computed as an identity before (max(acc + 0, -inf), + 0, max(fma(., 1, 0), -inf)): same bits, 5 VALU
+    // per output element whatever the launch needed.
+    auto finish = [&](auto hb_t, auto hr_t, auto hp_t) {
+        constexpr bool HB = decltype(hb_t)::value, HR = decltype(hr_t)::value, HP = decltype(hp_t)::value;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            f32x4 v = *(const f32x4 *)(ep + (erow0 + it * RPP) * EP_LD + ecol);
+            if constexpr (HB) {
+                v.x = fmaxf(v.x + bias.x, relu_lo);
+                v.y = fmaxf(v.y + bias.y, relu_lo);
+                v.z = fmaxf(v.z + bias.z, relu_lo);
+                v.w = fmaxf(v.w + bias.w, relu_lo);
+            }
+            if constexpr (HR) v += rall[it];
+            if constexpr (HP) {
+                v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
+                v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
+                v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
+                v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
+            }
+            vout[it] = v;
+        }
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool hb = p.bias != nullptr || p.relu;
+#if defined(HVN_X3G_FULL_EPI) && HVN_X3G_FULL_EPI
+        finish(T{}, T{}, T{});      // A/B build (lib.VARIANTS["fullepi"]): every operation, absent operands as identities
+#else
+        if (hb) {
+            if (has_res) {
+                if (has_post) finish(T{}, T{}, T{}); else finish(T{}, T{}, F{});
+            } else {
+                if (has_post) finish(T{}, F{}, T{}); else finish(T{}, F{}, F{});
+            }
+        } else {
+            if (has_res) {
+                if (has_post) finish(F{}, T{}, T{}); else finish(F{}, T{}, F{});
+            } else {
+                if (has_post) finish(F{}, F{}, T{}); else finish(F{}, F{}, F{});
+            }
+        }
+#endif
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));

@@ -423,51 +423,83 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
         e_oy = rem / (unsigned)p.Wo;
         e_ox = rem - e_oy * (unsigned)p.Wo;
     }
-    // two halves of NIT / 2 rows each (register pressure): all residual loads, every value finished, then the stores back to back
+    // two halves of NIT / 2 rows each (register pressure): all residual loads, every value finished, then the stores back to back.
+    // Round 6: the epilogue exists in the 8 forms {bias + ReLU | neither} x {residual | none} x {block BN-ReLU | none} and a launch takes the one
+    // that holds only ITS operations.  hvn_conv_igemm_x3 always computes max(acc + bias, lo) + res, max(fma(., qs, qb), lo') with bias = res = qb
+    // = 0, qs = 1 and lo = lo' = -inf standing in for what is absent: identities for every value that is not -0 (and an accumulator that
+    // started at +0 is never -0: x + y is -0 only if both are), so the bits are the same -- but 5 VALU per output element, 320 per thread,
+    // issued on SIMDs the co-resident workgroup's split needs (the bf16 chain kernel of this round is where that was measured).
+    auto epilogue = [&](auto has_bias_t, auto has_res_t, auto has_post_t) {
+        constexpr bool HB = decltype(has_bias_t)::value, HR = decltype(has_res_t)::value, HP = decltype(has_post_t)::value;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        constexpr int HN = NIT / 2;
-        f32x4 rall[HN];
-        long yoffs[HN];
-        bool oks[HN];
+        for (int half = 0; half < 2; ++half) {
+            constexpr int HN = NIT / 2;
+            f32x4 rall[HN];
+            long yoffs[HN];
+            bool oks[HN];
 #pragma unroll
-        for (int it = 0; it < HN; ++it) {
-            const unsigned m = m0 + erow0 + (half * HN + it) * RPP;
-            oks[it] = m < M && cok;
-            rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
-            yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
-            e_ox += RPP;
-            while (e_ox >= (unsigned)p.Wo) {
-                e_ox -= (unsigned)p.Wo;
-                ++e_oy;
+            for (int it = 0; it < HN; ++it) {
+                const unsigned m = m0 + erow0 + (half * HN + it) * RPP;
+                oks[it] = m < M && cok;
+                rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (HR && has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
+                yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+                e_ox += RPP;
+                while (e_ox >= (unsigned)p.Wo) {
+                    e_ox -= (unsigned)p.Wo;
+                    ++e_oy;
+                }
+                while (e_oy >= (unsigned)p.Ho) {
+                    e_oy -= (unsigned)p.Ho;
+                    ++e_n;
+                }
             }
-            while (e_oy >= (unsigned)p.Ho) {
-                e_oy -= (unsigned)p.Ho;
-                ++e_n;
+            f32x4 vout[HN];
+#pragma unroll
+            for (int it = 0; it < HN; ++it) {
+                f32x4 v = *(const f32x4 *)(ep + (erow0 + (half * HN + it) * RPP) * EP_LD + ecol);
+                if constexpr (HB) {
+                    v.x = fmaxf(v.x + bias.x, relu_lo);
+                    v.y = fmaxf(v.y + bias.y, relu_lo);
+                    v.z = fmaxf(v.z + bias.z, relu_lo);
+                    v.w = fmaxf(v.w + bias.w, relu_lo);
+                }
+                if constexpr (HR) v += rall[it];
+                if constexpr (HP) {
+                    v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
+                    v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
+                    v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
+                    v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
+                }
+                vout[it] = v;
             }
+#pragma unroll
+            for (int it = 0; it < HN; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < HN; ++it)
+                if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
         }
-        f32x4 vout[HN];
-#pragma unroll
-        for (int it = 0; it < HN; ++it) {
-            f32x4 v = *(const f32x4 *)(ep + (erow0 + (half * HN + it) * RPP) * EP_LD + ecol);
-            v.x = fmaxf(v.x + bias.x, relu_lo);
-            v.y = fmaxf(v.y + bias.y, relu_lo);
-            v.z = fmaxf(v.z + bias.z, relu_lo);
-            v.w = fmaxf(v.w + bias.w, relu_lo);
-            v += rall[it];
-            v.x = fmaxf(fmaf(v.x, qs.x, qb.x), post_lo);
-            v.y = fmaxf(fmaf(v.y, qs.y, qb.y), post_lo);
-            v.z = fmaxf(fmaf(v.z, qs.z, qb.z), post_lo);
-            v.w = fmaxf(fmaf(v.w, qs.w, qb.w), post_lo);
-            vout[it] = v;
+    };
+    const bool hb = p.bias != nullptr || p.relu;          // (a ReLU without a bias keeps the full first stage: max(acc + 0, 0))
+    using T = std::true_type;
+    using F = std::false_type;
+#if defined(HVN_X3G_FULL_EPI) && HVN_X3G_FULL_EPI
+    epilogue(T{}, T{}, T{});             // A/B build (lib.VARIANTS["fullepi"]): every operation, absent operands as identities
+    return;
+#endif
+    if (hb) {
+        if (has_res) {
+            if (has_post) epilogue(T{}, T{}, T{}); else epilogue(T{}, T{}, F{});
+        } else {
+            if (has_post) epilogue(T{}, F{}, T{}); else epilogue(T{}, F{}, F{});
         }
-#pragma unroll
-        for (int it = 0; it < HN; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int it = 0; it < HN; ++it)
-            if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
+    } else {
+        if (has_res) {
+            if (has_post) epilogue(F{}, T{}, T{}); else epilogue(F{}, T{}, F{});
+        } else {
+            if (has_post) epilogue(F{}, F{}, T{}); else epilogue(F{}, F{}, F{});
+        }
     }
 }
 

@@ -14,6 +14,7 @@ VARIANTS = {
     "nt": ("-DHVN_NT=1",),                          # prepared, NOT yet measured: non-temporal hints on the epilogue's residual loads / stores
     "lin_nt": ("-DHVN_EPI_LINEAR=1", "-DHVN_NT=1"),
     "noxcd": ("-DHVN_WINO_XCD=0", "-DHVN_CONV_XCD_CONTIG=0"),   # A/B: round-robin tile order in the Winograd input transform and the multi-tap convolutions
+    "fullepi": ("-DHVN_X3G_FULL_EPI=1",),           # A/B (round 6): hvn_conv_igemm_x3g with the one full epilogue of rounds 1-5 instead of the 8 operand-set forms
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
 CSRC = os.path.join(_HERE, "csrc")
