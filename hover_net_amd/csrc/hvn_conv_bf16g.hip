@@ -268,33 +268,48 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_bf16g(ConvArgs p)
     const float post_lo = has_post ? 0.f : -__builtin_inff();
     uint16_t *py = (uint16_t *)p.y;
     const uint16_t *pres = (const uint16_t *)p.res;
-    unsigned n, oy, ox;
+    // addresses: 32-bit byte offsets from the sample of the tile's first row, stepped row to row, through buffer descriptors (hvn_conv_x3g.hip:
+    // the 64-bit products per load / store cost several times the arithmetic they served); out-of-range offset = zeros loaded, store dropped
+    constexpr unsigned EOOB = 0x80000000u;
+    unsigned oy, ox, y_off, r_off;
+    const unsigned e_nblk = m0 / HoWo;
     {
         const unsigned m = m0 + erow0;
-        n = m / HoWo;
+        const unsigned n = m / HoWo;
         const unsigned rem = m - n * HoWo;
         oy = rem / (unsigned)p.Wo;
         ox = rem - oy * (unsigned)p.Wo;
+        y_off = (unsigned)(((long)(n - e_nblk) * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co) * 2);
+        r_off = (unsigned)(((long)(n - e_nblk) * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co) * 2);
     }
+    const unsigned y_step = (unsigned)(RPP * p.ysx * 2), y_row = (unsigned)((p.ysy - (long)p.Wo * p.ysx) * 2), y_smp = (unsigned)((p.ysn - (long)p.Ho * p.ysy) * 2);
+    const unsigned r_step = (unsigned)(RPP * p.rsx * 2), r_row = (unsigned)((p.rsy - (long)p.Wo * p.rsx) * 2), r_smp = (unsigned)((p.rsn - (long)p.Ho * p.rsy) * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void *)(py + (long)e_nblk * p.ysn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? pres + (long)e_nblk * p.rsn : py + (long)e_nblk * p.ysn), 0, 0x7fffffff, 0x00020000);
     // all residual loads of the tile first, every value finished in registers, then the stores back to back (one vmcnt for loads and stores)
     u32x4 rall[NIT];
-    long yoffs[NIT];
-    bool oks[NIT];
+    unsigned yoffs[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int rr = erow0 + it * RPP;
-        oks[it] = m0 + rr < M && cok;
+        const bool ok = m0 + rr < M && cok;
         rall[it] = (u32x4){0u, 0u, 0u, 0u};
-        if (has_res && oks[it]) rall[it] = *(const u32x4 *)(pres + (long)n * p.rsn + (long)oy * p.rsy + (long)ox * p.rsx + co);
-        yoffs[it] = (long)n * p.ysn + (long)oy * p.ysy + (long)ox * p.ysx + co;
+        if (has_res) rall[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? r_off : EOOB, 0, 0);
+        yoffs[it] = ok ? y_off : EOOB;
         ox += RPP;
+        y_off += y_step;
+        r_off += r_step;
         while (ox >= (unsigned)p.Wo) {
             ox -= (unsigned)p.Wo;
             ++oy;
+            y_off += y_row;
+            r_off += r_row;
         }
         while (oy >= (unsigned)p.Ho) {
             oy -= (unsigned)p.Ho;
-            ++n;
+            y_off += y_smp;
+            r_off += r_smp;
         }
     }
     u32x4 vout[NIT];
@@ -361,8 +376,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_bf16g(ConvArgs p)
     for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
-        if (oks[it]) *(u32x4 *)(py + yoffs[it]) = vout[it];
+    for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(vout[it], rsrc_y, yoffs[it], 0, 0);
 }
 
 template <int BM, bool PADDED, bool HAS_X2>
@@ -397,6 +411,9 @@ int hvn_launch_conv_bf16g(const ConvArgs &a, int bm, hipStream_t stream)
     const long ahead = (howo + bm - 2) / howo;       // samples a bm-row tile reaches beyond its first row's (hvn_launch_conv)
     const long span = ahead * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
     if (span < 0 || span * 2 >= (1L << 31)) return -1;
+    // the epilogue's 32-bit offsets into y / res, from the sample of the tile's first row
+    if ((ahead * a.ysn + (long)(a.Ho + 1) * a.ysy + (long)a.Wo * a.ysx) * 2 >= (1L << 31)) return -1;
+    if (a.res && (ahead * a.rsn + (long)(a.Ho + 1) * a.rsy + (long)a.Wo * a.rsx) * 2 >= (1L << 31)) return -1;
     if (a.x2 && (ahead * a.x2sn + (long)a.H * a.x2sy * a.stride2) * 2 >= (1L << 31)) return -1;
     const long kt = (long)a.KH * a.KW * ((a.Cin + HK - 1) / HK) + (a.x2 ? a.Cin2 / HK : 0);
     if ((long)(a.Cout + 128) * kt * HK * 2 >= (1L << 31)) return -1;

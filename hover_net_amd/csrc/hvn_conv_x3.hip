@@ -285,51 +285,49 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_x3(ConvArgs p)
     }
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
     const float post_lo = has_post ? 0.f : -__builtin_inff();
-    unsigned e_n, e_oy, e_ox;
+    // addresses: 32-bit byte offsets from the sample of the tile's first row, stepped row to row, through buffer descriptors (hvn_conv_x3g.hip:
+    // the 64-bit products per load / store were ~600 VALU per thread and tile); out-of-range offset = zeros loaded, store dropped
+    constexpr unsigned EOOB = 0x80000000u;
+    unsigned e_oy, e_ox, y_off, r_off;
+    const unsigned e_nblk = m0 / HoWo;
     {
         const unsigned m = m0 + erow0;
-        e_n = m / HoWo;
+        const unsigned e_n = m / HoWo;
         const unsigned rem = m - e_n * HoWo;
         e_oy = rem / (unsigned)p.Wo;
         e_ox = rem - e_oy * (unsigned)p.Wo;
+        y_off = (unsigned)(((long)(e_n - e_nblk) * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co) * 4);
+        r_off = (unsigned)(((long)(e_n - e_nblk) * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co) * 4);
     }
+    const unsigned y_step = (unsigned)(RPP * p.ysx * 4), y_row = (unsigned)((p.ysy - (long)p.Wo * p.ysx) * 4), y_smp = (unsigned)((p.ysn - (long)p.Ho * p.ysy) * 4);
+    const unsigned r_step = (unsigned)(RPP * p.rsx * 4), r_row = (unsigned)((p.rsy - (long)p.Wo * p.rsx) * 4), r_smp = (unsigned)((p.rsn - (long)p.Ho * p.rsy) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (long)e_nblk * p.ysn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? p.res + (long)e_nblk * p.rsn : p.y + (long)e_nblk * p.ysn), 0, 0x7fffffff, 0x00020000);
     // all residual loads of the tile, then every value finished in registers, then the stores back to back (one vmcnt for loads
     // and stores on gfx9: hvn_conv.hip has the measurements)
-    f32x4 rall[NIT];
-    {
-        unsigned a_n = e_n, a_oy = e_oy, a_ox = e_ox;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const unsigned m = m0 + erow0 + it * RPP;
-            rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (has_res && m < M && cok) rall[it] = *(const f32x4 *)(p.res + (long)a_n * p.rsn + (long)a_oy * p.rsy + (long)a_ox * p.rsx + co);
-            a_ox += RPP;
-            while (a_ox >= (unsigned)p.Wo) {
-                a_ox -= (unsigned)p.Wo;
-                ++a_oy;
-            }
-            while (a_oy >= (unsigned)p.Ho) {
-                a_oy -= (unsigned)p.Ho;
-                ++a_n;
-            }
-        }
-    }
-    f32x4 vout[NIT];
-    long yoffs[NIT];
-    bool oks[NIT];
+    f32x4 rall[NIT], vout[NIT];
+    unsigned yoffs[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const unsigned m = m0 + erow0 + it * RPP;
-        oks[it] = m < M && cok;
-        yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+        const bool ok = m < M && cok;
+        rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has_res) rall[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? r_off : EOOB, 0, 0));
+        yoffs[it] = ok ? y_off : EOOB;
         e_ox += RPP;
+        y_off += y_step;
+        r_off += r_step;
         while (e_ox >= (unsigned)p.Wo) {
             e_ox -= (unsigned)p.Wo;
             ++e_oy;
+            y_off += y_row;
+            r_off += r_row;
         }
         while (e_oy >= (unsigned)p.Ho) {
             e_oy -= (unsigned)p.Ho;
-            ++e_n;
+            y_off += y_smp;
+            r_off += r_smp;
         }
     }
     // Round 6 (hvn_conv_x3g.hip has the argument): the arithmetic in the 8 forms {bias + ReLU | neither} x {residual | none} x {block BN-ReLU |
@@ -382,8 +380,7 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_igemm_x3(ConvArgs p)
     for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
-        if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
+    for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vout[it]), rsrc_y, yoffs[it], 0, 0);
 }
 
 // Training: the fp32 weight packings change every step, so their bf16 planes are made on the device.  src = fp32 packings, any
@@ -466,6 +463,9 @@ int hvn_launch_conv_x3(const ConvArgs &a, int tile_n, int terms, hipStream_t str
     const long span = ahead * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
     if (span < 0 || span * 4 >= (1L << 31)) return -1;
     if (a.x2 && (ahead * a.x2sn + (long)a.H * a.x2sy * a.stride2) * 4 >= (1L << 31)) return -1;
+    // the epilogue's 32-bit offsets into y / res, from the sample of the tile's first row
+    if ((ahead * a.ysn + (long)(a.Ho + 1) * a.ysy + (long)a.Wo * a.ysx) * 4 >= (1L << 31)) return -1;
+    if (a.res && (ahead * a.rsn + (long)(a.Ho + 1) * a.rsy + (long)a.Wo * a.rsx) * 4 >= (1L << 31)) return -1;
     const long kt = (long)a.KH * a.KW * (a.Cin / XK) + (a.x2 ? a.Cin2 / XK : 0);
     if ((long)(a.Cout + 128) * kt * 192 >= (1L << 31)) return -1;
     const bool padded = a.pad_t > 0 || a.pad_l > 0 || (a.Ho - 1) * a.stride - a.pad_t + a.KH > a.H ||

@@ -415,14 +415,26 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     }
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
     const float post_lo = has_post ? 0.f : -__builtin_inff();
-    unsigned e_n, e_oy, e_ox;
+    // Addresses (round 6): 32-bit byte offsets from the sample of the tile's first row, stepped from row to row with scalar increments, through
+    // buffer descriptors -- the epilogue used to form `(long)n * sn + (long)oy * sy + (long)ox * sx` for every residual load and every store:
+    // ~140 64-bit multiply-adds and ~600 VALU instructions per thread and tile (hipcc's assembly), four times the arithmetic it serves, issued on
+    // the SIMDs the co-resident workgroup's split runs on.  A row past the batch or a column past cout gets the out-of-range offset: the load
+    // returns zeros, the store is dropped.
+    unsigned e_oy, e_ox, y_off, r_off;
     {
         const unsigned m = m0 + erow0;
-        e_n = m / HoWo;
+        const unsigned e_n = m / HoWo;
         const unsigned rem = m - e_n * HoWo;
         e_oy = rem / (unsigned)p.Wo;
         e_ox = rem - e_oy * (unsigned)p.Wo;
+        y_off = (unsigned)(((long)(e_n - n_blk) * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co) * 4);
+        r_off = (unsigned)(((long)(e_n - n_blk) * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co) * 4);
     }
+    const unsigned y_step = (unsigned)(RPP * p.ysx * 4), y_row = (unsigned)((p.ysy - (long)p.Wo * p.ysx) * 4), y_smp = (unsigned)((p.ysn - (long)p.Ho * p.ysy) * 4);
+    const unsigned r_step = (unsigned)(RPP * p.rsx * 4), r_row = (unsigned)((p.rsy - (long)p.Wo * p.rsx) * 4), r_smp = (unsigned)((p.rsn - (long)p.Ho * p.rsy) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void *)(p.y + (long)n_blk * p.ysn), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? p.res + (long)n_blk * p.rsn : p.y + (long)n_blk * p.ysn), 0, 0x7fffffff, 0x00020000);
     // two halves of NIT / 2 rows each (register pressure): all residual loads, every value finished, then the stores back to back.
     // Round 6: the epilogue exists in the 8 forms {bias + ReLU | neither} x {residual | none} x {block BN-ReLU | none} and a launch takes the one
     // that holds only ITS operations.  hvn_conv_igemm_x3 always computes max(acc + bias, lo) + res, max(fma(., qs, qb), lo') with bias = res = qb
@@ -435,23 +447,28 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
         for (int half = 0; half < 2; ++half) {
             constexpr int HN = NIT / 2;
             f32x4 rall[HN];
-            long yoffs[HN];
-            bool oks[HN];
+            unsigned yoffs[HN];
 #pragma unroll
             for (int it = 0; it < HN; ++it) {
                 const unsigned m = m0 + erow0 + (half * HN + it) * RPP;
-                oks[it] = m < M && cok;
+                const bool ok = m < M && cok;
                 rall[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (HR && has_res && oks[it]) rall[it] = *(const f32x4 *)(p.res + (long)e_n * p.rsn + (long)e_oy * p.rsy + (long)e_ox * p.rsx + co);
-                yoffs[it] = (long)e_n * p.ysn + (long)e_oy * p.ysy + (long)e_ox * p.ysx + co;
+                if (HR && has_res) rall[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? r_off : OOB, 0, 0));
+                yoffs[it] = ok ? y_off : OOB;
+                // next row of this thread: RPP pixels on; the wraps add what a row / a sample is longer than its pixels
                 e_ox += RPP;
+                y_off += y_step;
+                r_off += r_step;
                 while (e_ox >= (unsigned)p.Wo) {
                     e_ox -= (unsigned)p.Wo;
                     ++e_oy;
+                    y_off += y_row;
+                    r_off += r_row;
                 }
                 while (e_oy >= (unsigned)p.Ho) {
                     e_oy -= (unsigned)p.Ho;
-                    ++e_n;
+                    y_off += y_smp;
+                    r_off += r_smp;
                 }
             }
             f32x4 vout[HN];
@@ -477,8 +494,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
             for (int it = 0; it < HN; ++it) asm volatile("" : "+v"(vout[it]), "+v"(yoffs[it]));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int it = 0; it < HN; ++it)
-                if (oks[it]) *(f32x4 *)(p.y + yoffs[it]) = vout[it];
+            for (int it = 0; it < HN; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vout[it]), rsrc_y, yoffs[it], 0, 0);
         }
     };
     const bool hb = p.bias != nullptr || p.relu;          // (a ReLU without a bias keeps the full first stage: max(acc + 0, 0))
@@ -553,6 +569,9 @@ int hvn_launch_conv_x3g(const ConvArgs &a, int bm, int terms, hipStream_t stream
     const long span = ahead * a.xsn + (long)(a.H + a.KH) * a.xsy + (long)(a.W + a.KW) * a.xsx;
     if (span < 0 || span * 4 >= (1L << 31)) return -1;
     if (a.x2 && (ahead * a.x2sn + (long)a.H * a.x2sy * a.stride2) * 4 >= (1L << 31)) return -1;
+    // the epilogue's 32-bit offsets into y / res, from the sample of the tile's first row
+    if ((ahead * a.ysn + (long)(a.Ho + 1) * a.ysy + (long)a.Wo * a.ysx) * 4 >= (1L << 31)) return -1;
+    if (a.res && (ahead * a.rsn + (long)(a.Ho + 1) * a.rsy + (long)a.Wo * a.rsx) * 4 >= (1L << 31)) return -1;
     const long kt = (long)a.KH * a.KW * (a.Cin / GK) + (a.x2 ? a.Cin2 / GK : 0);
     if ((long)(a.Cout + 128) * kt * 192 >= (1L << 31)) return -1;
     const bool padded = a.pad_t > 0 || a.pad_l > 0 || (a.Ho - 1) * a.stride - a.pad_t + a.KH > a.H ||
