@@ -255,14 +255,16 @@ def test_bf16_trained_like_network_keeps_the_segmentation():
 
     THE TOLERANCE, as measured (round 6; round 5 had declared "no tile below PQ 0.95" from ONE fit, and the driver's box drew another
     fit, whose worst tile scored 0.857).  `profiles/r06_bf16_pq_table_box_*.json` (tools/bf16_pq_table.py: 8 fits x 48 tiles, 2 300
-    instances): bf16 changes the segmentation of about ONE INSTANCE IN A THOUSAND -- 2 of 2 300 had no IoU > 0.5 partner (one merged
-    into its neighbour, one lost its marker; |dp| <= 0.014, |d hv| <= 0.031 around them, no nucleus-threshold flips: the flips are in the
-    marker map, which thresholds a 21-tap Sobel of h / v) -- while two fp32 evaluations in different summation orders (default vs
-    conservative lowering) changed none.  A tile of n nuclei in which one flips scores 1 - 1/n at best, so a per-tile floor is a
+    fp32 instances, made twice -- two builds of the trainer, i.e. two different sets of eight checkpoints): bf16 changes the segmentation of
+    about ONE INSTANCE IN A THOUSAND -- 2 of 2 300 and 3 of 2 304 had no IoU > 0.5 partner (merged into a neighbour, or their marker lost to
+    the 10-pixel filter; |dp| <= 0.014, |d hv| <= 0.046 around them, no nucleus-threshold flips: the flips are in the marker map, which
+    thresholds a 21-tap Sobel of h / v) -- while two fp32 evaluations in different summation orders (default vs conservative lowering)
+    changed none of them.  A tile of n nuclei in which one flips scores 1 - 1/n at best, so a per-tile floor is a
     statement about tile size, not about bf16; what is declared is per INSTANCE:
         paired instances / instances >= 0.995 over the 48 tiles, mean PQ >= 0.99, no tile with more than ONE instance without a
         partner, at most 2 of the 48 tiles below PQ 0.95
-    (this checkpoint, which is the same on every box since the fit is deterministic: 1 of 575 without a partner, mean PQ 0.9977).
+    (worst fit of the 16 measured: 1 of 287 without a partner = 0.9982, mean PQ 0.9957, one tile at 0.80).  The checkpoint of this test is
+    the same on every box and every run of one build, since the fit is deterministic.
     The fit being deterministic is checked by test_gpu_train.py::test_two_fits_give_the_same_checkpoint."""
     import fit_util
     from hover_net_amd import post_proc, run_desc
