@@ -335,6 +335,27 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_f32(const WgradArgs p)
     const int og = p.Cout / p.groups;
     float *pout = p.part ? p.part + (long)blockIdx.y * p.part_stride + (long)blockIdx.z * p.wb : pdw;
     const bool det = p.part != nullptr;
+    if (p.groups == 1) {
+        // dense launches (round 6, as hvn_wgrad_x3.hip): one 64-bit element offset per thread, 32-bit offsets from it for the lane's elements
+        const int co0 = m0 + wm * WM + 4 * lh * MBA, ci0 = n0 + wn * WN + l31 * MBB;
+        float *pbase = pout + ((long)co0 * taps + tap) * p.Cin_g + ci0;
+        const unsigned row = (unsigned)(taps * p.Cin_g);
+#pragma unroll
+        for (int i = 0; i < MBA; ++i)
+#pragma unroll
+            for (int j = 0; j < MBB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dco = (8 * (r >> 2) + (r & 3)) * MBA + i;
+                    if (co0 + dco >= p.Cout) continue;
+                    float *d = pbase + (unsigned)dco * row + (unsigned)j;
+                    if (det)
+                        *d = acc[i][j][r];
+                    else
+                        unsafeAtomicAdd(d, acc[i][j][r]);
+                }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MBA; ++i)
 #pragma unroll

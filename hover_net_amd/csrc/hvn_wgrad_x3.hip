@@ -173,20 +173,25 @@ __global__ __launch_bounds__(256, 2) void hvn_conv_wgrad_x3(const WgradArgs p)
     }
 
     // epilogue: D[m][n] of block (i, j): m = 8*(r/4) + 4*lh + (r%4) -> output channel, n = l31 -> input channel; fp32 atomics (split K)
-    // deterministic form (p.part): this split's tile is stored into copy blockIdx.y and hvn_reduce_parts adds the copies in split order
+    // deterministic form (p.part): this split's tile is stored into copy blockIdx.y and hvn_reduce_parts adds the copies in split order.
+    // Addresses (round 6, as the conv epilogues): ONE 64-bit element offset per thread -- (first output channel, tap, first input channel) --
+    // and 32-bit offsets from it for the 64 elements a lane holds (the row of an output channel is taps x Cin_g floats long); the
+    // per-element `((long)co * taps + tap) * Cin_g + ci` was ~800 VALU instructions per thread for 64 stores.
     const int taps = p.KH * p.KW;
     float *pout = p.part ? p.part + (long)blockIdx.y * p.part_stride + (long)blockIdx.z * p.wb : pdw;
     const bool det = p.part != nullptr;
+    const int co0 = m0 + wm * 64 + 4 * lh, ci0 = n0 + wn * 64 + l31;
+    float *pbase = pout + ((long)co0 * taps + tap) * p.Cin_g + ci0;
+    const unsigned row = (unsigned)(taps * p.Cin_g);          // floats between consecutive output channels
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ci = n0 + wn * 64 + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                if (co >= p.Cout) continue;
-                float *d = pout + ((long)co * taps + tap) * p.Cin_g + ci;
+                const int dco = i * 32 + 8 * (r >> 2) + (r & 3);
+                if (co0 + dco >= p.Cout) continue;
+                float *d = pbase + (unsigned)dco * row + (unsigned)(j * 32);
                 if (det)
                     *d = acc[i][j][r];
                 else
