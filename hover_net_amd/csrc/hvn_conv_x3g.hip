@@ -70,7 +70,17 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
 {
     constexpr int NTHR = BM * 2;                 // 256 | 512
     constexpr int NW = NTHR / 64;                // waves
-    constexpr int WAVES_N = 2;
+    // Wave tile: 64 x 64 (TI = TJ = 2: two waves side by side read and split the same A fragment -- 88 VALU per slice and wave next to 24 MFMAs).
+    // Round 6 measured the alternative, 32 pixel rows x all 128 channels per wave (HVN_X3G_WN=1, lib.VARIANTS["wn1"]: the split done once, 44
+    // VALU per slice, 14 instead of 10 fragment reads, 210 - 248 VGPRs, same per-accumulator MFMA order = same bits): conv launches of a step 42.03
+    // vs 41.71 ms, bench 755.4 vs 754.8 tiles/s -- neutral, i.e. the split's VALU is NOT what holds the matrix pipe at 49 % (profiles/r06_x3g_wave_tile_ab.txt).
+#ifndef HVN_X3G_WN
+#define HVN_X3G_WN 2
+#endif
+    constexpr int WAVES_N = HVN_X3G_WN;
+    constexpr int TI = BM / (NW / WAVES_N) / 32;      // 32-row tiles per wave: 1 | 2
+    constexpr int TJ = GBN / WAVES_N / 32;            // 32-column tiles per wave: 4 | 2
+    static_assert(TI * TJ == 4, "four accumulators per wave");
     constexpr int NA = BM == 256 ? 3 : 2;        // A ring depth (stages)
     constexpr int A_STAGE = BM * 128;            // bytes: [BM rows][32 floats]
     constexpr int GA = A_STAGE / 1024 / NW;      // LDS-DMA instructions per wave and A stage (1 KiB each): 4
@@ -244,34 +254,34 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment addresses: lane (l31, lh) feeds row l31 of a 32-row tile, k = 16 q + 8 lh .. + 7
     const int akey = (l31 >> 1) & 7, bkey = (l31 >> 2) & 3;
-    const unsigned a_row = (unsigned)((wm * 64 + l31) * 128);
-    const unsigned b_row = (unsigned)((wn * 64 + l31) * 64);
+    const unsigned a_row = (unsigned)((wm * (32 * TI) + l31) * 128);
+    const unsigned b_row = (unsigned)((wn * (32 * TJ) + l31) * 64);
     const int taps = p.KH * p.KW;
     struct Frag {
-        bf16x8 a[2][3], b[2][3];
+        bf16x8 a[TI][3], b[TJ][3];
     };
     // one 16-deep slice (k-step kt, half q) of this wave's operands: A rows read raw, pre-activated and split here; B planes as stored
     auto prep = [&](Frag &f, int kt, int q, int c_slab) {
         const unsigned char *as = gs + (kt % NA) * A_STAGE + a_row;
         const unsigned char *bs = gs + B_OFF + (kt & 1) * G_BSTAGE + b_row;
-        f32x4 v0[2], v1[2];
+        f32x4 v0[TI], v1[TI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TI; ++i) {
             v0[i] = *(const f32x4 *)(as + i * 32 * 128 + (((4 * q + 2 * lh) ^ akey) << 4));
             v1[i] = *(const f32x4 *)(as + i * 32 * 128 + (((4 * q + 2 * lh + 1) ^ akey) << 4));
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
                 f.b[j][pl] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(bs + pl * (GBN * 64) + j * 32 * 64 + (((2 * q + lh) ^ bkey) << 4)));
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
                 pb0 = pvb[q][0], pb1 = pvb[q][1];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TI; ++i) {
                 v0[i].x = fmaxf(fmaf(v0[i].x, ps0.x, pb0.x), 0.f);
                 v0[i].y = fmaxf(fmaf(v0[i].y, ps0.y, pb0.y), 0.f);
                 v0[i].z = fmaxf(fmaf(v0[i].z, ps0.z, pb0.z), 0.f);
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) split3x8(v0[i], v1[i], f.a[i][0], f.a[i][1], f.a[i][2]);
+        for (int i = 0; i < TI; ++i) split3x8(v0[i], v1[i], f.a[i][0], f.a[i][1], f.a[i][2]);
     };
     // smallest partial products first; (plane of a, plane of b) with 0 = high, 2 = low -- hvn_conv_igemm_x3's order, per accumulator.
     // The 4 NTERMS MFMAs of a slice are numbered in that order; mma(f, lo, hi) issues numbers lo .. hi - 1.
@@ -313,9 +323,9 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
                 const int pb = s - pa;
                 if (pb < 0 || pb > 2) continue;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < TJ; ++j) {
                         if (idx >= lo && idx < hi) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[j][pb], acc[i][j], 0, 0, 0);
                         ++idx;
                     }
@@ -326,11 +336,11 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     // split runs in the shadow of this slice's matrix work
     auto interleave = [&]() {
         if constexpr (PRE_GLB) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);      // the next k-step's prologue vectors (first phase only)
-        __builtin_amdgcn_sched_group_barrier(0x100, PRE_LDS ? 14 : 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TI + 3 * TJ + (PRE_LDS ? 4 : 0), 0);
 #pragma unroll
         for (int g = 0; g < NM; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, TI == 1 ? 3 : 5, 0);
         }
     };
 
@@ -396,13 +406,13 @@ __global__ __launch_bounds__(BM * 2, 2) void hvn_conv_igemm_x3g(ConvArgs p)
     // ---- epilogue (fp32, as hvn_conv_igemm_x3): accumulators -> LDS tile -> bias / ReLU / + residual / block BN-ReLU -> 16-byte stores
     float *ep = (float *)gs;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                ep[row * EP_LD + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                const int row = wm * (32 * TI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ep[row * EP_LD + wn * (32 * TJ) + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
     f32x4 bias = {0.f, 0.f, 0.f, 0.f}, qs = {1.f, 1.f, 1.f, 1.f}, qb = bias;

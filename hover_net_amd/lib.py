@@ -15,6 +15,7 @@ VARIANTS = {
     "lin_nt": ("-DHVN_EPI_LINEAR=1", "-DHVN_NT=1"),
     "noxcd": ("-DHVN_WINO_XCD=0", "-DHVN_CONV_XCD_CONTIG=0"),   # A/B: round-robin tile order in the Winograd input transform and the multi-tap convolutions
     "fullepi": ("-DHVN_X3G_FULL_EPI=1",),           # A/B (round 6): hvn_conv_igemm_x3g with the one full epilogue of rounds 1-5 instead of the 8 operand-set forms
+    "wn1": ("-DHVN_X3G_WN=1",),                      # A/B (round 6, neutral): hvn_conv_igemm_x3g with 32 x 128 wave tiles (every wave splits its A fragment once)
     "prev": (),                                      # same-box A/B against ANOTHER CHECKOUT's library: built by hand into libhvn_hip_prev.so (never by build_variant)
     "trace": ("-DHVN_TRACE_FINE=1",),               # diagnosis: per-phase timestamps of the conv epilogue (with HVN_CONV_TRACE, tools/conv_trace.py --fine)
 }
