@@ -5,9 +5,9 @@ P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $P -d gpurun_out/r05_pmcX$i -o p -- python bench.py --pmc-child > gpurun_out/r05_pmcX$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $P -d gpurun_out/r06_pmcX$i -o p -- python bench.py --pmc-child > gpurun_out/r06_pmcX$i.log 2>&1
   echo "pass $i rc=$?"
 done
-python tools/pmc_stall.py gpurun_out/r05_pmc_stall.json $(find gpurun_out/r05_pmcX1 gpurun_out/r05_pmcX2 gpurun_out/r05_pmcX3 -name "*_results.db") 2>&1 | tail -12
-tail -3 gpurun_out/r05_pmcX2.log
-rm -rf gpurun_out/r05_pmcX1 gpurun_out/r05_pmcX2 gpurun_out/r05_pmcX3
+python tools/pmc_stall.py gpurun_out/r06_pmc_stall.json $(find gpurun_out/r06_pmcX1 gpurun_out/r06_pmcX2 gpurun_out/r06_pmcX3 -name "*_results.db") 2>&1 | tail -12
+tail -3 gpurun_out/r06_pmcX2.log
+rm -rf gpurun_out/r06_pmcX1 gpurun_out/r06_pmcX2 gpurun_out/r06_pmcX3
