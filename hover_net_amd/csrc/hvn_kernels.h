@@ -223,7 +223,7 @@ int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, 
 struct BnArgs {
     const float *z;       // conv output (pre-normalisation)
     long zsn, zsy, zsx;
-    const float *a;       // backward: the forward output relu(bn(z))
+    const float *a;       // backward: the forward output relu(bn(z)) -- NOT READ since round 6 (the ReLU mask is recomputed from z, save[0..2C))
     float *a_out;         // forward: where it is written
     long asn, asy, asx;
     const float *da;      // backward: gradient of a
@@ -237,6 +237,7 @@ struct BnArgs {
     float *dgamma, *dbeta, *running_mean, *running_var;
     int N, H, W, C, lq, nparts;
     float eps, momentum;
+    int dz_store;         // backward: dz = ... instead of dz += ... (the caller knows this launch is the first writer of dz in the step)
 };
 int hvn_launch_bn_forward(BnArgs a, hipStream_t stream);
 int hvn_launch_bn_backward(BnArgs a, hipStream_t stream);

@@ -599,6 +599,11 @@ int hvn_launch_wino_dw(const float *du, float *dg, const float *gmat, int cout, 
 // g = da * (a > 0), xhat = (z - mean) * rstd.  A thread owns one channel quad (LQ lanes per row, 256/LQ rows per
 // block pass), accumulates in double (8 rows in flight), the block combines through LDS and writes one partial per
 // (row block, channel) to ws[block][2*c + {0,1}]; the finalize kernels sum the partials in a fixed order.
+// The forward value before the ReLU (a product and a sum, two roundings: the library is built with -ffp-contract=off): the backward
+// pass recomputes it from z and the saved scale / shift to get the ReLU mask `a > 0` instead of reading a -- the same two instructions
+// on the same operands, hence the same predicate.
+__device__ inline float bn_act(float z, float sc, float sh) { return z * sc + sh; }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
 {
@@ -609,8 +614,10 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
     const int CQ = p.C >> 2;
     const bool act = q < CQ;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    f32x4 mean = (f32x4){0.f, 0.f, 0.f, 0.f}, rstd = mean;
+    f32x4 mean = (f32x4){0.f, 0.f, 0.f, 0.f}, rstd = mean, sc = mean, sh = mean;
     if (MODE == 1 && act) {
+        sc = *(const f32x4 *)(p.save + q * 4);
+        sh = *(const f32x4 *)(p.save + p.C + q * 4);
         mean = *(const f32x4 *)(p.save + 2 * p.C + q * 4);
         rstd = *(const f32x4 *)(p.save + 3 * p.C + q * 4);
     }
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
     const unsigned rstep = gridDim.y * rper;
     constexpr int UN = 8;   // independent rows per iteration: all their loads are in flight before any is consumed
     for (unsigned r0 = blockIdx.y * rper + rsub; r0 < rows && act; r0 += UN * rstep) {
-        f32x4 z[UN], a[UN], da[UN];
+        f32x4 z[UN], da[UN];
         bool ok[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -630,10 +637,7 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
             const unsigned n = t / H;
             const unsigned y = t - n * H;
             z[u] = *(const f32x4 *)(p.z + (long)n * p.zsn + (long)y * p.zsy + (long)x * p.zsx + q * 4);
-            if (MODE == 1) {
-                a[u] = *(const f32x4 *)(p.a + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4);
-                da[u] = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
-            }
+            if (MODE == 1) da[u] = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(256) void hvn_bn_reduce(const BnArgs p)
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = a[u][e] > 0.f ? da[u][e] : 0.f;
+                    const float g = bn_act(z[u][e], sc[e], sh[e]) > 0.f ? da[u][e] : 0.f;      // a > 0, a recomputed (not re-read)
                     const float xh = (z[u][e] - mean[e]) * rstd[e];
                     s[e] += (double)g;
                     s[4 + e] += (double)(g * xh);
@@ -681,7 +685,8 @@ __device__ inline bool bn_part_sums(const BnArgs &p, double &s1, double &s2, int
     c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < p.C)
-        for (int k = pl; k < p.nparts; k += 8) {
+#pragma unroll 4
+        for (int k = pl; k < p.nparts; k += 8) {            // (unrolled: four pairs of loads in flight, the adds in the same order)
             a += p.ws[(long)k * 2 * p.C + 2 * c];
             b += p.ws[(long)k * 2 * p.C + 2 * c + 1];
         }
@@ -733,8 +738,8 @@ __global__ __launch_bounds__(256) void hvn_bn_bwd_final(const BnArgs p)
     p.coef[2 * p.C + c] = (float)(s2 / n);
 }
 
-// MODE 0: a = relu(z*scale + shift).  MODE 1: dz += c1 * (g - c2 - xhat*c3).
-template <int MODE>
+// MODE 0: a = relu(z*scale + shift).  MODE 1: dz (+)= c1 * (g - c2 - xhat*c3).
+template <int MODE, bool STORE = false>
 __global__ __launch_bounds__(256) void hvn_bn_apply(const BnArgs p, long total)
 {
     const unsigned CQ = p.C >> 2, W = p.W, H = p.H;
@@ -750,19 +755,20 @@ __global__ __launch_bounds__(256) void hvn_bn_apply(const BnArgs p, long total)
             const f32x4 sc = *(const f32x4 *)(p.save + q * 4), sh = *(const f32x4 *)(p.save + p.C + q * 4);
             f32x4 a;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = fmaxf(z[e] * sc[e] + sh[e], 0.f);
+            for (int e = 0; e < 4; ++e) a[e] = fmaxf(bn_act(z[e], sc[e], sh[e]), 0.f);
             *(f32x4 *)(p.a_out + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4) = a;
         } else {
-            const f32x4 a = *(const f32x4 *)(p.a + (long)n * p.asn + (long)y * p.asy + (long)x * p.asx + q * 4);
             const f32x4 da = *(const f32x4 *)(p.da + (long)n * p.gsn + (long)y * p.gsy + (long)x * p.gsx + q * 4);
+            const f32x4 sc = *(const f32x4 *)(p.save + q * 4), sh = *(const f32x4 *)(p.save + p.C + q * 4);
             const f32x4 mean = *(const f32x4 *)(p.save + 2 * p.C + q * 4), rstd = *(const f32x4 *)(p.save + 3 * p.C + q * 4);
             const f32x4 c1 = *(const f32x4 *)(p.coef + q * 4), c2 = *(const f32x4 *)(p.coef + p.C + q * 4),
                         c3 = *(const f32x4 *)(p.coef + 2 * p.C + q * 4);
             float *dzp = p.dz + (long)n * p.dsn + (long)y * p.dsy + (long)x * p.dsx + q * 4;
-            f32x4 dz = *(const f32x4 *)dzp;
+            f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!STORE) dz = *(const f32x4 *)dzp;        // STORE: this launch is the first writer of dz in the step (train_plan first-writer rule)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float g = a[e] > 0.f ? da[e] : 0.f;
+                const float g = bn_act(z[e], sc[e], sh[e]) > 0.f ? da[e] : 0.f;
                 const float xh = (z[e] - mean[e]) * rstd[e];
                 dz[e] += c1[e] * (g - c2[e] - xh * c3[e]);
             }
@@ -801,7 +807,7 @@ int hvn_launch_bn_forward(BnArgs a, hipStream_t stream)
     const long total = (long)a.N * a.H * a.W * (a.C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(hvn_bn_apply<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
+    hipLaunchKernelGGL((hvn_bn_apply<0, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
     return launch_ok();
 }
 
@@ -816,7 +822,10 @@ int hvn_launch_bn_backward(BnArgs a, hipStream_t stream)
         const long total = (long)a.N * a.H * a.W * (a.C / 4);
         long blocks = (total + 255) / 256;
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(hvn_bn_apply<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
+        if (a.dz_store)
+            hipLaunchKernelGGL((hvn_bn_apply<1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
+        else
+            hipLaunchKernelGGL((hvn_bn_apply<1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, total);
     }
     return launch_ok();
 }

@@ -102,6 +102,7 @@ static int run_top(const hvn_top *t, int batch, hipStream_t s, long idx, float *
             if (!view_ok(t->dx)) return tfail(HVN_E_ARG, "bn backward: bad dz view", idx);
             a.dz = (float *)t->dx.base; a.dsn = t->dx.sn; a.dsy = t->dx.sy; a.dsx = t->dx.sx;
         }
+        a.dz_store = t->mode & 1;
         a.dgamma = (float *)t->p[3]; a.dbeta = (float *)t->p[4]; a.coef = (float *)t->p[5];
         if (!a.dgamma || !a.dbeta || !a.coef) return tfail(HVN_E_ARG, "bn backward: null pointer", idx);
         return hvn_launch_bn_backward(a, s);

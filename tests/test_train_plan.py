@@ -70,3 +70,41 @@ def test_plan_structure_invariants():
     F = TP.TrainPlan("original", 5, True)
     fb = {b.name: b for b in F.bufs}
     assert fb["d0.units.1.z1"].g is None and fb["d1.out"].g is None and fb["d0.shortcut"].g is not None and fb["conv0.z"].g is not None
+
+
+@pytest.mark.parametrize("mode,nt,freeze", [("original", 5, False), ("original", 5, True), ("fast", None, False)])
+def test_first_writer_rule_is_sound(mode, nt, freeze):
+    """train_plan._first_writers, checked statically for every configuration the engine builds: (a) an op marked `store` is the first op
+    of the backward list that touches its destination buffer at all; (b) a buffer the engine does not clear (`zero` False) is written
+    completely by such an op before any op reads it; (c) the layout puts the cleared buffers first, disjoint and aligned; (d) most of the
+    arena needs no clearing (the point of the exercise).  test_lowering_matches_oracle_fp64 executes the same flags with NaN in the
+    uncleared buffers against the autograd oracle."""
+    P = TrainPlan(mode, nt, freeze)
+    _, gelems = P.layout(2)
+    seen_w, seen_r = {}, {}
+    for i, op in enumerate(P.bwd):
+        for k in ("dy", "da"):
+            v = getattr(op, k, None)
+            if v is not None:
+                seen_r.setdefault(id(v.buf), i)
+        for k in ("dx", "dz", "dlo", "dskip"):
+            v = getattr(op, k, None)
+            if v is None:
+                continue
+            if getattr(op, "store", False) and k in ("dx", "dz"):
+                assert id(v.buf) not in seen_w and id(v.buf) not in seen_r, op.name
+            seen_w.setdefault(id(v.buf), (i, op, v))
+    n_store = 0
+    for g in P.gbufs:
+        if g.zero:
+            continue
+        i, op, v = seen_w[id(g)]
+        assert op.store and op.kind in ("bnrelu_bwd", "dgrad"), g.name
+        assert (v.y0, v.x0, v.c0, v.step, v.h, v.w, v.c) == (0, 0, 0, 1, g.h, g.w, g.c), g.name
+        assert seen_r.get(id(g), 1 << 30) > i, g.name
+        n_store += 1
+    spans = sorted((g.off, g.off + g.size(2), g.zero) for g in P.gbufs)
+    for (a0, a1, _), (b0, _, _) in zip(spans, spans[1:]):
+        assert a1 <= b0 and b0 % 64 == 0
+    assert all(z for o, _, z in spans if o < P.gzero_elems) and not any(z for o, _, z in spans if o >= P.gzero_elems)
+    assert spans[-1][1] <= gelems and P.gzero_elems < 0.3 * gelems and n_store > 100

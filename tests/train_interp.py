@@ -138,8 +138,8 @@ class Interp:
 
     def backward(self, dlogits):
         sd = self.sd
-        for g in self.gbuf.values():
-            g.zero_()
+        for gb in self.P.gbufs:                      # the engine clears only the buffers the plan marks (train_plan._first_writers):
+            self.gbuf[id(gb)].fill_(0.0 if getattr(gb, "zero", True) else float("nan"))    # whatever the others hold must never be read
         for g in self.grads.values():
             g.zero_()
         for op in self.P.bwd:
@@ -156,11 +156,12 @@ class Interp:
                 self.grads[k + ".weight"] += dg
                 self.grads[k + ".bias"] += db
                 if op.dz is not None:
-                    self.view(op.dz).add_(dz)
+                    self.view(op.dz).copy_(dz) if getattr(op, "store", False) else self.view(op.dz).add_(dz)
             elif op.kind == "wgrad":
                 self.grads[op.wkey] += wgrad_ref(op, self.view(op.x), self.view(op.dy), sd[op.wkey].shape)
             elif op.kind == "dgrad":
-                self.view(op.dx).add_(dgrad_ref(op, self.view(op.dy), sd[op.wkey], (op.dx.h, op.dx.w)))
+                dx = dgrad_ref(op, self.view(op.dy), sd[op.wkey], (op.dx.h, op.dx.w))
+                self.view(op.dx).copy_(dx) if getattr(op, "store", False) else self.view(op.dx).add_(dx)
             elif op.kind == "upadd_bwd":
                 dy = self.view(op.dy)
                 if op.dlo is not None:
