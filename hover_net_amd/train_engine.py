@@ -112,8 +112,18 @@ class TrainEngine:
         self.sums = torch.zeros(64, dtype=torch.float64, device=dev)
         self.sobel_ws = torch.empty((self.n, ho, ho, 2), dtype=torch.float32, device=dev)
         cmax = max(P.bns.values())
-        self.bn_ws = torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev)     # HVN_BN_MAX_PARTS partial sums
-        self.bn_coef = torch.empty(3 * cmax, dtype=torch.float32, device=dev)
+        # Branch streams (round 6): the decoder branches (np / hv / tp, net_desc.py:77-97) are independent between the encoder's output and
+        # the loss, and at the reference's batch of 4 per GPU (opt.py:75-76) one branch's launches fill a fraction of the 256 CUs -- each
+        # branch's section of the forward and of the backward list runs on its own HIP stream, with its own scratch set (BN partial sums
+        # and coefficients, transform-domain tensors, the deterministic-reduce workspace).  What the branches ADD to shared gradient
+        # buffers (the skips' and conv_bot's output gradients, `upadd_bwd`) is deferred to after the join and runs in the single-stream
+        # order: same sums in the same order, same bits (tests/test_gpu_train.py).  HVN_TRAIN_BRANCH_STREAMS=0: one stream.
+        self.branches = arch.branch_names(net.nr_types)
+        self.branch_streams = os.environ.get("HVN_TRAIN_BRANCH_STREAMS", "1") != "0"
+        self._nsets = len(self.branches) if self.branch_streams else 1
+        self._side = [torch.cuda.Stream(device=dev) for _ in range(self._nsets - 1)]
+        self.bn_ws = [torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev) for _ in range(self._nsets)]     # HVN_BN_MAX_PARTS partial sums
+        self.bn_coef = [torch.empty(3 * cmax, dtype=torch.float32, device=dev) for _ in range(self._nsets)]
         self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
         self._bn_save_off, off = {}, 0
         for k, c in P.bns.items():
@@ -126,21 +136,35 @@ class TrainEngine:
         self._alloc_packs()
         self._alloc_wino_scratch()
         self._nbt = [self._buffers[k + ".num_batches_tracked"] for k in P.bns]
-        self.fwd_ops = self._lower([self._pack_ops()] + [self._lower_fwd(op) for op in P.fwd])
-        bwd_groups = [self._lower_bwd(op) for op in P.bwd]
-        self.bwd_ops = self._lower(bwd_groups)
-        self._use_x3()
+        fwd_groups = [self._pack_ops()] + [self._lower_fwd(op) for op in P.fwd]
+        self.fwd_ops = self._lower(fwd_groups)
+        self._fwd_runs = self._runs([-1] + [self._set_of(op.name, True) for op in P.fwd], fwd_groups)
+        bwd_groups, deferred = [], []
+        for op in P.bwd:
+            if op.kind == "upadd_bwd" and self.branch_streams:
+                mine, later = self._lower_upadd_bwd_split(op)
+                bwd_groups.append(mine)
+                deferred += later
+            else:
+                bwd_groups.append(self._lower_bwd(op))
         # gradient buckets for data-parallel training: the backward list finishes the decoder branches first and their
         # parameters are the tail of the slab, so their all-reduce can run under the encoder's backward pass
         first_enc = next((i for i, op in enumerate(P.bwd) if not op.name.startswith("decoder.")), len(P.bwd))
         self._bwd_split = sum(len(g) for g in bwd_groups[:first_enc])
+        tags = [self._set_of(op.name, True) for op in P.bwd]
+        bwd_groups.insert(first_enc, deferred)          # the branches' sums into shared buffers: after the join, in list order
+        tags.insert(first_enc, -1)
+        self.bwd_ops = self._lower(bwd_groups)
+        self._bwd_runs = self._runs(tags, bwd_groups)
+        assert not self.branch_streams or all(hi <= self._bwd_split for k, lo, hi in self._bwd_runs if k >= 0)
+        self._use_x3()
         dec_keys = [k for k in self._poff if k.startswith("decoder.")]
         self._dec_off = min(self._poff[k] for k in dec_keys)
         self.det_ws = self.loss_parts = None
         if self.deterministic:
             lib = L.lib()
             need = max(int(lib.hvn_train_workspace_bytes(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), self.n)), 64)
-            self.det_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            self.det_ws = [torch.empty((need + 3) // 4, dtype=torch.float32, device=dev) for _ in range(self._nsets)]
             ho = P.geo["out"]
             self.loss_parts = torch.empty(max(int(lib.hvn_loss_partials_count(self.n, ho, ho)), 64), dtype=torch.float64, device=dev)
         self._loss = self._loss_desc()
@@ -308,8 +332,8 @@ class TrainEngine:
                 if op.dx:
                     t = -(-op.x.h // 4) * -(-op.x.w // 4)
                     v, m = max(v, 64 * t * op.y.c), max(m, 64 * t * op.x.c)
-        self.wino_v = torch.empty(self.n * v, dtype=torch.float32, device=self.device)
-        self.wino_m = torch.empty(self.n * m, dtype=torch.float32, device=self.device)
+        self.wino_v = [torch.empty(self.n * v, dtype=torch.float32, device=self.device) for _ in range(self._nsets)]
+        self.wino_m = [torch.empty(self.n * m, dtype=torch.float32, device=self.device) for _ in range(self._nsets)]
 
     @staticmethod
     def _tview(ptr, t1, h, c):
@@ -318,15 +342,35 @@ class TrainEngine:
         v.base, v.sn, v.sy, v.sx, v.h, v.w, v.c, v.sc = ptr, 64 * t1 * c, t1 * c, c, h, t1, c, 1
         return v
 
-    def _wino_conv(self, xin, yout, pad, wptr, lead, accumulate, vbuf=None):
+    def _set_of(self, name, tag=False):
+        """Scratch set / stream of an op: the decoder branch's index with branch streams on, else 0 (tag=True: -1 for ops outside the
+        decoder branches -- the sections of `_runs`)."""
+        if self.branch_streams and name.startswith("decoder."):
+            return self.branches.index(name.split(".")[1])
+        return -1 if tag else 0
+
+    @staticmethod
+    def _runs(tags, groups):
+        """[(tag, first launch, end launch)] for the maximal runs of equal tags over the lowered groups."""
+        runs, pos = [], 0
+        for t, g in zip(tags, groups):
+            if len(g):
+                if runs and runs[-1][0] == t:
+                    runs[-1][2] = pos + len(g)
+                else:
+                    runs.append([t, pos, pos + len(g)])
+            pos += len(g)
+        return [tuple(r) for r in runs]
+
+    def _wino_conv(self, xin, yout, pad, wptr, lead, accumulate, vbuf=None, scr=0):
         """WINO_IN -> 64 batched GEMMs on the conv kernel -> WINO_OUT for one 5x5 stride-1 convolution of the view
-        `xin` (hvn_view, zero padding `pad`) into the view `yout`."""
+        `xin` (hvn_view, zero padding `pad`) into the view `yout`; `scr`: the scratch set (branch stream) it runs on."""
         ty, tx = -(-yout.h // 4), -(-yout.w // 4)
         t1, cin, cout = ty * tx, xin.c, yout.c
 
         def tview(ptr, h, c):
             return self._tview(ptr, t1, h, c)
-        vp, mp = (self.wino_v if vbuf is None else vbuf).data_ptr(), self.wino_m.data_ptr()
+        vp, mp = (self.wino_v[scr] if vbuf is None else vbuf).data_ptr(), self.wino_m[scr].data_ptr()
         ops = [self._net(kind=OP_WINO_IN, kh=ty, kw=tx, stride=4, _rsv=5, pad_t=pad, pad_l=pad, x=xin, y=tview(vp, 64, cin), w=self._bt_ptr)]
         g = dict(kind=OP_CONV, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, relu=0, cout=cout, tile_n=_tile_n(cout), groups=1,
                  x=tview(vp, 1, cin), y=tview(mp, 1, cout), w=wptr, nbatch=64)
@@ -374,7 +418,7 @@ class TrainEngine:
         if op.kind == "conv" and self._is_wino(self.plan.convs[op.wkey]) and op.stride == 1 and op.res is None:
             off, lead = self._pack_off[(op.wkey, 3)]
             return self._wino_conv(self._view(op.x), self._view(op.y), op.pad[0], self.packs.data_ptr() + 4 * off, lead, False,
-                                   vbuf=self.wino_vs.get(op.wkey))
+                                   vbuf=self.wino_vs.get(op.wkey), scr=self._set_of(op.name))
         if op.kind == "conv":
             kw = dict(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=op.stride, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.y.c,
                       tile_n=_tile_n(op.y.c), groups=op.groups, x=self._view(op.x), y=self._view(op.y),
@@ -387,7 +431,7 @@ class TrainEngine:
             t.kind = T_BN_FWD
             t.x, t.y = self._view(op.z), self._view(op.a)
             k = op.bnkey
-            t.p[0] = self.bn_ws.data_ptr()
+            t.p[0] = self.bn_ws[self._set_of(op.name)].data_ptr()
             t.p[1] = self.bn_save.data_ptr() + 4 * self._bn_save_off[k]
             t.p[2], t.p[3] = self.wptr(k + ".weight"), self.wptr(k + ".bias")
             t.p[4], t.p[5] = self._buffers[k + ".running_mean"].data_ptr(), self._buffers[k + ".running_var"].data_ptr()
@@ -416,11 +460,11 @@ class TrainEngine:
             k = op.bnkey
             t.kind = T_BN_BWD
             t.x, t.y, t.dy, t.dx = self._view(op.z), self._view(op.a), self._view(op.da), self._view(op.dz)
-            t.p[0] = self.bn_ws.data_ptr()
+            t.p[0] = self.bn_ws[self._set_of(op.name)].data_ptr()
             t.p[1] = self.bn_save.data_ptr() + 4 * self._bn_save_off[k]
             t.p[2] = self.wptr(k + ".weight")
             t.p[3], t.p[4] = self.gptr(k + ".weight"), self.gptr(k + ".bias")
-            t.p[5] = self.bn_coef.data_ptr()
+            t.p[5] = self.bn_coef[self._set_of(op.name)].data_ptr()
             t.mode = 1 if (self.first_store and op.store) else 0          # grad z = instead of += (first writer of the step)
             return [t]
         if op.kind == "wgrad" and op.wkey in self._du_off and op.stride == 1:
@@ -429,14 +473,15 @@ class TrainEngine:
             t1, cin, cout = ty * tx, op.x.c, op.dy.c
             du = self.wino_du.data_ptr() + 4 * self._du_off[op.wkey]
             t.kind, t.kh, t.kw = T_WINO_DY, ty, tx
-            t.x, t.y = self._view(op.dy), self._tview(self.wino_m.data_ptr(), t1, 64, cout)
+            wm = self.wino_m[self._set_of(op.name)].data_ptr()
+            t.x, t.y = self._view(op.dy), self._tview(wm, t1, 64, cout)
             t.p[0] = self._at_ptr
             g = L.hvn_top()
             g.kind, g.kh, g.kw, g.stride, g.groups, g.nbatch = T_WGRAD, 1, 1, 1, 1, 64
             g.mode = static_wgrad_target(1, 1) if self.deterministic else 0
             g._pad = self.wgrad_x3
             g.x = self._tview(self.wino_vs[op.wkey].data_ptr(), t1, 1, cin)
-            g.dy = self._tview(self.wino_m.data_ptr(), t1, 1, cout)
+            g.dy = self._tview(wm, t1, 1, cout)
             g.p[0] = du
             g.batch_stride[0], g.batch_stride[1], g.batch_stride[2] = t1 * cin, t1 * cout, cout * cin
             w = L.hvn_top()
@@ -454,7 +499,7 @@ class TrainEngine:
         if op.kind == "dgrad" and self._is_wino(self.plan.convs[op.wkey]):
             off, lead = self._pack_off[(op.wkey, 4)]
             return self._wino_conv(self._view(op.dy), self._view(op.dx), op.pad[0], self.packs.data_ptr() + 4 * off, lead,
-                                   not (self.first_store and op.store))
+                                   not (self.first_store and op.store), scr=self._set_of(op.name))
         if op.kind == "dgrad":
             dx = self._view(op.dx)
             kw = dict(kind=OP_CONV, kh=op.kh, kw=op.kw, stride=1, pad_t=op.pad[0], pad_l=op.pad[0], relu=0, cout=op.dx.c,
@@ -474,6 +519,23 @@ class TrainEngine:
             t.p[0] = self.gptr(op.wkey)
             return [t]
         raise KeyError(op.kind)
+
+    def _lower_upadd_bwd_split(self, op):
+        """`upadd_bwd` of a decoder branch with branch streams: -> (launches of the branch's own section, deferred launches).  The
+        low-resolution input of u2 / u1 belongs to the branch (its gradient is needed at once); the skips (d0 .. d2) and conv_bot's
+        output are shared by the branches: those sums wait for the join."""
+        def private(v):
+            return v is not None and v.buf.name.startswith("decoder.")
+        mine, later = [], []
+        for keep, dst in ((private, mine), (lambda v: v is not None and not private(v), later)):
+            dlo, dskip = (op.dlo if keep(op.dlo) else None), (op.dskip if keep(op.dskip) else None)
+            if dlo is None and dskip is None:
+                continue
+            t = L.hvn_top()
+            t.kind = T_UPADD_BWD
+            t.dy, t.dx, t.y = self._view(op.dy), self._view(dlo), self._view(dskip)
+            dst.append(t)
+        return mine, later
 
     def _lower(self, groups):
         flat = [t for g in groups for t in g]
@@ -642,18 +704,50 @@ class TrainEngine:
         if self.net.nr_types is not None:
             put(self.true_tp, torch.squeeze(torch.as_tensor(batch["tp_map"])).reshape(self.true_tp.shape), torch.int32)
 
-    def _run_plan(self, ops_addr, n_ops, what):
-        """One hvn_top list on this engine's stream; with the deterministic-reduce workspace when the engine has one."""
+    def _run_plan(self, ops_addr, n_ops, what, scr=0):
+        """One hvn_top list on the current stream; with the deterministic-reduce workspace (of scratch set `scr`) when the engine has one."""
         lib = L.lib()
         if self.det_ws is not None:
-            rc = lib.hvn_run_train_plan_ws(ops_addr, n_ops, self.n, self._stream(), self.det_ws.data_ptr(), 4 * self.det_ws.numel())
+            ws = self.det_ws[scr]
+            rc = lib.hvn_run_train_plan_ws(ops_addr, n_ops, self.n, self._stream(), ws.data_ptr(), 4 * ws.numel())
         else:
             rc = lib.hvn_run_train_plan(ops_addr, n_ops, self.n, self._stream())
         if rc:
             raise L.HvnError("hvn_run_train_plan(%s) failed (%d): %s" % (what, rc, lib.hvn_train_last_error().decode()))
 
+    def _run_range(self, ops, runs, lo, hi, what):
+        """Launches [lo, hi) of a lowered list: sections tagged with a branch (`_runs`) on that branch's stream -- branch 0 on the
+        current one -- between a fork and a join, everything else on the current stream in list order."""
+        base, osz = ctypes.addressof(ops), ctypes.sizeof(L.hvn_top)
+        main = torch.cuda.current_stream(self.device)
+        runs = [(k, max(a, lo), min(b, hi)) for k, a, b in runs if max(a, lo) < min(b, hi)]
+        i = 0
+        while i < len(runs):
+            k, a, b = runs[i]
+            if k < 0 or not self.branch_streams:
+                self._run_plan(base + a * osz, b - a, what)
+                i += 1
+                continue
+            j = i
+            while j < len(runs) and runs[j][0] >= 0:
+                j += 1
+            used = []
+            for k, a, b in sorted(runs[i:j], key=lambda r: -r[0]):       # side streams first, branch 0 on the current stream last
+                if k == 0:
+                    self._run_plan(base + a * osz, b - a, what)
+                    continue
+                side = self._side[k - 1]
+                if side not in used:
+                    side.wait_stream(main)
+                    used.append(side)
+                with torch.cuda.stream(side):
+                    self._run_plan(base + a * osz, b - a, what, scr=k)
+            for side in used:
+                main.wait_stream(side)
+            i = j
+
     def forward(self):
-        self._run_plan(ctypes.addressof(self.fwd_ops), len(self.fwd_ops), "forward")
+        self._run_range(self.fwd_ops, self._fwd_runs, 0, len(self.fwd_ops), "forward")
         torch._foreach_add_(self._nbt, 1)
         self.net._train_version = getattr(self.net, "_train_version", 0) + 1    # invalidates the cached inference plan
         return self.logits
@@ -679,11 +773,11 @@ class TrainEngine:
         rc = lib.hvn_loss_backward(ctypes.byref(self._loss), s)
         if rc:
             raise L.HvnError("hvn_loss_backward failed (%d): %s" % (rc, lib.hvn_train_last_error().decode()))
-        base, osz, n = ctypes.addressof(self.bwd_ops), ctypes.sizeof(L.hvn_top), len(self.bwd_ops)
+        n = len(self.bwd_ops)
 
         def run(lo, hi):
             if hi > lo:
-                self._run_plan(base + lo * osz, hi - lo, "backward")
+                self._run_range(self.bwd_ops, self._bwd_runs, lo, hi, "backward")
 
         split = self._bwd_split
         if all_reduce is None:
@@ -714,7 +808,7 @@ class TrainEngine:
                 buf.zero_()
             else:
                 buf.copy_(g.to(buf.dtype).reshape(buf.shape))
-        self._run_plan(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), "backward")
+        self._run_range(self.bwd_ops, self._bwd_runs, 0, len(self.bwd_ops), "backward")
         return self.gslab
 
     def loss_and_backward(self, world=1, all_reduce=None):
