@@ -122,6 +122,17 @@ class TrainEngine:
         self.branch_streams = os.environ.get("HVN_TRAIN_BRANCH_STREAMS", "1") != "0"
         self._nsets = len(self.branches) if self.branch_streams else 1
         self._side = [torch.cuda.Stream(device=dev) for _ in range(self._nsets - 1)]
+        # Weight-gradient streams (round 6): a conv's weight gradient and its data gradient are independent, and nothing in the backward
+        # pass waits for a weight gradient -- every plain `wgrad` launch floats on a second stream of its section, from the moment its
+        # output gradient is complete (an event) to the first later launch that writes that gradient's buffer again (`_floats`: the
+        # residual sums and the dense blocks' concats are accumulated further), at the latest the section's join.  Own deterministic-
+        # reduce workspace per stream; same launches, same bits.  Measured (profiles/r06_wgrad_stream_ab.txt): phase 1 (batch 4, every
+        # layer trains) 42.8 -> 39.2 ms, phase 0 (batch 16, frozen encoder: launches that fill the chip alone) 61.3 -> 62.9 ms -- so the
+        # default `HVN_TRAIN_WGRAD_STREAM=auto` times the backward list both ways once at engine build (`_choose_wgrad_stream`; the bits
+        # do not depend on the answer); 1 / 0 force it on / in list order on the section's stream.
+        self._wgrad_mode = os.environ.get("HVN_TRAIN_WGRAD_STREAM", "auto")
+        self.wgrad_stream = self._wgrad_mode != "0"
+        self._wside = [torch.cuda.Stream(device=dev) for _ in range(self._nsets)] if self.wgrad_stream else []
         self.bn_ws = [torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev) for _ in range(self._nsets)]     # HVN_BN_MAX_PARTS partial sums
         self.bn_coef = [torch.empty(3 * cmax, dtype=torch.float32, device=dev) for _ in range(self._nsets)]
         self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
@@ -156,6 +167,7 @@ class TrainEngine:
         tags.insert(first_enc, -1)
         self.bwd_ops = self._lower(bwd_groups)
         self._bwd_runs = self._runs(tags, bwd_groups)
+        self._floats = self._floating_wgrads(bwd_groups, first_enc) if self.wgrad_stream else {}
         assert not self.branch_streams or all(hi <= self._bwd_split for k, lo, hi in self._bwd_runs if k >= 0)
         self._use_x3()
         dec_keys = [k for k in self._poff if k.startswith("decoder.")]
@@ -165,11 +177,13 @@ class TrainEngine:
             lib = L.lib()
             need = max(int(lib.hvn_train_workspace_bytes(ctypes.addressof(self.bwd_ops), len(self.bwd_ops), self.n)), 64)
             self.det_ws = [torch.empty((need + 3) // 4, dtype=torch.float32, device=dev) for _ in range(self._nsets)]
+            self.det_ws_w = [torch.empty((need + 3) // 4, dtype=torch.float32, device=dev) for _ in self._wside]
             ho = P.geo["out"]
             self.loss_parts = torch.empty(max(int(lib.hvn_loss_partials_count(self.n, ho, ho)), 64), dtype=torch.float64, device=dev)
         self._loss = self._loss_desc()
         self.last_terms = None
         self.autotune_tiles()
+        self._choose_wgrad_stream()
 
     # -- parameter / gradient slabs ------------------------------------------------------------------
     def _build_slabs(self):
@@ -520,6 +534,32 @@ class TrainEngine:
             return [t]
         raise KeyError(op.kind)
 
+    def _floating_wgrads(self, bwd_groups, first_enc):
+        """{launch index of a plain weight-gradient launch: launch index it must have finished before (None: the section's join)} --
+        the first later op of the backward list that WRITES the buffer its output gradient lives in (a deferred `upadd_bwd` sum runs
+        later than its op's position: the position is the conservative bound).  Winograd-domain weight gradients stay in list order
+        (they share the transform-domain scratch with the data gradients)."""
+        bwd = self.plan.bwd
+        starts, pos = [], 0
+        for g in bwd_groups:
+            starts.append(pos)
+            pos += len(g)
+
+        def group(pi):
+            return pi if pi < first_enc else pi + 1        # the deferred group sits at `first_enc`
+        out = {}
+        for pi, op in enumerate(bwd):
+            if op.kind != "wgrad" or (op.wkey in self._du_off and op.stride == 1):
+                continue
+            assert len(bwd_groups[group(pi)]) == 1
+            buf, dead = op.dy.buf, None
+            for pj in range(pi + 1, len(bwd)):
+                if any(getattr(bwd[pj], k, None) is not None and getattr(bwd[pj], k).buf is buf for k in ("dx", "dz", "dlo", "dskip")):
+                    dead = starts[group(pj)]
+                    break
+            out[starts[group(pi)]] = dead
+        return out
+
     def _lower_upadd_bwd_split(self, op):
         """`upadd_bwd` of a decoder branch with branch streams: -> (launches of the branch's own section, deferred launches).  The
         low-resolution input of u2 / u1 belongs to the branch (its gradient is needed at once); the skips (d0 .. d2) and conv_bot's
@@ -630,6 +670,30 @@ class TrainEngine:
         self.gmem.zero_()       # the data-gradient and weight-gradient launches accumulate
         self._share_launch_shapes()
 
+    def _choose_wgrad_stream(self, reps=2):
+        """HVN_TRAIN_WGRAD_STREAM=auto: the whole backward list timed with the weight gradients floating and in list order (on whatever
+        the arenas hold, like `autotune_tiles`; the forward list is not run: it would move the running statistics), the faster one kept.
+        Every rank may answer for itself: the answer changes no bit."""
+        if self._wgrad_mode != "auto" or not self._floats or os.environ.get("HVN_TILE_SELECT", "auto") == "0":
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = {}
+        for on in (True, False):
+            self.wgrad_stream = on
+            best = float("inf")
+            for r in range(_tune_reps(reps) + 1):
+                e0.record()
+                self._run_range(self.bwd_ops, self._bwd_runs, 0, len(self.bwd_ops), "backward (timing)")
+                e1.record()
+                e1.synchronize()
+                if r:
+                    best = min(best, e0.elapsed_time(e1))
+            ms[on] = best
+        self.wgrad_stream = ms[True] < 0.985 * ms[False]          # a tie keeps the list order (fewer events, fewer host calls)
+        self.wgrad_stream_ms = (ms[True], ms[False])
+        torch.cuda.synchronize(self.device)
+        self.gmem.zero_()
+
     def _share_launch_shapes(self):
         """Data-parallel training: every rank times its own launches, and noise could give two ranks different weight-gradient splits,
         i.e. different fp32 summation orders of the same gradient (harmless after the all-reduce, but run-to-run variation nobody asked
@@ -704,16 +768,49 @@ class TrainEngine:
         if self.net.nr_types is not None:
             put(self.true_tp, torch.squeeze(torch.as_tensor(batch["tp_map"])).reshape(self.true_tp.shape), torch.int32)
 
-    def _run_plan(self, ops_addr, n_ops, what, scr=0):
-        """One hvn_top list on the current stream; with the deterministic-reduce workspace (of scratch set `scr`) when the engine has one."""
+    def _run_plan(self, ops_addr, n_ops, what, scr=0, w=False):
+        """One hvn_top list on the current stream; with the deterministic-reduce workspace (of scratch set `scr`; w: of that set's
+        weight-gradient stream) when the engine has one."""
         lib = L.lib()
         if self.det_ws is not None:
-            ws = self.det_ws[scr]
+            ws = (self.det_ws_w if w else self.det_ws)[scr]
             rc = lib.hvn_run_train_plan_ws(ops_addr, n_ops, self.n, self._stream(), ws.data_ptr(), 4 * ws.numel())
         else:
             rc = lib.hvn_run_train_plan(ops_addr, n_ops, self.n, self._stream())
         if rc:
             raise L.HvnError("hvn_run_train_plan(%s) failed (%d): %s" % (what, rc, lib.hvn_train_last_error().decode()))
+
+    def _run_section(self, ops, a, b, what, scr=0):
+        """Launches [a, b) of a lowered list on the current stream, its floating weight gradients (`_floats`, backward list only) on the
+        weight-gradient stream of scratch set `scr` between their two events; joined before returning."""
+        base, osz = ctypes.addressof(ops), ctypes.sizeof(L.hvn_top)
+        fl = self._floats if (ops is self.bwd_ops and self.wgrad_stream) else {}
+        mine = [i for i in fl if a <= i < b]
+        if not mine:
+            return self._run_plan(base + a * osz, b - a, what, scr)
+        S, W = torch.cuda.current_stream(self.device), self._wside[scr]
+        cuts = sorted(set(mine) | {fl[i] for i in mine if fl[i] is not None and fl[i] < b})
+        pos, pending = a, {}
+        for c in cuts + [b]:
+            if c > pos:
+                self._run_plan(base + pos * osz, c - pos, what, scr)
+            pos = c
+            if c == b:
+                break
+            for ev in pending.pop(c, ()):                    # the launch at c writes a buffer a floating weight gradient reads
+                S.wait_event(ev)
+            if c in fl:
+                ready = torch.cuda.Event()
+                ready.record(S)                              # its output gradient is complete
+                W.wait_event(ready)
+                with torch.cuda.stream(W):
+                    self._run_plan(base + c * osz, 1, what, scr, w=True)
+                    if fl[c] is not None and fl[c] < b:
+                        done = torch.cuda.Event()
+                        done.record(W)
+                        pending.setdefault(fl[c], []).append(done)
+                pos = c + 1
+        S.wait_stream(W)
 
     def _run_range(self, ops, runs, lo, hi, what):
         """Launches [lo, hi) of a lowered list: sections tagged with a branch (`_runs`) on that branch's stream -- branch 0 on the
@@ -725,7 +822,7 @@ class TrainEngine:
         while i < len(runs):
             k, a, b = runs[i]
             if k < 0 or not self.branch_streams:
-                self._run_plan(base + a * osz, b - a, what)
+                self._run_section(ops, a, b, what)
                 i += 1
                 continue
             j = i
@@ -734,14 +831,14 @@ class TrainEngine:
             used = []
             for k, a, b in sorted(runs[i:j], key=lambda r: -r[0]):       # side streams first, branch 0 on the current stream last
                 if k == 0:
-                    self._run_plan(base + a * osz, b - a, what)
+                    self._run_section(ops, a, b, what)
                     continue
                 side = self._side[k - 1]
                 if side not in used:
                     side.wait_stream(main)
                     used.append(side)
                 with torch.cuda.stream(side):
-                    self._run_plan(base + a * osz, b - a, what, scr=k)
+                    self._run_section(ops, a, b, what, scr=k)
             for side in used:
                 main.wait_stream(side)
             i = j

@@ -612,14 +612,16 @@ def test_first_writer_stores_give_the_bits_of_the_accumulating_step(mode, nt, fr
     sd = synth_state_dict(mode, nt, seed=12)
     batch = synth_train_batch(n, mode, nt, seed=44)
 
-    def run(first_store, streams="1"):
+    def run(first_store, streams="1", wstream="1"):
         monkeypatch.setenv("HVN_TRAIN_FIRST_STORE", first_store)
         monkeypatch.setenv("HVN_TRAIN_BRANCH_STREAMS", streams)
+        monkeypatch.setenv("HVN_TRAIN_WGRAD_STREAM", wstream)
         net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3, freeze=freeze)
         net.load_state_dict(sd, strict=True)
         eng = TrainEngine(net.to("cuda"), n, deterministic=True)
         assert eng.first_store == (first_store == "1") and eng.branch_streams == (streams == "1")
         assert len(eng._side) == ((3 if nt else 2) - 1 if streams == "1" else 0)
+        assert eng.wgrad_stream == (wstream == "1") and (len(eng._floats) > 40) == (wstream == "1")
         if streams == "1":          # every branch has its section in both lists, and the shared sums sit behind the decoder's bucket boundary
             assert sorted(k for k, _, _ in eng._fwd_runs if k >= 0) == sorted(k for k, _, _ in eng._bwd_runs if k >= 0) == list(range(3 if nt else 2))
         if eng.first_store:
@@ -632,11 +634,13 @@ def test_first_writer_stores_give_the_bits_of_the_accumulating_step(mode, nt, fr
         return eng.gslab.clone(), eng.sums.clone(), {k: v.clone() for k, v in eng.dlogits.items()}
 
     g1, s1, d1 = run("1")
-    g0, s0, d0 = run("0", streams="0")
+    g0, s0, d0 = run("0", streams="0", wstream="0")
     # ... and the decoder branches on their own streams (round 6) against one stream: what the branches add to shared gradient buffers runs
-    # after the join in the single-stream order, everything else a branch writes is its own
-    g2, s2, d2 = run("1", streams="0")
-    assert torch.equal(g2, g1) and torch.equal(s2, s1) and all(torch.equal(d2[k], d1[k]) for k in d1)
+    # after the join in the single-stream order, everything else a branch writes is its own; and the weight gradients floating on a second
+    # stream per section between the event that completes their output gradient and the next writer of its buffer
+    for streams, wstream in (("0", "1"), ("1", "0")):
+        g2, s2, d2 = run("1", streams=streams, wstream=wstream)
+        assert torch.equal(g2, g1) and torch.equal(s2, s1) and all(torch.equal(d2[k], d1[k]) for k in d1), (streams, wstream)
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
     assert torch.equal(s1, s0)
     for k in d0:

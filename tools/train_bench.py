@@ -109,6 +109,8 @@ def measure(phase, steps=10, warmup=3, mode="original", nt=5, device="cuda", see
            "algorithmic_speedup": (af + ab) / (ef + eb),
            "timed_conv_launches": int(n_conv), "timed_conv_launch_ms": conv_ms, "timed_conv_launch_share_of_step": conv_ms / ms,
            "plan_ops_per_step": len(eng.fwd_ops) + len(eng.bwd_ops), "deterministic_reduce": bool(eng.deterministic),
+           "first_writer_stores": bool(eng.first_store), "branch_streams": bool(eng.branch_streams), "wgrad_stream": bool(eng.wgrad_stream),
+           "wgrad_stream_timed_ms_on_off": [round(v, 3) for v in getattr(eng, "wgrad_stream_ms", ())],
            "gradient_slab_mb": slab_mb, "world_size": world,
            "loss": eng.loss_terms()["overall_loss"], "arena_gb": eng.arena.numel() * 4 / 1e9, "grad_gb": eng.gmem.numel() * 4 / 1e9}
     if world > 1:
@@ -171,7 +173,9 @@ def main():
                           "algorithmic_speedup": (af + ab) / (ef + eb),
                           "mfma_frac_of_step": (ef + eb) / ms / 1e9 / PEAK_FP32_MATRIX_TFLOPS,
                           "mfma_frac_note": "executed MFMA FLOPs / whole step time / 157.3 TFLOP/s: a LOWER bound of the conv kernels' fraction",
-                          "gradient_slab_mb": slab_mb,
+                          "gradient_slab_mb": slab_mb, "plan_ops_per_step": len(eng.fwd_ops) + len(eng.bwd_ops),
+                          "first_writer_stores": bool(eng.first_store), "branch_streams": bool(eng.branch_streams), "wgrad_stream": bool(eng.wgrad_stream),
+                          "wgrad_stream_timed_ms_on_off": [round(v, 3) for v in getattr(eng, "wgrad_stream_ms", ())],
                           "allreduce": "not measurable on one GPU: N > 1 all-reduces the gradient slab (%.0f MB fp32) in two buckets + 64 doubles of "
                                        "loss partial sums per step; no RCCL run exists for it (one-GPU box)" % slab_mb,
                           "conv_tiles": {"launch_shapes_timed": sum(1 for k in train_engine._TILE_CHOICE if k[0] == bs),
