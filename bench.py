@@ -818,7 +818,8 @@ def main():
                 legs, what="BASELINE cfg 5 on %d GPU(s): one training step (forward in train mode, the reference's loss table, backward, FusedAdam) of "
                            "phase 0 (frozen encoder, batch 16 per GPU) and phase 1 (all layers, batch 4 per GPU), CoNSeP '%s' mode, %s types, "
                            "synthetic batch; 5 steps after 2 warm-up steps each; deterministic cross-workgroup sums (round 6 default; "
-                           "atomic_reduce_ms_per_step = the same step with fp32 atomics and timed weight-gradient splits); N > 1: SUM all-reduce of the loss partial sums and of the "
+                           "atomic_reduce_ms_per_step = the same step with fp32 atomics and timed weight-gradient splits); first-writer stores, the decoder branches on their own "
+                           "streams and floating weight gradients as each leg's first_writer_stores / branch_streams / wgrad_stream say (round 6, bit-identical to the single-stream step); N > 1: SUM all-reduce of the loss partial sums and of the "
                            "gradient slab in two buckets inside the step (ms_per_step = slowest rank)" % (world, args.mode, nt))
     if world > 1 and (args.wsi_leg or not args.no_variants) and not args.no_wsi_leg:
         # BASELINE cfg 4 on all ranks (round-5 verdict, next #4: the row-slab + halo all_to_all path of infer_wsi.py never ran in a bench):

@@ -29,8 +29,10 @@ timeout 300 python tools/layer_ms.py 2>/dev/null | grep -v amdgpu.ids > gpurun_o
 timeout 400 python bench.py --dtype bf16 --mode fast --nr-types 6 --batch 64 --steps 10 --warmup 2 --no-cpu-baseline --no-variants --no-traffic > gpurun_out/${R}_bench_cfg3_fast_b64_bf16.json 2>/dev/null
 timeout 200 python tools/layer_ms.py --dtype bf16 --mode fast --nr-types 6 --batch 64 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${R}_layers_cfg3_bf16.txt
 for ph in 0 1; do
-  CMD="python tools/train_bench.py --steps 4 --warmup 2 --phase $ph"
+  # one stream (round 6's branch / weight-gradient streams off): under concurrency overlapped kernels' durations inflate; the default step is timed right after
+  CMD="env HVN_TRAIN_BRANCH_STREAMS=0 HVN_TRAIN_WGRAD_STREAM=0 python tools/train_bench.py --steps 4 --warmup 2 --phase $ph"
   timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_tprof$ph -o r -- $CMD 2>/dev/null | grep "^{" > gpurun_out/${R}_train_profiled_phase$ph.json
+  timeout 300 python tools/train_bench.py --steps 8 --warmup 3 --phase $ph 2>/dev/null | grep "^{" > gpurun_out/${R}_train_default_phase$ph.json
   tdb=$(find gpurun_out/${R}_tprof$ph -name "*_results.db" | head -1)
   python tools/kernel_stats.py $tdb "rocprofv3 --kernel-trace --stats -- $CMD" > gpurun_out/${R}_train_kernel_stats_phase$ph.csv 2>/dev/null
   python tools/train_roofline.py $tdb gpurun_out/${R}_train_profiled_phase$ph.json 6 > gpurun_out/${R}_train_roofline_phase$ph.json 2>/dev/null
