@@ -48,6 +48,20 @@ def _tune_reps(default):
     return max(1, int(os.environ.get("HVN_TUNE_REPS", default)))
 
 
+_STREAMS = {}
+
+
+def _shared_streams(device, role, count):
+    """The step's side streams, ONE set per process and device shared by every engine (engines run from one host thread, never
+    concurrently): HIP multiplexes streams onto a few hardware queues, and a process that makes five new streams per engine -- a fit, then
+    phase 0, then phase 1 -- ends up with two streams of one step on the same queue, i.e. without the concurrency they exist for (measured:
+    phase 1 inside bench.py after the bench's own fit 41.4 ms, in a fresh process 37.6)."""
+    have = _STREAMS.setdefault((str(device), role), [])
+    while len(have) < count:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:count]
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 
@@ -121,7 +135,7 @@ class TrainEngine:
         self.branches = arch.branch_names(net.nr_types)
         self.branch_streams = os.environ.get("HVN_TRAIN_BRANCH_STREAMS", "1") != "0"
         self._nsets = len(self.branches) if self.branch_streams else 1
-        self._side = [torch.cuda.Stream(device=dev) for _ in range(self._nsets - 1)]
+        self._side = _shared_streams(dev, "side", self._nsets - 1)
         # Weight-gradient streams (round 6): a conv's weight gradient and its data gradient are independent, and nothing in the backward
         # pass waits for a weight gradient -- every plain `wgrad` launch floats on a second stream of its section, from the moment its
         # output gradient is complete (an event) to the first later launch that writes that gradient's buffer again (`_floats`: the
@@ -132,7 +146,7 @@ class TrainEngine:
         # do not depend on the answer); 1 / 0 force it on / in list order on the section's stream.
         self._wgrad_mode = os.environ.get("HVN_TRAIN_WGRAD_STREAM", "auto")
         self.wgrad_stream = self._wgrad_mode != "0"
-        self._wside = [torch.cuda.Stream(device=dev) for _ in range(self._nsets)] if self.wgrad_stream else []
+        self._wside = _shared_streams(dev, "wgrad", self._nsets) if self.wgrad_stream else []
         self.bn_ws = [torch.zeros(256 * 2 * cmax, dtype=torch.float64, device=dev) for _ in range(self._nsets)]     # HVN_BN_MAX_PARTS partial sums
         self.bn_coef = [torch.empty(3 * cmax, dtype=torch.float32, device=dev) for _ in range(self._nsets)]
         self.bn_save = torch.empty(sum(4 * c for c in P.bns.values()), dtype=torch.float32, device=dev)
