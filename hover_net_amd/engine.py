@@ -56,6 +56,17 @@ def pick_tile_n(op, batch):
     return 64 if narrow < wide else 128
 
 
+_STREAM_POOL, _STREAM_CHOICE = {}, {}   # device -> [streams]; (device, sub-batches, lanes, dtype) -> (pool offset, {offset: ms})
+
+
+def lane_stream_pool(device, count):
+    """The inference engines' side streams: one list per process and device, grown on demand, never replaced (see Engine.autotune_streams)."""
+    have = _STREAM_POOL.setdefault(str(device), [])
+    while len(have) < count:
+        have.append(torch.cuda.Stream(device))
+    return have
+
+
 _TILE_CACHE = {}        # device -> {launch shape key: (choice, ms of the default, ms of the choice, {candidate: ms})}
 X3G_256, X3G_128 = 128 + 0x300, 128 + 0x200     # hvn_op.tile_n of the LDS-DMA forms of the bf16x3 convolution (include/hvn.h)
 X3R = 128 + 0x400                               # hvn_op.tile_n of the bf16x3 CHAIN with a register-resident input tile (include/hvn.h)
@@ -161,6 +172,7 @@ class Engine:
         self.n_lane_streams = int(os.environ.get("HVN_LANES", dflt[1])) if n_lanes is None else int(n_lanes)  # extra streams for the decoder branches (0: one launch stream)
         self.split_decoder = os.environ.get("HVN_SPLIT_DECODER", "0") != "0"
         self._streams = None
+        self._stream_off = 0
         self._upload_params()
         self.arena = torch.empty((self.max_batch, plan.arena_per_sample), dtype=torch.float32 if dtype == "fp32" else torch.int16,
                                  device=self.device)
@@ -192,6 +204,8 @@ class Engine:
             self.autotune_tiles()
         elif dtype == "bf16" and os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and os.environ.get("HVN_BF16G", "1") != "0":
             self.autotune_bf16_forms()
+        if os.environ.get("HVN_TILE_SELECT", "auto") == "auto" and os.environ.get("HVN_STREAM_SELECT", "1") != "0":
+            self.autotune_streams()
 
     # ---------------------------------------------------------------------------------
     def _upload_params(self):
@@ -321,6 +335,43 @@ class Engine:
             o.post_scale, o.post_shift = self._pptr(i, "post_s"), self._pptr(i, "post_b")
 
     # ---------------------------------------------------------------------------------
+    def autotune_streams(self, reps=3):
+        """Which streams of the process-wide pool this engine's launch schedule runs on (round 6).  HIP multiplexes a process's streams
+        onto a few hardware queues in creation order, and two lanes of one step that share a queue run one after the other: with k idle
+        streams created before the engine's own, the cfg-2 network step measured 41.5 / 42.4 / 41.7 / 43.4 / 41.5 ms for k = 0 .. 4 against
+        42.4 on one stream (`profiles/r06_stream_map_probe.txt`) -- the schedule's gain depended on what the process had done before (in
+        bench.py: a fit).  So the streams come from one pool per process and device (`lane_stream_pool`), and the engine times its whole
+        schedule on the pool's four rotations once per (device, schedule) and process; outputs do not depend on the answer
+        (tests/test_gpu_chain.py: every schedule gives the same bits)."""
+        split = self.n_split if (self.n_split > 1 and self.max_batch >= 2 * self.n_split) else 1
+        need = (split - 1) + split * self.n_lane_streams
+        if need == 0 or self.plan.ops[0].kind != PL.OP_CONV0 or not getattr(self.plan, "geo", None):
+            return
+        g = int(self.plan.geo.get("inp", 0))
+        if g <= 0:
+            return
+        key = (str(self.device), split, self.n_lane_streams, self.dtype)
+        if key not in _STREAM_CHOICE:
+            import os
+            reps = max(1, int(os.environ.get("HVN_TUNE_REPS", reps)))
+            imgs = torch.zeros((self.max_batch, g, g, 3), dtype=torch.uint8, device=self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ms = {}
+            for off in range(4):
+                self._stream_off, self._streams = off, None
+                best = float("inf")
+                for r in range(reps + 1):
+                    e0.record()
+                    self.run(imgs)
+                    self.run(imgs)
+                    e1.record()
+                    e1.synchronize()
+                    if r:
+                        best = min(best, e0.elapsed_time(e1) / 2)
+                ms[off] = best
+            _STREAM_CHOICE[key] = (min(ms, key=ms.get), ms)
+        self._stream_off, self._streams = _STREAM_CHOICE[key][0], None
+
     def autotune_tiles(self, reps=3, margin=0.985):
         """Measured column-tile selection (the default; `HVN_TILE_SELECT=model` keeps `pick_tile_n`'s rounds model): every
         re-tileable CONV launch is timed once per distinct shape with 128x128 and with 128x64 tiles at this engine's batch
@@ -581,7 +632,7 @@ class Engine:
         n_lane = self.n_lane_streams
         need = (split - 1) + split * n_lane
         if self._streams is None or len(self._streams) < need:
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(need)]
+            self._streams = lane_stream_pool(self.device, self._stream_off + need)[self._stream_off:self._stream_off + need]
         lane_pool = self._streams[split - 1:]
         lanes = getattr(self.plan, "lanes", None)
         enc_end = lanes[0][2] if (lanes and lanes[0][0] == "main" and len(lanes) > 1) else 0
