@@ -22,7 +22,10 @@ def main():
             torch.zeros(1, device="cuda")
     torch.cuda.synchronize()
     out = []
-    for sched in (None, (1, 0)):
+    scheds = (None, (1, 0))
+    if len(sys.argv) > 2:               # e.g. "2,1 1,2 1,3 2,0": sub-batches,lanes per schedule
+        scheds = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[2:])
+    for sched in scheds:
         net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
         net.load_state_dict(synth_state_dict("original", 5, seed=0), strict=True)
         net.max_batch = 32
@@ -44,6 +47,9 @@ def main():
         del net
     from hover_net_amd import engine as E
     pick = {k_[1:3]: (v[0], {o: round(m, 2) for o, m in v[1].items()}) for k_, v in E._STREAM_CHOICE.items()}
+    if len(sys.argv) > 2:
+        print("idle streams created first: %d   " % k + "   ".join("schedule %s %.2f ms" % (a, t) for a, t in zip(sys.argv[2:], out)) + "   pool offsets: %s" % pick, flush=True)
+        return
     print("idle streams created first: %d   network step default schedule %.2f ms   single stream %.2f ms   pool offset timed at engine build: %s" % (
         k, out[0], out[1], pick), flush=True)
 
