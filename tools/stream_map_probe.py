@@ -26,13 +26,15 @@ def main():
     if len(sys.argv) > 2:               # e.g. "2,1 1,2 1,3 2,0": sub-batches,lanes per schedule
         scheds = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[2:])
     for sched in scheds:
-        net = net_desc.create_model(mode="original", nr_types=5, input_ch=3)
-        net.load_state_dict(synth_state_dict("original", 5, seed=0), strict=True)
-        net.max_batch = 32
+        mode, nt, bs = os.environ.get("PROBE_MODE", "original"), int(os.environ.get("PROBE_TYPES", "5")), int(os.environ.get("PROBE_BATCH", "32"))
+        net = net_desc.create_model(mode=mode, nr_types=nt, input_ch=3)
+        net.load_state_dict(synth_state_dict(mode, nt, seed=0), strict=True)
+        net.max_batch = bs
+        net.compute_dtype = os.environ.get("PROBE_DTYPE", "fp32")      # PROBE_MODE=fast PROBE_TYPES=6 PROBE_BATCH=64 PROBE_DTYPE=bf16: cfg 3
         if sched is not None:
             net.launch_schedule = sched
         net = net.to("cuda").eval()
-        tiles = torch.from_numpy(synth_tiles(32, 270, seed=1)).to("cuda")
+        tiles = torch.from_numpy(synth_tiles(bs, 270 if mode == "original" else 256, seed=1)).to("cuda")
         for _ in range(3):
             run_desc.infer_step_device(tiles, net)
         torch.cuda.synchronize()
