@@ -562,16 +562,12 @@ class TrainEngine:
         def group(pi):
             return pi if pi < first_enc else pi + 1        # the deferred group sits at `first_enc`
         out = {}
-        for pi, op in enumerate(bwd):
-            if op.kind != "wgrad" or (op.wkey in self._du_off and op.stride == 1):
+        for pi, pj in self.plan.wgrad_windows().items():
+            op = bwd[pi]
+            if op.wkey in self._du_off and op.stride == 1:
                 continue
             assert len(bwd_groups[group(pi)]) == 1
-            buf, dead = op.dy.buf, None
-            for pj in range(pi + 1, len(bwd)):
-                if any(getattr(bwd[pj], k, None) is not None and getattr(bwd[pj], k).buf is buf for k in ("dx", "dz", "dlo", "dskip")):
-                    dead = starts[group(pj)]
-                    break
-            out[starts[group(pi)]] = dead
+            out[starts[group(pi)]] = None if pj is None else starts[group(pj)]
         return out
 
     def _lower_upadd_bwd_split(self, op):

@@ -340,6 +340,23 @@ class TrainPlan:
                 first(op.dlo, False)
                 first(op.dskip, False)
 
+    def wgrad_windows(self):
+        """{index of a `wgrad` op in `bwd`: index of the first later op that WRITES the buffer its output gradient `dy` lives in, or None}.
+        A weight gradient reads x (an activation: never written in the backward pass) and dy, and nothing in the backward pass reads what it
+        writes -- so it may run on another stream from the moment dy is complete (the ops before it) to that later writer (the residual
+        sums and the dense blocks' concats are accumulated further; a BN's grad z is not): `train_engine._floating_wgrads`."""
+        out = {}
+        for i, op in enumerate(self.bwd):
+            if op.kind != "wgrad":
+                continue
+            buf, dead = op.dy.buf, None
+            for j in range(i + 1, len(self.bwd)):
+                if any(getattr(self.bwd[j], k, None) is not None and getattr(self.bwd[j], k).buf is buf for k in ("dx", "dz", "dlo", "dskip")):
+                    dead = j
+                    break
+            out[i] = dead
+        return out
+
     # -- memory ----------------------------------------------------------------------------------
     def layout(self, n):
         """Assign element offsets for batch `n` -> (data elements, grad elements); 64-element (256 B) aligned.  The gradient buffers

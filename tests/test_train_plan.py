@@ -108,3 +108,29 @@ def test_first_writer_rule_is_sound(mode, nt, freeze):
         assert a1 <= b0 and b0 % 64 == 0
     assert all(z for o, _, z in spans if o < P.gzero_elems) and not any(z for o, _, z in spans if o >= P.gzero_elems)
     assert spans[-1][1] <= gelems and P.gzero_elems < 0.3 * gelems and n_store > 100
+
+
+@pytest.mark.parametrize("mode,nt,freeze", [("original", 5, False), ("original", 5, True), ("fast", None, False)])
+def test_weight_gradient_windows_hold_no_writer_of_their_output_gradient(mode, nt, freeze):
+    """train_plan.wgrad_windows (what lets a weight gradient run on a second stream, train_engine._floating_wgrads): between a `wgrad`
+    op and the end of its window no op writes the buffer its dy lives in, the op at the end of the window does, dy has a writer BEFORE the
+    weight gradient (its dy is complete when the ops in front of it are)."""
+    P = TrainPlan(mode, nt, freeze)
+    win = P.wgrad_windows()
+    assert len(win) == sum(1 for op in P.bwd if op.kind == "wgrad") > 50
+
+    def written(op):
+        return {id(getattr(op, k).buf) for k in ("dx", "dz", "dlo", "dskip") if getattr(op, k, None) is not None}
+    open_ended = 0
+    for i, j in win.items():
+        g = id(P.bwd[i].dy.buf)
+        end = len(P.bwd) if j is None else j
+        assert all(g not in written(P.bwd[k]) for k in range(i + 1, end)), P.bwd[i].name
+        if j is None:
+            open_ended += 1
+        else:
+            assert j > i and g in written(P.bwd[j]), P.bwd[i].name
+        assert any(g in written(P.bwd[k]) for k in range(i)), P.bwd[i].name            # its dy was produced by an earlier op of the list
+    # a BN's grad z has one writer: the weight gradients of the convs in front of a BN float to the join; the ones reading a residual sum or a
+    # dense block's concat end at the next accumulation into it
+    assert open_ended > 30 and open_ended < len(win)
