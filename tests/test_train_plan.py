@@ -134,3 +134,12 @@ def test_weight_gradient_windows_hold_no_writer_of_their_output_gradient(mode, n
     # a BN's grad z has one writer: the weight gradients of the convs in front of a BN float to the join; the ones reading a residual sum or a
     # dense block's concat end at the next accumulation into it
     assert open_ended > 30 and open_ended < len(win)
+
+
+def test_section_runs_of_the_lowered_lists():
+    """train_engine.TrainEngine._runs: maximal runs of equal section tags over lowered groups, in launch indices (empty groups -- an
+    `upadd_bwd` whose sums are all deferred -- neither break nor start a run)."""
+    from hover_net_amd.train_engine import TrainEngine
+    runs = TrainEngine._runs([-1, -1, 0, 0, 0, 1, 1, -1, -1], [[1], [1, 2], [1], [], [1, 1], [1], [1, 1, 1], [], [1, 2, 3]])
+    assert runs == [(-1, 0, 3), (0, 3, 6), (1, 6, 10), (-1, 10, 13)]
+    assert TrainEngine._runs([], []) == [] and TrainEngine._runs([2], [[]]) == []
