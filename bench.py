@@ -801,18 +801,21 @@ def main():
 
         torch.cuda.empty_cache()
         legs = {}
-        for ph in (0, 1):
-            r_ = train_bench.measure(ph, steps=5, warmup=2, mode=args.mode, nt=nt, device=dev)
-            if world == 1:          # the same step with rounds 1-5's reduce (fp32 atomics, timed weight-gradient splits): what determinism costs
-                a_ = train_bench.measure(ph, steps=3, warmup=2, mode=args.mode, nt=nt, device=dev, deterministic=False)
-                r_["atomic_reduce_ms_per_step"] = a_["ms_per_step"]
-            if world > 1:
-                allr = [None] * world
-                dist.all_gather_object(allr, {k: r_[k] for k in ("ms_per_step", "forward_ms", "loss_backward_ms", "optimizer_ms", "allreduce_slab_alone_ms")})
-                r_["per_rank"] = allr
-                r_["ms_per_step"] = max(a_["ms_per_step"] for a_ in allr)
-                r_["tiles_per_s"] = world * r_["batch"] * 1000.0 / r_["ms_per_step"]
-            legs["phase%d" % ph] = r_
+        try:
+            for ph in (0, 1):
+                r_ = train_bench.measure(ph, steps=5, warmup=2, mode=args.mode, nt=nt, device=dev)
+                if world == 1:          # the same step with rounds 1-5's reduce (fp32 atomics, timed weight-gradient splits): what determinism costs
+                    a_ = train_bench.measure(ph, steps=3, warmup=2, mode=args.mode, nt=nt, device=dev, deterministic=False)
+                    r_["atomic_reduce_ms_per_step"] = a_["ms_per_step"]
+                if world > 1:
+                    allr = [None] * world
+                    dist.all_gather_object(allr, {k: r_[k] for k in ("ms_per_step", "forward_ms", "loss_backward_ms", "optimizer_ms", "allreduce_slab_alone_ms")})
+                    r_["per_rank"] = allr
+                    r_["ms_per_step"] = max(a_["ms_per_step"] for a_ in allr)
+                    r_["tiles_per_s"] = world * r_["batch"] * 1000.0 / r_["ms_per_step"]
+                legs["phase%d" % ph] = r_
+        except Exception as e:       # an optional leg must not cost the run its headline line.  (A code error fails alike on every rank; a rank
+            legs = {"error": "%s: %s" % (type(e).__name__, e)}       # failing alone leaves the others in a collective -- no guard here helps that.)
         if rank == 0:
             result.setdefault("variants", {})["train_step"] = dict(
                 legs, what="BASELINE cfg 5 on %d GPU(s): one training step (forward in train mode, the reference's loss table, backward, FusedAdam) of "
