@@ -830,10 +830,15 @@ def main():
         import wsi_bench
 
         torch.cuda.empty_cache()
-        mine = wsi_bench.measure_dist(args.wsi_size, args.mode, nt, args.batch, device=dev)
+        try:
+            mine = wsi_bench.measure_dist(args.wsi_size, args.mode, nt, args.batch, device=dev)
+        except Exception as e:       # as for the training leg: reported, not fatal (a failure on every rank alike; the gather below still pairs up)
+            mine = {"error": "%s: %s" % (type(e).__name__, e)}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
-        if rank == 0:
+        if rank == 0 and any("error" in a_ for a_ in allr):
+            result.setdefault("variants", {})["wsi_%dk" % (args.wsi_size // 1024)] = {"error": [a_.get("error") for a_ in allr]}
+        elif rank == 0:
             s1, s2 = max(a_["stage1_s"] for a_ in allr), max(a_["stage2_s"] for a_ in allr)
             n_p = sum(a_["patches"] for a_ in allr)
             result.setdefault("variants", {})["wsi_%dk" % (args.wsi_size // 1024)] = {
